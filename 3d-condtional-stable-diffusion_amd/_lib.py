@@ -1,0 +1,105 @@
+"""ctypes binding of libdm3d_hip.so (C ABI declared in include/dm3d.h).
+
+The product path has no fallback: if the shared library is missing or a call fails, this module raises.  Build it with
+``__graft_entry__.build()`` or ``make -C 3d-condtional-stable-diffusion_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdm3d_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
+COUT_PAD, CIN_PAD = 64, 16
+
+_f32p = C.c_void_p      # device pointers travel as integers
+_i32p = C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("x1", _f32p), ("x2", _f32p), ("c1", C.c_int32), ("c2", C.c_int32), ("batch", C.c_int32),
+        ("in_d", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32), ("upsample", C.c_int32),
+        ("ksize", C.c_int32), ("stride", C.c_int32), ("wpk", _f32p), ("bias", _f32p),
+        ("pro_scale", _f32p), ("pro_shift", _f32p), ("vec", _f32p), ("vec_idx", _i32p), ("vec_ld", C.c_int32),
+        ("relu", C.c_int32), ("res", _f32p), ("out", _f32p), ("cout", C.c_int32),
+    ]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("a", _f32p), ("lda", C.c_int64), ("stride_a", C.c_int64),
+        ("b", _f32p), ("ldb", C.c_int64), ("stride_b", C.c_int64),
+        ("out", _f32p), ("ldo", C.c_int64), ("stride_o", C.c_int64),
+        ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("batch", C.c_int32),
+        ("alpha", C.c_float), ("bias", _f32p), ("bias_along_m", C.c_int32), ("act", C.c_int32),
+        ("res", _f32p), ("ldr", C.c_int64), ("stride_r", C.c_int64),
+    ]
+
+
+class DdpmDesc(C.Structure):
+    _fields_ = [
+        ("x", _f32p), ("eps", _f32p), ("noise", _f32p), ("batch", C.c_int32), ("per_sample", C.c_int64),
+        ("t", _i32p), ("timesteps", C.c_int32),
+        ("beta", _f32p), ("sqrt_alpha", _f32p), ("alpha_bar", _f32p), ("alpha_bar_prev", _f32p),
+        ("sqrt_alpha_bar", _f32p), ("sqrt_alpha_bar_prev", _f32p), ("sqrt_one_minus_alpha_bar", _f32p),
+        ("seed", C.c_uint64), ("mode", C.c_int32), ("mean_out", _f32p), ("var_out", _f32p),
+    ]
+
+
+# name -> (restype, argtypes): every symbol include/dm3d.h declares
+SIGNATURES = {
+    "dm3d_version": (C.c_int, []),
+    "dm3d_last_error": (C.c_char_p, []),
+    "dm3d_device_ok": (C.c_int, []),
+    "dm3d_packed_weight_elems": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "dm3d_pack_weights": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, _f32p, _f32p, C.c_void_p]),
+    "dm3d_conv3d_ndhwc": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "dm3d_gemm_tn": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "dm3d_layernorm3": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_float] + [_f32p] * 9 + [C.c_void_p]),
+    "dm3d_softmax_rows": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]),
+    "dm3d_affine_act": (C.c_int, [_f32p, _f32p, C.c_int64, C.c_int32, _f32p, _f32p, C.c_int32, C.c_void_p]),
+    "dm3d_ddpm_update": (C.c_int, [C.POINTER(DdpmDesc), C.c_void_p]),
+    "dm3d_add_i32": (C.c_int, [_i32p, C.c_int32, C.c_int32, C.c_void_p]),
+    "dm3d_randn": (C.c_int, [_f32p, C.c_int64, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "dm3d_gather_rows": (C.c_int, [_f32p, C.c_int32, _i32p, _f32p, C.c_int32, C.c_int32, C.c_void_p]),
+    "dm3d_graph_begin": (C.c_int, [C.c_void_p]),
+    "dm3d_graph_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "dm3d_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dm3d_graph_destroy": (C.c_int, [C.c_void_p]),
+}
+
+_lib = None
+
+
+class Dm3dError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Dm3dError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. There is no CPU or PyTorch fallback; "
+                "run `python -c 'import __graft_entry__ as g; g.build()'` at the repo root.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the ABI lost a symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().dm3d_last_error()
+        raise Dm3dError(f"{what or 'dm3d call'} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def require_device() -> None:
+    if not lib().dm3d_device_ok():
+        raise Dm3dError("no gfx950 (MI355X) device is visible: the dm3d kernels have no CPU path")

@@ -1,0 +1,261 @@
+// dm3d_conv.hip — Conv3D(padding="same") on NDHWC float32 as an implicit GEMM on v_mfma_f32_32x32x2_f32.
+//
+// Replaces layers.Conv3D / UpSampling3D+Conv3D / Concatenate+Conv3D and the BatchNormalization+swish in front of them
+// (reference networks/conditional_dm3d.py:238-296, 348-353, 410-414).  GEMM view: M = batch*Dout*Hout*Wout output
+// voxels, N = Cout, K = k^3 * Cin.
+//
+// One workgroup (256 threads = 4 waves) owns a TD x TH x TW brick of output voxels times 64 output channels.
+//   for each 16-channel chunk of Cin:
+//       stage the brick's input halo ((TD-1)*S+k) x ((TH-1)*S+k) x ((TW-1)*S+k) voxels x 16 channels into LDS once,
+//       applying the fused prologue silu(x*scale+shift) and the zero padding on the way in;
+//       for each of the k^3 taps: stream that tap's [64 cout][16 cin] weight slice into a double-buffered LDS slot
+//       (one barrier per tap) and issue the MFMAs; a tap only shifts the LDS read address of the A operand.
+// Every input element is fetched from HBM/L2 once per workgroup and chunk (halo overhead 2.3x for a 4x8x8 brick) instead
+// of k^3 times, and activation tensors are read in their raw form, so norm/activation/concat/upsample never round-trip
+// through HBM.  LDS: 600*20*4 + 2*64*20*4 = 58 KB -> two workgroups per CU, whose staging and MFMA phases overlap.
+#include "dm3d_common.h"
+
+namespace {
+
+struct ConvArgs {
+    const float* x1; const float* x2; int c1, c2;
+    int ind, inh, inw;        // physical input extent
+    int lgd, lgh, lgw;        // logical extent seen by the conv (2x when upsampling)
+    int od, oh, ow;
+    int ups, pad;             // pad = zero voxels in front of index 0 (TF SAME)
+    const float* wpk; int cinpad, coutpad;
+    const float* bias; const float* pscale; const float* pshift;
+    const float* vec; const int* vec_idx; int vec_ld;
+    int relu; const float* res; float* out; int cout;
+    int bd, bh, bw;           // bricks per volume along d, h, w
+    int nchunks;
+};
+
+template <int TD, int TH, int TW, int S, int KS, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv3d_igemm_f32(const ConvArgs p) {
+    constexpr int CK = 16, LDV = CK + 4, NT = 64;
+    constexpr int TM = TD * TH * TW;
+    constexpr int HD = (TD - 1) * S + KS, HH = (TH - 1) * S + KS, HW = (TW - 1) * S + KS;
+    constexpr int HVOX = HD * HH * HW;
+    constexpr int TAPS = KS * KS * KS;
+    constexpr int MR = TM / WM / 32, NR = NT / WN / 32;
+    constexpr int NTHR = WM * WN * 64;
+    constexpr int NSLOT = (HVOX * 4 + NTHR - 1) / NTHR;
+    static_assert(NTHR == 256, "kernel assumes 4 waves");
+    static_assert(TM % (WM * 32) == 0 && NT % (WN * 32) == 0, "tile split");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* lds_in = smem;                       // [HVOX][LDV]
+    float* lds_w = smem + HVOX * LDV;           // [2][NT][LDV]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // brick -> (sample, origin)
+    int brick = blockIdx.x;
+    const int bpv = p.bd * p.bh * p.bw;
+    const int b = brick / bpv;
+    brick -= b * bpv;
+    const int oz0 = (brick / (p.bh * p.bw)) * TD;
+    const int oy0 = ((brick / p.bw) % p.bh) * TH;
+    const int ox0 = (brick % p.bw) * TW;
+    const int n0 = blockIdx.y * NT;
+
+    // staging slots: this thread copies float4 piece `piece` of halo voxels hv0 + j*64
+    const int piece = tid & 3;
+    int gvox[NSLOT];
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+        const int hv = (tid >> 2) + j * (NTHR / 4);
+        int g = -1;
+        if (hv < HVOX) {
+            const int hz = hv / (HH * HW), hy = (hv / HW) % HH, hx = hv % HW;
+            const int iz = oz0 * S - p.pad + hz, iy = oy0 * S - p.pad + hy, ix = ox0 * S - p.pad + hx;
+            if (iz >= 0 && iz < p.lgd && iy >= 0 && iy < p.lgh && ix >= 0 && ix < p.lgw) {
+                const int pz = p.ups ? (iz >> 1) : iz, py = p.ups ? (iy >> 1) : iy, px = p.ups ? (ix >> 1) : ix;
+                g = ((b * p.ind + pz) * p.inh + py) * p.inw + px;
+            }
+        }
+        gvox[j] = g;
+    }
+
+    // per-lane LDS row bases (floats) for the A operand of each 32-row tile, tap (0,0,0)
+    const float* a_base[MR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+        const int r = wm * (TM / WM) + mr * 32 + l32;
+        const int dz = r / (TH * TW), dy = (r / TW) % TH, dx = r % TW;
+        a_base[mr] = lds_in + ((dz * S * HH + dy * S) * HW + dx * S) * LDV;
+    }
+    int b_off[NR];
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) b_off[nr] = (wn * (NT / WN) + nr * 32 + l32) * LDV;
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.0f;
+
+    // weight slice (tap, chunk): row n = tid>>2 of 64, float4 piece tid&3 of the 16 input channels
+    const float* w_thread = p.wpk + (size_t)(n0 + (tid >> 2)) * p.cinpad + piece * 4;
+    const size_t w_tap_stride = (size_t)p.coutpad * p.cinpad;
+    const int w_lds_off = (tid >> 2) * LDV + piece * 4;
+    f32x4 wreg = *reinterpret_cast<const f32x4*>(w_thread);      // (tap 0, chunk 0)
+
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        const int c0 = ch * CK;
+        const float* src;
+        int ldc, cb;
+        if (c0 < p.c1) { src = p.x1; ldc = p.c1; cb = c0; } else { src = p.x2; ldc = p.c2; cb = c0 - p.c1; }
+        const bool chan_ok = cb + piece * 4 < ldc;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        const bool pro = p.pscale != nullptr;
+        if (pro && chan_ok) {
+            sc = *reinterpret_cast<const f32x4*>(p.pscale + c0 + piece * 4);
+            sh = *reinterpret_cast<const f32x4*>(p.pshift + c0 + piece * 4);
+        }
+        f32x4 hval[NSLOT];
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gvox[j] >= 0 && chan_ok) {
+                v = *reinterpret_cast<const f32x4*>(src + (size_t)gvox[j] * ldc + cb + piece * 4);
+                if (pro) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = dm3d_silu(fmaf(v[e], sc[e], sh[e]));
+                }
+            }
+            hval[j] = v;
+        }
+        __syncthreads();                        // every wave is done with the previous chunk's halo and weight slots
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            const int hv = (tid >> 2) + j * (NTHR / 4);
+            if (hv < HVOX) *reinterpret_cast<f32x4*>(lds_in + hv * LDV + piece * 4) = hval[j];
+        }
+        *reinterpret_cast<f32x4*>(lds_w + w_lds_off) = wreg;
+        __syncthreads();
+
+        for (int tap = 0; tap < TAPS; ++tap) {
+            // prefetch the next weight slice (next tap, or tap 0 of the next chunk)
+            const bool last_tap = tap + 1 == TAPS;
+            if (!last_tap)
+                wreg = *reinterpret_cast<const f32x4*>(w_thread + (size_t)(tap + 1) * w_tap_stride + c0);
+            else if (ch + 1 < p.nchunks)
+                wreg = *reinterpret_cast<const f32x4*>(w_thread + c0 + CK);
+
+            const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
+            const int tap_off = ((kd * HH + kh) * HW + kw) * LDV;
+            const float* wbuf = lds_w + (tap & 1) * (NT * LDV);
+            const float* a_lds[MR];
+            const float* b_lds[NR];
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) a_lds[mr] = a_base[mr] + tap_off;
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) b_lds[nr] = wbuf + b_off[nr];
+            dm3d_mma_step<MR, NR, CK>(acc, a_lds, b_lds, half);
+
+            if (!last_tap) {
+                *reinterpret_cast<f32x4*>(lds_w + ((tap + 1) & 1) * (NT * LDV) + w_lds_off) = wreg;
+                __syncthreads();
+            }
+        }
+    }
+
+    // epilogue: + bias + vec[row(b)] -> relu -> + res -> store.  Lanes 0..31 cover 32 consecutive output channels.
+    const int vrow = p.vec ? (p.vec_idx ? p.vec_idx[b] : b) : 0;
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int n = n0 + wn * (NT / WN) + nr * 32 + l32;
+        if (n >= p.cout) continue;
+        float add = p.bias ? p.bias[n] : 0.0f;
+        if (p.vec) add += p.vec[(size_t)vrow * p.vec_ld + n];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * (TM / WM) + mr * 32 + dm3d_acc_row(r, half);
+                const int oz = oz0 + row / (TH * TW), oy = oy0 + (row / TW) % TH, ox = ox0 + row % TW;
+                if (oz < p.od && oy < p.oh && ox < p.ow) {
+                    const size_t o = ((((size_t)b * p.od + oz) * p.oh + oy) * p.ow + ox) * p.cout + n;
+                    float v = acc[mr][nr][r] + add;
+                    if (p.relu) v = fmaxf(v, 0.0f);
+                    if (p.res) v += p.res[o];
+                    p.out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int TD, int TH, int TW, int S, int KS, int WM, int WN>
+int launch_conv(ConvArgs& a, int batch, hipStream_t st) {
+    constexpr int LDV = 20;
+    constexpr int HVOX = ((TD - 1) * S + KS) * ((TH - 1) * S + KS) * ((TW - 1) * S + KS);
+    constexpr size_t lds = (size_t)(HVOX * LDV + 2 * 64 * LDV) * sizeof(float);
+    a.bd = (a.od + TD - 1) / TD;
+    a.bh = (a.oh + TH - 1) / TH;
+    a.bw = (a.ow + TW - 1) / TW;
+    static bool attr_set = false;                       // one per instantiation
+    if (!attr_set) {
+        DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_f32<TD, TH, TW, S, KS, WM, WN>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64));
+    hipLaunchKernelGGL((conv3d_igemm_f32<TD, TH, TW, S, KS, WM, WN>), grid, dim3(256), lds, st, a);
+    return dm3d_launch_check("conv3d_igemm_f32");
+}
+
+}  // namespace
+
+extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
+    DM3D_REQUIRE(d != nullptr, "conv: null descriptor");
+    DM3D_REQUIRE(d->x1 && d->wpk && d->out, "conv: x1/wpk/out must be non-null");
+    DM3D_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv: ksize %d not in {1,3}", d->ksize);
+    DM3D_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride %d not in {1,2}", d->stride);
+    DM3D_REQUIRE(!(d->upsample && d->stride != 1), "conv: upsample requires stride 1");
+    DM3D_REQUIRE(!(d->ksize == 1 && (d->stride != 1 || d->upsample)), "conv: ksize 1 supports stride 1 without upsample only");
+    DM3D_REQUIRE(d->batch > 0 && d->in_d > 0 && d->in_h > 0 && d->in_w > 0 && d->cout > 0, "conv: non-positive extent");
+    DM3D_REQUIRE(d->c1 > 0 && d->c1 % 4 == 0 && d->c2 >= 0 && d->c2 % 4 == 0, "conv: c1=%d c2=%d must be multiples of 4", d->c1, d->c2);
+    DM3D_REQUIRE((d->c2 == 0) == (d->x2 == nullptr), "conv: x2 and c2 must be given together");
+    DM3D_REQUIRE(d->c2 == 0 || d->c1 % 16 == 0, "conv: with a second input c1=%d must be a multiple of 16", d->c1);
+    DM3D_REQUIRE((d->pro_scale == nullptr) == (d->pro_shift == nullptr), "conv: pro_scale and pro_shift go together");
+    DM3D_REQUIRE(!d->vec || d->vec_ld >= d->cout, "conv: vec_ld %d < cout %d", d->vec_ld, d->cout);
+    const void* ptrs[] = {d->x1, d->x2, d->wpk, d->pro_scale, d->pro_shift, d->out, d->res};
+    for (const void* q : ptrs) DM3D_REQUIRE(dm3d_aligned16(q), "conv: pointer %p is not 16-byte aligned", q);
+    const int64_t vox = (int64_t)d->batch * d->in_d * d->in_h * d->in_w * (d->upsample ? 8 : 1);
+    DM3D_REQUIRE(vox < (1ll << 31) / 4, "conv: %lld voxels overflow the 32-bit voxel index", (long long)vox);
+
+    ConvArgs a{};
+    a.x1 = d->x1; a.x2 = d->x2; a.c1 = d->c1; a.c2 = d->c2;
+    a.ind = d->in_d; a.inh = d->in_h; a.inw = d->in_w;
+    const int up = d->upsample ? 2 : 1;
+    a.lgd = d->in_d * up; a.lgh = d->in_h * up; a.lgw = d->in_w * up;
+    a.od = (a.lgd + d->stride - 1) / d->stride;
+    a.oh = (a.lgh + d->stride - 1) / d->stride;
+    a.ow = (a.lgw + d->stride - 1) / d->stride;
+    a.ups = d->upsample ? 1 : 0;
+    // TF SAME: total = max((out-1)*stride + k - in, 0), zeros in front = total/2.  For k=3: stride 1 -> 1; stride 2 -> 0 on
+    // even sizes and 1 on odd sizes.  The kernel uses one pad for all three axes, so mixed parity is rejected.
+    auto pad_front = [&](int in, int out) { int t = (out - 1) * d->stride + d->ksize - in; return t > 0 ? t / 2 : 0; };
+    a.pad = pad_front(a.lgd, a.od);
+    DM3D_REQUIRE(pad_front(a.lgh, a.oh) == a.pad && pad_front(a.lgw, a.ow) == a.pad,
+                 "conv: stride-2 SAME padding differs between axes (mixed odd/even extents)");
+    const int cin = d->c1 + d->c2;
+    a.cinpad = (int)dm3d_round_up(cin, DM3D_CIN_PAD);
+    a.coutpad = (int)dm3d_round_up(d->cout, DM3D_COUT_PAD);
+    a.nchunks = a.cinpad / 16;
+    a.wpk = d->wpk; a.bias = d->bias; a.pscale = d->pro_scale; a.pshift = d->pro_shift;
+    a.vec = d->vec; a.vec_idx = d->vec_idx; a.vec_ld = d->vec_ld;
+    a.relu = d->relu; a.res = d->res; a.out = d->out; a.cout = d->cout;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (d->ksize == 1) return launch_conv<4, 8, 8, 1, 1, 4, 1>(a, d->batch, st);
+    if (d->stride == 2) return launch_conv<2, 4, 8, 2, 3, 2, 2>(a, d->batch, st);
+    return launch_conv<4, 8, 8, 1, 3, 4, 1>(a, d->batch, st);
+}

@@ -1,0 +1,347 @@
+// dm3d_elem.hip — the HBM-bound companions of the conv/GEMM kernels: LayerNormalization, row softmax (wavefront
+// shuffle reductions), per-channel affine+activation, the DDPM posterior update with in-kernel Philox noise, and small
+// index utilities.  All accesses are 16 B per lane, coalesced.
+#include "dm3d_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- LayerNormalization: one wavefront per row, row kept in registers, up to three affine outputs ----------------
+__global__ __launch_bounds__(256) void layernorm3_kernel(const float* __restrict__ x, long rows, int c, float eps,
+                                                         const float* g1, const float* b1, float* o1,
+                                                         const float* g2, const float* b2, float* o2,
+                                                         const float* g3, const float* b3, float* o3) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = c >> 2;                          // float4 per row, <= 256
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * c);
+    f32x4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = lane + j * 64;
+        v[j] = (i < nv) ? xr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    }
+    const float mean = wave_sum(s) / (float)c;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (lane + j * 64 < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float dlt = v[j][e] - mean; q += dlt * dlt; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)c + eps);
+    const float* gs[3] = {g1, g2, g3};
+    const float* bs[3] = {b1, b2, b3};
+    float* os[3] = {o1, o2, o3};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (!os[k]) continue;
+        f32x4* orow = reinterpret_cast<f32x4*>(os[k] + row * c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = lane + j * 64;
+            if (i < nv) {
+                const f32x4 g = reinterpret_cast<const f32x4*>(gs[k])[i];
+                const f32x4 bb = reinterpret_cast<const f32x4*>(bs[k])[i];
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = (v[j][e] - mean) * rstd * g[e] + bb[e];
+                orow[i] = y;
+            }
+        }
+    }
+}
+
+// ---- softmax over the last axis, in place: one wavefront per row, max and sum by cross-lane shuffles --------------
+template <int NE>   // elements per lane kept in registers (cols <= 64*NE)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, long rows, int cols, long ld) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* r = s + row * ld;
+    float v[NE];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int i = lane + j * 64;
+        v[j] = (i < cols) ? r[i] : -INFINITY;
+        mx = fmaxf(mx, v[j]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        v[j] = (lane + j * 64 < cols) ? __expf(v[j] - mx) : 0.f;
+        sum += v[j];
+    }
+    const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int i = lane + j * 64;
+        if (i < cols) r[i] = v[j] * inv;
+    }
+}
+
+// long rows: three passes through L1/L2 (a row of a few thousand floats stays cached)
+__global__ __launch_bounds__(256) void softmax_rows_stream_kernel(float* __restrict__ s, long rows, int cols, long ld) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* r = s + row * ld;
+    float mx = -INFINITY;
+    for (int i = lane; i < cols; i += 64) mx = fmaxf(mx, r[i]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int i = lane; i < cols; i += 64) sum += __expf(r[i] - mx);
+    const float inv = 1.0f / wave_sum(sum);
+    for (int i = lane; i < cols; i += 64) r[i] = __expf(r[i] - mx) * inv;
+}
+
+// ---- y = act(x*scale[c] + shift[c]) ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, float* __restrict__ y, long n4,
+                                                         int c4, const float* scale, const float* shift, int act) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        const int cc = (int)(i % c4);
+        if (scale) {
+            const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[cc];
+            const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[cc];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = dm3d_act(v[e], act);
+        reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+}
+
+// ---- Philox4x32-10 + Box-Muller ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+// four N(0,1) draws for 128-bit counter (i_lo, i_hi, s0, s1) under key seed
+__device__ __forceinline__ f32x4 philox_normal4(uint64_t idx, uint32_t s0, uint32_t s1, uint64_t seed) {
+    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), s0, s1};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float u0 = ((float)c[0] + 0.5f) * 2.3283064365386963e-10f;   // (0,1]: float rounding can reach 1, log(1)=0 is fine
+    const float u1 = (float)c[1] * 2.3283064365386963e-10f;
+    const float u2 = ((float)c[2] + 0.5f) * 2.3283064365386963e-10f;
+    const float u3 = (float)c[3] * 2.3283064365386963e-10f;
+    const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+    float s_0, c_0, s_1, c_1;
+    sincosf(6.283185307179586f * u1, &s_0, &c_0);
+    sincosf(6.283185307179586f * u3, &s_1, &c_1);
+    return f32x4{r0 * c_0, r0 * s_0, r1 * c_1, r1 * s_1};
+}
+
+__global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ x, long n4, uint64_t seed, uint32_t stream_id) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+        reinterpret_cast<f32x4*>(x)[i] = philox_normal4((uint64_t)i, stream_id, 0x5eedu, seed);
+}
+
+// ---- DDPM posterior (reference conditional_dm3d.py:517-548) and loop body (:571-573), float32 in the written order -----
+struct DdpmArgs {
+    float* x; const float* eps; const float* noise;
+    int batch; long per4;                          // float4 per sample
+    const int* t;
+    const float *beta, *sqa, *ab, *abp, *sqab, *sqabp, *sq1ab;
+    uint64_t seed; int mode;
+    float* mean_out; float* var_out;
+};
+
+__global__ __launch_bounds__(256) void ddpm_kernel(const DdpmArgs p) {
+    const int b = blockIdx.y;
+    const int t = p.t[b];
+    const float be = p.beta[t], sqa = p.sqa[t], ab = p.ab[t], abp = p.abp[t];
+    const float sqab = p.sqab[t], sqabp = p.sqabp[t], sq1ab = p.sq1ab[t];
+    const float one_m_ab = __fsub_rn(1.0f, ab), one_m_abp = __fsub_rn(1.0f, abp);
+    const float c1 = __fdiv_rn(__fmul_rn(be, sqabp), one_m_ab);             // b*sqab_prev/(1-ab)
+    const float c2 = __fdiv_rn(__fmul_rn(one_m_abp, sqa), one_m_ab);        // (1-ab_prev)*sqa/(1-ab)
+    const float var = __fdiv_rn(__fmul_rn(one_m_abp, be), one_m_ab);        // (1-ab_prev)*b/(1-ab)
+    const float sigma = expf(__fmul_rn(0.5f, logf(fmaxf(var, 1e-20f))));    // tf.exp(0.5*np.log(np.maximum(var,1e-20)))
+    if (p.mode == 0 && p.var_out && blockIdx.x == 0 && threadIdx.x == 0) p.var_out[b] = var;
+    const long base = (long)b * p.per4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.per4; i += (long)gridDim.x * 256) {
+        const f32x4 x = reinterpret_cast<const f32x4*>(p.x)[base + i];
+        const f32x4 e = reinterpret_cast<const f32x4*>(p.eps)[base + i];
+        f32x4 mean;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float x0 = __fdiv_rn(__fsub_rn(x[k], __fmul_rn(sq1ab, e[k])), sqab);
+            mean[k] = __fadd_rn(__fmul_rn(c1, x0), __fmul_rn(c2, x[k]));
+        }
+        if (p.mode == 0) {
+            reinterpret_cast<f32x4*>(p.mean_out)[base + i] = mean;
+            continue;
+        }
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (t > 0) z = p.noise ? reinterpret_cast<const f32x4*>(p.noise)[base + i]
+                               : philox_normal4((uint64_t)(base + i), (uint32_t)t, 0xd1f0u, p.seed);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = __fadd_rn(fminf(fmaxf(mean[k], -1.0f), 1.0f), __fmul_rn(sigma, z[k]));
+        reinterpret_cast<f32x4*>(p.x)[base + i] = o;
+    }
+}
+
+__global__ void add_i32_kernel(int* p, int n, int delta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] += delta;
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, int table_rows,
+                                                          const int* __restrict__ idx, float* __restrict__ out,
+                                                          int rows, int c4) {
+    const long n = (long)rows * c4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / c4), cc = (int)(i % c4);
+        int src = idx[r];
+        src = src < 0 ? 0 : (src >= table_rows ? table_rows - 1 : src);      // clamp like tf.gather on GPU never faults
+        reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(table)[(long)src * c4 + cc];
+    }
+}
+
+// Keras [taps][cin][cout] -> [taps][coutpad][cinpad], optional per-input-channel scale
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int taps, int cin, int cout,
+                                                           int cinpad, int coutpad, const float* in_scale,
+                                                           float* __restrict__ out) {
+    const long n = (long)taps * coutpad * cinpad;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int ci = (int)(i % cinpad);
+        const int co = (int)((i / cinpad) % coutpad);
+        const int tap = (int)(i / ((long)cinpad * coutpad));
+        float v = 0.f;
+        if (ci < cin && co < cout) {
+            v = w[((long)tap * cin + ci) * cout + co];
+            if (in_scale) v *= in_scale[ci];
+        }
+        out[i] = v;
+    }
+}
+
+inline unsigned grid_for(long n, int cap = 256 * 8) {
+    long g = (n + 255) / 256;
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int dm3d_layernorm3(const float* x, int64_t rows, int32_t c, float eps,
+                               const float* g1, const float* b1, float* o1,
+                               const float* g2, const float* b2, float* o2,
+                               const float* g3, const float* b3, float* o3, void* stream) {
+    DM3D_REQUIRE(x && rows > 0, "layernorm: x null or rows <= 0");
+    DM3D_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, "layernorm: c=%d must be a multiple of 4 and <= 1024", c);
+    DM3D_REQUIRE(o1 || o2 || o3, "layernorm: no output");
+    DM3D_REQUIRE((!o1 || (g1 && b1)) && (!o2 || (g2 && b2)) && (!o3 || (g3 && b3)), "layernorm: output without gamma/beta");
+    const void* ptrs[] = {x, g1, b1, o1, g2, b2, o2, g3, b3, o3};
+    for (const void* q : ptrs) DM3D_REQUIRE(dm3d_aligned16(q), "layernorm: pointer %p is not 16-byte aligned", q);
+    hipLaunchKernelGGL(layernorm3_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x, (long)rows, c, eps, g1, b1, o1, g2, b2, o2, g3, b3, o3);
+    return dm3d_launch_check("layernorm3_kernel");
+}
+
+extern "C" int dm3d_softmax_rows(float* s, int64_t rows, int32_t cols, int64_t ld, void* stream) {
+    DM3D_REQUIRE(s && rows > 0 && cols > 0 && ld >= cols, "softmax: bad arguments rows=%lld cols=%d ld=%lld",
+                 (long long)rows, cols, (long long)ld);
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (cols <= 64) hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, block, 0, st, s, (long)rows, cols, (long)ld);
+    else if (cols <= 256) hipLaunchKernelGGL(softmax_rows_kernel<4>, grid, block, 0, st, s, (long)rows, cols, (long)ld);
+    else if (cols <= 512) hipLaunchKernelGGL(softmax_rows_kernel<8>, grid, block, 0, st, s, (long)rows, cols, (long)ld);
+    else if (cols <= 1024) hipLaunchKernelGGL(softmax_rows_kernel<16>, grid, block, 0, st, s, (long)rows, cols, (long)ld);
+    else hipLaunchKernelGGL(softmax_rows_stream_kernel, grid, block, 0, st, s, (long)rows, cols, (long)ld);
+    return dm3d_launch_check("softmax_rows_kernel");
+}
+
+extern "C" int dm3d_affine_act(const float* x, float* y, int64_t rows, int32_t c, const float* scale, const float* shift,
+                               int32_t act, void* stream) {
+    DM3D_REQUIRE(x && y && rows > 0 && c > 0 && c % 4 == 0, "affine_act: bad arguments (c=%d must be a multiple of 4)", c);
+    DM3D_REQUIRE((scale == nullptr) == (shift == nullptr), "affine_act: scale and shift go together");
+    DM3D_REQUIRE(act >= DM3D_ACT_NONE && act <= DM3D_ACT_SILU, "affine_act: unknown act %d", act);
+    DM3D_REQUIRE(dm3d_aligned16(x) && dm3d_aligned16(y) && dm3d_aligned16(scale) && dm3d_aligned16(shift),
+                 "affine_act: pointers must be 16-byte aligned");
+    const long n4 = (long)rows * (c / 4);
+    hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for(n4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n4,
+                       c / 4, scale, shift, act);
+    return dm3d_launch_check("affine_act_kernel");
+}
+
+extern "C" int dm3d_ddpm_update(const dm3d_ddpm_desc* d, void* stream) {
+    DM3D_REQUIRE(d != nullptr, "ddpm: null descriptor");
+    DM3D_REQUIRE(d->x && d->eps && d->t, "ddpm: x/eps/t must be non-null");
+    DM3D_REQUIRE(d->batch > 0 && d->batch <= 65535 && d->per_sample > 0 && d->per_sample % 4 == 0,
+                 "ddpm: batch=%d per_sample=%lld (must be a positive multiple of 4)", d->batch, (long long)d->per_sample);
+    DM3D_REQUIRE(d->beta && d->sqrt_alpha && d->alpha_bar && d->alpha_bar_prev && d->sqrt_alpha_bar &&
+                 d->sqrt_alpha_bar_prev && d->sqrt_one_minus_alpha_bar, "ddpm: a Betas table is null");
+    DM3D_REQUIRE(d->mode == 0 || d->mode == 1, "ddpm: mode %d not in {0,1}", d->mode);
+    DM3D_REQUIRE(d->mode == 1 || d->mean_out, "ddpm: mode 0 needs mean_out");
+    DM3D_REQUIRE(dm3d_aligned16(d->x) && dm3d_aligned16(d->eps) && dm3d_aligned16(d->noise) && dm3d_aligned16(d->mean_out),
+                 "ddpm: pointers must be 16-byte aligned");
+    DdpmArgs a{};
+    a.x = d->x; a.eps = d->eps; a.noise = d->noise; a.batch = d->batch; a.per4 = d->per_sample / 4; a.t = d->t;
+    a.beta = d->beta; a.sqa = d->sqrt_alpha; a.ab = d->alpha_bar; a.abp = d->alpha_bar_prev; a.sqab = d->sqrt_alpha_bar;
+    a.sqabp = d->sqrt_alpha_bar_prev; a.sq1ab = d->sqrt_one_minus_alpha_bar;
+    a.seed = d->seed; a.mode = d->mode; a.mean_out = d->mean_out; a.var_out = d->var_out;
+    dim3 grid(grid_for(a.per4, 256), (unsigned)d->batch);
+    hipLaunchKernelGGL(ddpm_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return dm3d_launch_check("ddpm_kernel");
+}
+
+extern "C" int dm3d_add_i32(int32_t* p, int32_t n, int32_t delta, void* stream) {
+    DM3D_REQUIRE(p && n > 0, "add_i32: bad arguments");
+    hipLaunchKernelGGL(add_i32_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), p, n, delta);
+    return dm3d_launch_check("add_i32_kernel");
+}
+
+extern "C" int dm3d_randn(float* x, int64_t n, uint64_t seed, uint32_t stream_id, void* stream) {
+    DM3D_REQUIRE(x && n > 0 && n % 4 == 0 && dm3d_aligned16(x), "randn: x null/unaligned or n=%lld not a positive multiple of 4", (long long)n);
+    hipLaunchKernelGGL(randn_kernel, dim3(grid_for(n / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, (long)(n / 4), seed, stream_id);
+    return dm3d_launch_check("randn_kernel");
+}
+
+extern "C" int dm3d_gather_rows(const float* table, int32_t table_rows, const int32_t* idx, float* out, int32_t rows,
+                                int32_t c, void* stream) {
+    DM3D_REQUIRE(table && idx && out && table_rows > 0 && rows > 0 && c > 0 && c % 4 == 0, "gather_rows: bad arguments");
+    DM3D_REQUIRE(dm3d_aligned16(table) && dm3d_aligned16(out), "gather_rows: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)rows * (c / 4))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       table, table_rows, idx, out, rows, c / 4);
+    return dm3d_launch_check("gather_rows_kernel");
+}
+
+extern "C" int64_t dm3d_packed_weight_elems(int32_t taps, int32_t cin, int32_t cout) {
+    if (taps <= 0 || cin <= 0 || cout <= 0) return 0;
+    return (int64_t)taps * dm3d_round_up(cout, DM3D_COUT_PAD) * dm3d_round_up(cin, DM3D_CIN_PAD);
+}
+
+extern "C" int dm3d_pack_weights(const float* keras_kernel, int32_t taps, int32_t cin, int32_t cout, const float* in_scale,
+                                 float* packed, void* stream) {
+    DM3D_REQUIRE(keras_kernel && packed && taps > 0 && cin > 0 && cout > 0, "pack_weights: bad arguments");
+    const int cinpad = (int)dm3d_round_up(cin, DM3D_CIN_PAD), coutpad = (int)dm3d_round_up(cout, DM3D_COUT_PAD);
+    const long n = (long)taps * cinpad * coutpad;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), keras_kernel,
+                       taps, cin, cout, cinpad, coutpad, in_scale, packed);
+    return dm3d_launch_check("pack_weights_kernel");
+}

@@ -1,0 +1,130 @@
+// dm3d_gemm.hip — batched float32 "TN" contraction on v_mfma_f32_32x32x2_f32:
+//     out[b][m][n] = act(alpha * sum_k A[b][m][k] * B[b][n][k] + bias) + res[b][m][n]
+// Replaces layers.Dense on the last axis, the 1x1 Conv3D projections of the attention blocks and the two attention
+// einsums (reference networks/conditional_dm3d.py:129-137, 164-180, 251, 301-304, 313; networks/dm3d.py:46-62).
+//
+// Workgroup = 256 threads (4 waves), tile 256 (m) x 64 (n), K in chunks of 32.  Both operand tiles are register-
+// prefetched one chunk ahead (global loads in flight during the MFMAs) and staged through one LDS buffer.
+#include "dm3d_common.h"
+
+namespace {
+
+struct GemmArgs {
+    const float* a; long lda, sa;
+    const float* b; long ldb, sb;
+    float* out; long ldo, so;
+    int m, n, k;
+    float alpha;
+    const float* bias; int bias_m; int act;
+    const float* res; long ldr, sr;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_f32(const GemmArgs p) {
+    constexpr int CK = 32, LDV = CK + 4, TM = 256, NT = 64, MR = 2, NR = 2;
+    constexpr int A_SLOTS = TM * (CK / 4) / 256;   // 8 float4 per thread
+    constexpr int B_SLOTS = NT * (CK / 4) / 256;   // 2
+    __shared__ __attribute__((aligned(16))) float lds_a[TM * LDV];
+    __shared__ __attribute__((aligned(16))) float lds_b[NT * LDV];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * NT, bz = blockIdx.z;
+    const float* A = p.a + (size_t)bz * p.sa;
+    const float* B = p.b + (size_t)bz * p.sb;
+
+    const int piece = tid & 7;                      // float4 piece of the 32-wide chunk
+    const int row0 = tid >> 3;                      // + j*32
+    f32x4 ra[A_SLOTS], rb[B_SLOTS];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto fetch = [&](int k0) {
+        const bool kok = k0 + piece * 4 < p.k;
+#pragma unroll
+        for (int j = 0; j < A_SLOTS; ++j) {
+            const int m = m0 + row0 + j * 32;
+            ra[j] = (kok && m < p.m) ? *reinterpret_cast<const f32x4*>(A + (size_t)m * p.lda + k0 + piece * 4) : zero4;
+        }
+#pragma unroll
+        for (int j = 0; j < B_SLOTS; ++j) {
+            const int n = n0 + row0 + j * 32;
+            rb[j] = (kok && n < p.n) ? *reinterpret_cast<const f32x4*>(B + (size_t)n * p.ldb + k0 + piece * 4) : zero4;
+        }
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.0f;
+
+    const float* a_lds[MR];
+    const float* b_lds[NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) a_lds[mr] = lds_a + (wave * 64 + mr * 32 + l32) * LDV;
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) b_lds[nr] = lds_b + (nr * 32 + l32) * LDV;
+
+    fetch(0);
+    for (int k0 = 0; k0 < p.k; k0 += CK) {
+        __syncthreads();                            // previous chunk's MFMAs have read the LDS tiles
+#pragma unroll
+        for (int j = 0; j < A_SLOTS; ++j) *reinterpret_cast<f32x4*>(lds_a + (row0 + j * 32) * LDV + piece * 4) = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_SLOTS; ++j) *reinterpret_cast<f32x4*>(lds_b + (row0 + j * 32) * LDV + piece * 4) = rb[j];
+        __syncthreads();
+        if (k0 + CK < p.k) fetch(k0 + CK);
+        dm3d_mma_step<MR, NR, CK>(acc, a_lds, b_lds, half);
+    }
+
+    float* O = p.out + (size_t)bz * p.so;
+    const float* R = p.res ? p.res + (size_t)bz * p.sr : nullptr;
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int n = n0 + nr * 32 + l32;
+        if (n >= p.n) continue;
+        const float bn = (p.bias && !p.bias_m) ? p.bias[n] : 0.0f;
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wave * 64 + mr * 32 + dm3d_acc_row(r, half);
+                if (m < p.m) {
+                    float v = acc[mr][nr][r] * p.alpha + bn;
+                    if (p.bias && p.bias_m) v += p.bias[m];
+                    v = dm3d_act(v, p.act);
+                    if (R) v += R[(size_t)m * p.ldr + n];
+                    O[(size_t)m * p.ldo + n] = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dm3d_gemm_tn(const dm3d_gemm_desc* d, void* stream) {
+    DM3D_REQUIRE(d != nullptr, "gemm: null descriptor");
+    DM3D_REQUIRE(d->a && d->b && d->out, "gemm: a/b/out must be non-null");
+    DM3D_REQUIRE(d->m > 0 && d->n > 0 && d->k > 0 && d->batch > 0, "gemm: non-positive extent m=%d n=%d k=%d batch=%d",
+                 d->m, d->n, d->k, d->batch);
+    DM3D_REQUIRE(d->k % 4 == 0 && d->lda % 4 == 0 && d->ldb % 4 == 0, "gemm: k=%d lda=%lld ldb=%lld must be multiples of 4",
+                 d->k, (long long)d->lda, (long long)d->ldb);
+    DM3D_REQUIRE(d->stride_a % 4 == 0 && d->stride_b % 4 == 0, "gemm: batch strides of a/b must be multiples of 4");
+    DM3D_REQUIRE(d->lda >= d->k && d->ldb >= d->k && d->ldo >= d->n, "gemm: leading dimension smaller than the row");
+    DM3D_REQUIRE(!d->res || d->ldr >= d->n, "gemm: ldr smaller than n");
+    DM3D_REQUIRE(dm3d_aligned16(d->a) && dm3d_aligned16(d->b), "gemm: a/b must be 16-byte aligned");
+    DM3D_REQUIRE(d->act >= DM3D_ACT_NONE && d->act <= DM3D_ACT_SILU, "gemm: unknown act %d", d->act);
+    DM3D_REQUIRE(d->batch <= 65535, "gemm: batch %d exceeds grid.z", d->batch);
+    GemmArgs a{};
+    a.a = d->a; a.lda = d->lda; a.sa = d->stride_a;
+    a.b = d->b; a.ldb = d->ldb; a.sb = d->stride_b;
+    a.out = d->out; a.ldo = d->ldo; a.so = d->stride_o;
+    a.m = d->m; a.n = d->n; a.k = d->k; a.alpha = d->alpha;
+    a.bias = d->bias; a.bias_m = d->bias_along_m; a.act = d->act;
+    a.res = d->res; a.ldr = d->ldr; a.sr = d->stride_r;
+    dim3 grid((unsigned)((d->m + 255) / 256), (unsigned)((d->n + 63) / 64), (unsigned)d->batch);
+    hipLaunchKernelGGL(gemm_tn_f32, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return dm3d_launch_check("gemm_tn_f32");
+}

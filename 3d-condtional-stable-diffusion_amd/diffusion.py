@@ -1,0 +1,249 @@
+"""``DiffusionModel`` — the reference's DDPM wrapper around the U-Net, on the dm3d HIP kernels.
+
+reference: networks/conditional_dm3d.py:418-594 (conditional) and networks/dm3d.py:379-545 (unconditional).  Same
+constructor, attributes and method signatures; tensors are PyTorch device tensors (NDHWC float32) instead of tf.Tensor.
+Keyword-only extensions: ``x_T=`` / ``noise=`` inject the random draws (parity tests), ``seed=``
+selects the in-kernel Philox stream, ``use_graph=`` toggles HIP-graph replay of the step.
+
+The sampling loop (:559-573) runs with no host synchronisation: the step index lives in device memory, one step
+(U-Net forward + posterior update + index decrement) is captured once into a HIP graph and replayed T times.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DdpmDesc, check, lib
+from .betas import BETAS_FIELDS, Betas
+from .unet import UNet
+from .weights import UNetConfig
+
+
+class _LossTracker:
+    """keras.metrics.Mean(name="loss") stand-in (conditional_dm3d.py:467, 507-515)."""
+
+    def __init__(self, name="loss"):
+        self.name, self.total, self.count = name, 0.0, 0
+
+    def update_state(self, v):
+        self.total += float(v)
+        self.count += 1
+
+    def result(self):
+        return self.total / max(self.count, 1)
+
+    def reset_state(self):
+        self.total, self.count = 0.0, 0
+
+
+class DiffusionModel:
+    conditional = True
+
+    def __init__(self, latent_size, num_embed, latent_channels, vqvae_load_ckpt, args, *, device="cuda", weights=None,
+                 seed=0):
+        # conditional_dm3d.py:420-469.  ``args`` is any object with .timesteps .num_gpus .kernel_resize .bs
+        self.timesteps = int(args.timesteps)
+        self.b = Betas(self.timesteps)
+        self.lc = latent_channels
+        # The VQ-VAE bracket (networks/vqvae3d_monai.py) is outside this path: the attributes
+        # exist, nothing is constructed.
+        self.num_embed = num_embed
+        self.vqvae_load_ckpt = vqvae_load_ckpt
+        self.vqvae_trainer = None
+        self.encoder = self.quantizer = self.decoder = None
+        self.network = UNet(
+            UNetConfig(img_size=latent_size, img_channels=latent_channels, widths=[64, 128, 256],
+                       has_attention=[False, False, True, True], conditional=self.conditional),
+            device=device, weights=weights, seed=seed)
+        self.loss_tracker = _LossTracker("loss")
+        self.num_gpus = getattr(args, "num_gpus", 1)
+        self.global_bs = getattr(args, "bs", 1)
+        self.device = self.network.device
+        self._graphs = {}
+        self._stream = None
+
+    # -- Keras-model conveniences the reference's drivers touch ----------------------------------------------------
+    @property
+    def metrics(self):
+        return [self.loss_tracker]
+
+    def compile(self, loss=None, optimizer=None):
+        self.loss, self.optimizer = loss, optimizer
+
+    def load_state_dict(self, sd, strict=True):
+        self.network.load_state_dict(sd, strict)
+        self._drop_graphs()
+
+    def _drop_graphs(self):
+        for g in self._graphs.values():
+            lib().dm3d_graph_destroy(g)
+        self._graphs = {}
+
+    def __del__(self):
+        try:
+            self._drop_graphs()
+        except Exception:
+            pass
+
+    def train_step(self, inputs):
+        """conditional_dm3d.py:471-510.  Needs the frozen VQ encoder (next-1) and the backward kernels (next-2)."""
+        raise NotImplementedError(
+            "train_step is not built in this round: it needs batch-statistics BatchNormalization, the backward kernels "
+            "and the VQ-VAE encoder (SURVEY.md §8(f) next-1/next-2). There is deliberately no PyTorch-autograd fallback.")
+
+    # -- a13: sample ------------------------------------------------------------------------------------------------
+    def _ddpm_desc(self, x, eps, t_idx, mode, noise=None, seed=0, mean_out=None, var_out=None) -> DdpmDesc:
+        tab = self.b.device_tables(self.device)
+        d = DdpmDesc()
+        d.x, d.eps, d.noise = x.data_ptr(), eps.data_ptr(), (noise.data_ptr() if noise is not None else None)
+        d.batch, d.per_sample = x.shape[0], x[0].numel()
+        d.t, d.timesteps = t_idx.data_ptr(), self.timesteps
+        for i, f in enumerate(BETAS_FIELDS):
+            if f != "alpha":
+                setattr(d, f, tab[i].data_ptr())
+        d.seed, d.mode = int(seed) & (2 ** 64 - 1), mode
+        d.mean_out = mean_out.data_ptr() if mean_out is not None else None
+        d.var_out = var_out.data_ptr() if var_out is not None else None
+        d._keep = (x, eps, noise, t_idx, tab, mean_out, var_out)
+        return d
+
+    def sample(self, x_t, pred_noise, curr_time_step, shape):
+        """conditional_dm3d.py:517-548: returns (posterior_mean, posterior 'log_variance' [B,1,1,1,1])."""
+        x_t = torch.as_tensor(x_t, dtype=torch.float32).to(self.device).contiguous()
+        eps = torch.as_tensor(pred_noise, dtype=torch.float32).to(self.device).contiguous()
+        B = int(shape[0])
+        if x_t.shape[0] != B or eps.shape != x_t.shape:
+            raise ValueError("x_t / pred_noise / shape disagree")
+        t = torch.as_tensor(curr_time_step).reshape(-1).to(torch.int32)
+        if t.numel() != B or int(t.min()) < 0 or int(t.max()) >= self.timesteps:
+            raise ValueError("curr_time_step must hold one index in [0, timesteps) per sample")
+        t = t.to(self.device)
+        mean = torch.empty_like(x_t)
+        var = torch.empty(B, dtype=torch.float32, device=self.device)
+        d = self._ddpm_desc(x_t, eps, t, 0, mean_out=mean, var_out=var)
+        check(lib().dm3d_ddpm_update(C.byref(d), torch.cuda.current_stream().cuda_stream), "ddpm_update")
+        return mean, var.reshape(B, 1, 1, 1, 1)
+
+    # -- a14: generate ----------------------------------------------------------------------------------------------
+    def _context_ids(self, context_value):
+        if context_value is None:
+            # the reference builds tf.constant([[None]]) here and fails (conditional_dm3d.py:552, 586-589)
+            raise ValueError("context_value is required for the conditional model")
+        return np.asarray([int(context_value)], dtype=np.int32)
+
+    def sampler(self, shape, context_value=None, *, seed=0, use_graph=True) -> "Sampler":
+        """The state of one generate() call: plan, tables, context rows and the captured step graph."""
+        net = self.network
+        cfg = net.cfg
+        shape = tuple(int(s) for s in shape)
+        if len(shape) != 5 or shape[1:] != (cfg.img_size,) * 3 + (cfg.img_channels,):
+            raise ValueError(f"shape must be (B,{cfg.img_size},{cfg.img_size},{cfg.img_size},{cfg.img_channels})")
+        return Sampler(self, shape, self._context_ids(context_value) if self.conditional else None, seed, use_graph)
+
+    def generate(self, shape=(1, 16, 16, 16, 16), last_step=0, context_value=None, *, x_T=None, noise=None, seed=0,
+                 use_graph=True, steps=None):
+        """conditional_dm3d.py:550-575.  For shape[0] > 1 the single context row is broadcast to every sample.
+        ``noise`` (optional): tensor [timesteps, *shape]; row i is the draw of step i.  ``steps`` (optional) stops
+        after that many steps (benchmarks time a prefix of the chain)."""
+        if not 0 <= last_step <= self.timesteps:
+            raise ValueError("last_step out of range")
+        smp = self.sampler(shape, context_value, seed=seed, use_graph=use_graph and noise is None)
+        smp.reset(x_T)
+        T = self.timesteps
+        n_steps = T - last_step if steps is None else min(int(steps), T - last_step)
+        if noise is not None:
+            noise = torch.as_tensor(noise, dtype=torch.float32).to(self.device)
+            if tuple(noise.shape) != (T,) + smp.shape:
+                raise ValueError("noise must be [timesteps, *shape]")
+            for k in range(n_steps):
+                smp.step(noise=noise[T - 1 - k])
+        else:
+            for _ in range(n_steps):
+                smp.step()
+        return smp.plan.x.clone()
+
+    def _capture(self, smp: "Sampler"):
+        """Capture one step of ``smp`` into a HIP graph (cached per plan and seed; the seed is a kernel argument)."""
+        key = (id(smp.plan), smp.seed)
+        if key not in self._graphs:
+            torch.cuda.synchronize()
+            cap = torch.cuda.Stream()
+            g = C.c_void_p()
+            check(lib().dm3d_graph_begin(cap.cuda_stream), "graph_begin")
+            try:
+                smp._enqueue(cap.cuda_stream, smp.desc)
+            finally:
+                rc = lib().dm3d_graph_end(cap.cuda_stream, C.byref(g))
+            check(rc, "graph_end")
+            self._graphs[key] = g
+            self._graph_keep = getattr(self, "_graph_keep", []) + [smp.desc, cap, smp.plan]
+        return self._graphs[key]
+
+    def test(self, test_prefix, context=None):
+        """conditional_dm3d.py:577-594 decodes through the VQ-VAE, which is outside this path."""
+        raise NotImplementedError("test() needs the VQ-VAE decoder (SURVEY.md §8(f) next-1); use generate()")
+
+
+class UnconditionalDiffusionModel(DiffusionModel):
+    """networks/dm3d.py:379-545: no context input, self-attention blocks, first_conv_channels = 64."""
+
+    conditional = False
+
+    def _context_ids(self, context_value):
+        return None
+
+    def generate(self, shape=(1, 16, 16, 16, 16), last_step=0, **kw):
+        kw.pop("context_value", None)
+        return super().generate(shape, last_step, None, **kw)
+
+    def test(self, test_prefix):
+        raise NotImplementedError("test() needs the VQ-VAE decoder (SURVEY.md §8(f) next-1); use generate()")
+
+
+class Sampler:
+    """One DDPM chain over a fixed batch (the loop body of generate, conditional_dm3d.py:559-573).
+
+    ``step()`` enqueues U-Net forward + posterior update + index decrement on the current stream and never synchronises;
+    with ``use_graph`` the three are one HIP-graph replay."""
+
+    def __init__(self, model: DiffusionModel, shape, ctx_ids, seed, use_graph):
+        self.model, self.shape, self.seed, self.use_graph = model, shape, int(seed) & (2 ** 64 - 1), use_graph
+        net, T = model.network, model.timesteps
+        self.plan = net.plan(shape[0], T, False)
+        if getattr(self.plan, "_time_filled", None) is not net.P:
+            net.fill_time_table(np.arange(T), self.plan.vec)
+            self.plan._time_filled = net.P
+        if ctx_ids is not None:
+            self.plan.set_context(ctx_ids)
+        self.desc = model._ddpm_desc(self.plan.x, self.plan.eps, self.plan.t_idx, 1, seed=self.seed)
+        self.graph = None
+
+    def reset(self, x_T=None):
+        plan, T = self.plan, self.model.timesteps
+        st = torch.cuda.current_stream().cuda_stream
+        if x_T is not None:
+            plan.x.copy_(torch.as_tensor(x_T, dtype=torch.float32).reshape(self.shape))
+        else:
+            check(lib().dm3d_randn(plan.x.data_ptr(), plan.x.numel(), self.seed, 0x7fffffff, st), "randn")
+        plan.t_idx.fill_(T - 1)
+
+    def _enqueue(self, st, desc):
+        self.plan.run(st)
+        check(lib().dm3d_ddpm_update(C.byref(desc), st), "ddpm_update")
+        check(lib().dm3d_add_i32(self.plan.t_idx.data_ptr(), self.plan.B, -1, st), "add_i32")
+
+    def step(self, noise=None):
+        st = torch.cuda.current_stream().cuda_stream
+        if noise is not None:
+            d = self.model._ddpm_desc(self.plan.x, self.plan.eps, self.plan.t_idx, 1, noise=noise)
+            self._enqueue(st, d)
+        elif self.use_graph:
+            if self.graph is None:
+                self.graph = self.model._capture(self)
+            check(lib().dm3d_graph_launch(self.graph, st), "graph_launch")
+        else:
+            self._enqueue(st, self.desc)

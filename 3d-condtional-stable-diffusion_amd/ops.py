@@ -1,0 +1,134 @@
+"""Immediate-mode wrappers over the C ABI (one call = one kernel launch on the current stream).
+
+These mirror the stock Keras / TensorFlow ops the reference's hot path executes (include/dm3d.h cites each one).  They
+validate shapes in Python (``ValueError``, like the reference's only explicit check, conditional_dm3d.py:343-346) and then
+call the HIP kernels; there is no fallback implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ConvDesc, DdpmDesc, GemmDesc, check, lib
+
+
+def _st() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+        raise ValueError(f"{name} must be a contiguous float32 device tensor")
+    return t
+
+
+def pack_weights(kernel: torch.Tensor, in_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Keras Conv3D [kd,kh,kw,Cin,Cout] or Dense [in,out] kernel -> [taps][CoutPad][CinPad]."""
+    _f32c(kernel, "kernel")
+    if kernel.dim() not in (2, 5):
+        raise ValueError("kernel must be [in,out] or [kd,kh,kw,cin,cout]")
+    taps = 1 if kernel.dim() == 2 else kernel.shape[0] * kernel.shape[1] * kernel.shape[2]
+    cin, cout = kernel.shape[-2], kernel.shape[-1]
+    out = torch.empty(lib().dm3d_packed_weight_elems(taps, cin, cout), dtype=torch.float32, device=kernel.device)
+    check(lib().dm3d_pack_weights(kernel.data_ptr(), taps, cin, cout, _p(in_scale), out.data_ptr(), _st()), "pack_weights")
+    return out
+
+
+def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False, pro_scale=None, pro_shift=None,
+           vec=None, vec_idx=None, relu=False, res=None) -> torch.Tensor:
+    """Conv3D(padding="same") on NDHWC with the fused prologue / concat / upsample / epilogue of dm3d_conv3d_ndhwc."""
+    _f32c(x1, "x1")
+    if x1.dim() != 5:
+        raise ValueError("x1 must be [B,D,H,W,C]")
+    B, D, H, W, c1 = x1.shape
+    c2 = 0
+    if x2 is not None:
+        _f32c(x2, "x2")
+        if x2.shape[:4] != x1.shape[:4]:
+            raise ValueError("x2 must share x1's batch and spatial shape")
+        c2 = x2.shape[4]
+    up = 2 if upsample else 1
+    od, oh, ow = (-(-D * up // stride), -(-H * up // stride), -(-W * up // stride))
+    out = torch.empty(B, od, oh, ow, cout, dtype=torch.float32, device=x1.device)
+    d = ConvDesc()
+    d.x1, d.x2, d.c1, d.c2, d.batch = x1.data_ptr(), _p(x2), c1, c2, B
+    d.in_d, d.in_h, d.in_w, d.upsample, d.ksize, d.stride = D, H, W, int(bool(upsample)), ksize, stride
+    d.wpk, d.bias, d.pro_scale, d.pro_shift = wpk.data_ptr(), _p(bias), _p(pro_scale), _p(pro_shift)
+    if vec is not None:
+        d.vec, d.vec_idx, d.vec_ld = vec.data_ptr(), _p(vec_idx), vec.shape[-1]
+    if res is not None and tuple(res.shape) != tuple(out.shape):
+        raise ValueError("res must have the output's shape")
+    d.relu, d.res, d.out, d.cout = int(bool(relu)), _p(res), out.data_ptr(), cout
+    check(lib().dm3d_conv3d_ndhwc(C.byref(d), _st()), "conv3d")
+    return out
+
+
+def gemm_tn(a, b, *, m=None, n=None, k=None, lda=None, ldb=None, batch=1, stride_a=None, stride_b=None, alpha=1.0, bias=None,
+            bias_along_m=False, act=ACT_NONE, res=None, out=None) -> torch.Tensor:
+    """out[b][m][n] = act(alpha * sum_k a[b][m][k] b[b][n][k] + bias) + res.  a: [batch?, m, k], b: [batch?, n, k]."""
+    _f32c(a, "a"), _f32c(b, "b")
+    m = a.shape[-2] if m is None else m
+    k = a.shape[-1] if k is None else k
+    n = b.shape[-2] if n is None else n
+    lda = a.shape[-1] if lda is None else lda
+    ldb = b.shape[-1] if ldb is None else ldb
+    if stride_a is None:
+        stride_a = a.shape[-2] * a.shape[-1] if (batch > 1 and a.dim() == 3 and a.shape[0] == batch) else 0
+    if stride_b is None:
+        stride_b = b.shape[-2] * b.shape[-1] if (batch > 1 and b.dim() == 3 and b.shape[0] == batch) else 0
+    if out is None:
+        out = torch.empty((batch, m, n) if batch > 1 else (m, n), dtype=torch.float32, device=a.device)
+    d = GemmDesc()
+    d.a, d.lda, d.stride_a = a.data_ptr(), lda, stride_a
+    d.b, d.ldb, d.stride_b = b.data_ptr(), ldb, stride_b
+    d.out, d.ldo, d.stride_o = out.data_ptr(), n, m * n
+    d.m, d.n, d.k, d.batch, d.alpha = m, n, k, batch, alpha
+    d.bias, d.bias_along_m, d.act = _p(bias), int(bool(bias_along_m)), act
+    if res is not None:
+        d.res, d.ldr, d.stride_r = res.data_ptr(), n, m * n
+    check(lib().dm3d_gemm_tn(C.byref(d), _st()), "gemm_tn")
+    return out
+
+
+def layernorm3(x, params, eps=1e-3):
+    """params: up to three (gamma, beta) pairs -> list of outputs sharing one statistics pass."""
+    _f32c(x, "x")
+    c = x.shape[-1]
+    rows = x.numel() // c
+    outs = [torch.empty_like(x) for _ in params]
+    args = []
+    for i in range(3):
+        if i < len(params):
+            args += [params[i][0].data_ptr(), params[i][1].data_ptr(), outs[i].data_ptr()]
+        else:
+            args += [None, None, None]
+    check(lib().dm3d_layernorm3(x.data_ptr(), rows, c, eps, *args, _st()), "layernorm3")
+    return outs
+
+
+def softmax_rows_(s: torch.Tensor) -> torch.Tensor:
+    _f32c(s, "s")
+    cols = s.shape[-1]
+    check(lib().dm3d_softmax_rows(s.data_ptr(), s.numel() // cols, cols, cols, _st()), "softmax_rows")
+    return s
+
+
+def affine_act(x, scale=None, shift=None, act=ACT_NONE) -> torch.Tensor:
+    _f32c(x, "x")
+    c = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib().dm3d_affine_act(x.data_ptr(), y.data_ptr(), x.numel() // c, c, _p(scale), _p(shift), act, _st()), "affine_act")
+    return y
+
+
+def randn(shape, seed: int, stream_id: int = 0, device="cuda") -> torch.Tensor:
+    x = torch.empty(shape, dtype=torch.float32, device=device)
+    check(lib().dm3d_randn(x.data_ptr(), x.numel(), seed, stream_id, _st()), "randn")
+    return x

@@ -1,0 +1,498 @@
+"""The 3D U-Net of the reference (``build_model``) as a static launch plan over the dm3d HIP kernels.
+
+reference: networks/conditional_dm3d.py:324-415 (conditional, CrossAttentionBlock) and networks/dm3d.py:294-376
+(unconditional, AttentionBlock).  PyTorch is used only to own device memory and streams; every arithmetic op on
+activations is a call through the C ABI (include/dm3d.h).  A *plan* is the flat list of those calls for one batch size
+with every buffer pre-allocated, so a whole denoising step can be captured into a HIP graph and replayed.
+
+What is hoisted out of the per-step work (none of it changes results):
+  * inference BatchNormalization is folded to a per-channel scale/shift applied, with swish, while the conv stages its
+    input tile into LDS (ResidualBlock :255-256, 262-263; end block :410-411), or folded into the following 1x1 conv's
+    weights (CrossAttentionBlock norm -> proj_in, :187-188);
+  * the time path (TimeEmbedding -> TimeMLP -> per-ResidualBlock swish+Dense, :355-356, 250-253) depends only on t: it
+    is evaluated once for all needed t into a [rows, sum(widths)] table that the conv epilogues index with t[b];
+  * ContextMLP and the cross-attention key/value projections (:310-318, 168-169) depend only on the context id: they
+    are evaluated once per weight set for both ids.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, ConvDesc, GemmDesc, check, lib
+from .betas import time_embedding_table
+from .weights import UNetConfig, keras_init_weights, walk
+
+BN_EPS = 1e-3     # keras.layers.BatchNormalization default
+LN_EPS = 1e-3     # keras.layers.LayerNormalization default
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor], offset_elems: int = 0) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr() + 4 * offset_elems
+
+
+class _Conv:
+    """Packed Conv3D / Dense weights on the device."""
+
+    def __init__(self, wpk, bias, taps, cin, cout):
+        self.wpk, self.bias, self.taps, self.cin, self.cout = wpk, bias, taps, cin, cout
+        self.cin_pad = -(-cin // _lib.CIN_PAD) * _lib.CIN_PAD
+
+
+class UNet:
+    """Callable like the Keras model returned by ``build_model``: ``net([x, t, context]) -> eps`` (NDHWC float32)."""
+
+    def __init__(self, cfg: UNetConfig, device="cuda", weights: Optional[Dict[str, np.ndarray]] = None, seed: int = 0):
+        self.cfg = cfg
+        self.blocks, self.spec = walk(cfg)
+        self.device = torch.device(device)
+        self.state: Dict[str, np.ndarray] = {}
+        self._plans: Dict[tuple, "Plan"] = {}
+        self._prepared = False
+        self.load_state_dict(weights if weights is not None else keras_init_weights(cfg, seed))
+
+    # ---- weights -------------------------------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, np.ndarray], strict: bool = True):
+        new = {}
+        for name, shape in self.spec.items():
+            if name not in sd:
+                if strict:
+                    raise ValueError(f"missing weight {name}")
+                new[name] = self.state[name]
+                continue
+            arr = sd[name]
+            if isinstance(arr, torch.Tensor):
+                arr = arr.detach().cpu().numpy()
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            if tuple(arr.shape) != tuple(shape):
+                raise ValueError(f"weight {name}: expected shape {tuple(shape)}, got {tuple(arr.shape)}")
+            new[name] = arr
+        extra = set(sd) - set(self.spec)
+        if strict and extra:
+            raise ValueError(f"unexpected weights: {sorted(extra)[:5]}")
+        self.state = new
+        self._prepared = False
+        self._plans.clear()
+
+    def state_dict(self) -> Dict[str, np.ndarray]:
+        return dict(self.state)
+
+    def num_params(self) -> int:
+        return int(sum(int(np.prod(s)) for s in self.spec.values()))
+
+    # ---- one-time device preparation -----------------------------------------------------------------------------
+    def _dev(self, arr: np.ndarray) -> torch.Tensor:
+        return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(self.device)
+
+    def _pack(self, kernel: np.ndarray, bias: Optional[np.ndarray], in_scale: Optional[torch.Tensor] = None) -> _Conv:
+        shape = kernel.shape
+        taps = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+        cin, cout = int(shape[-2]), int(shape[-1])
+        raw = self._dev(kernel)
+        n = lib().dm3d_packed_weight_elems(taps, cin, cout)
+        wpk = torch.empty(n, dtype=torch.float32, device=self.device)
+        check(lib().dm3d_pack_weights(raw.data_ptr(), taps, cin, cout, _ptr(in_scale), wpk.data_ptr(), _stream()),
+              "pack_weights")
+        return _Conv(wpk, self._dev(bias) if bias is not None else None, taps, cin, cout)
+
+    def _fold_bn(self, name: str):
+        """Inference BatchNormalization gamma*(x-mean)/sqrt(var+eps)+beta as x*scale+shift."""
+        s = self.state
+        scale = (s[f"{name}.gamma"].astype(np.float64) / np.sqrt(s[f"{name}.var"].astype(np.float64) + BN_EPS))
+        shift = s[f"{name}.beta"].astype(np.float64) - s[f"{name}.mean"].astype(np.float64) * scale
+        return self._dev(scale.astype(np.float32)), self._dev(shift.astype(np.float32))
+
+    def prepare(self):
+        if self._prepared:
+            return
+        _lib.require_device()
+        s, cfg = self.state, self.cfg
+        P: Dict[str, object] = {}
+        P["conv_in"] = self._pack(s["conv_in.kernel"], s["conv_in.bias"])
+        P["time_mlp.0"] = self._pack(s["time_mlp.0.kernel"], s["time_mlp.0.bias"])
+        P["time_mlp.1"] = self._pack(s["time_mlp.1.kernel"], s["time_mlp.1.bias"])
+        temb_k, temb_b, self.temb_off, off = [], [], {}, 0
+        for blk in self.blocks:
+            n = blk.name
+            if blk.kind == "res":
+                if f"{n}.skip.kernel" in s:
+                    P[f"{n}.skip"] = self._pack(s[f"{n}.skip.kernel"], s[f"{n}.skip.bias"])
+                P[f"{n}.conv1"] = self._pack(s[f"{n}.conv1.kernel"], s[f"{n}.conv1.bias"])
+                P[f"{n}.conv2"] = self._pack(s[f"{n}.conv2.kernel"], s[f"{n}.conv2.bias"])
+                P[f"{n}.norm1"] = self._fold_bn(f"{n}.norm1")
+                P[f"{n}.norm2"] = self._fold_bn(f"{n}.norm2")
+                temb_k.append(s[f"{n}.temb.kernel"])
+                temb_b.append(s[f"{n}.temb.bias"])
+                self.temb_off[n] = off
+                off += blk.cout
+            elif blk.kind in ("down", "up"):
+                P[n] = self._pack(s[f"{n}.kernel"], s[f"{n}.bias"])
+            elif blk.kind == "attn":
+                self._prepare_attn(P, blk)
+        self.temb_ld = off
+        P["temb_all"] = self._pack(np.concatenate(temb_k, axis=1), np.concatenate(temb_b))
+        P["out.norm"] = self._fold_bn("out.norm")
+        P["out.conv"] = self._pack(s["out.conv.kernel"], s["out.conv.bias"])
+        self.P = P
+        self._prepared = True
+        if cfg.conditional:
+            self._prepare_context_tables()
+
+    def _prepare_attn(self, P, blk):
+        s, n, u = self.state, blk.name, blk.cout
+        if self.cfg.conditional:
+            scale, shift = self._fold_bn(f"{n}.norm")
+            # BN folded into proj_in: W' = diag(scale) W ; b' = b + shift @ W (the latter through the GEMM kernel)
+            plain = self._pack(s[f"{n}.proj_in.kernel"], s[f"{n}.proj_in.bias"])
+            bias2 = torch.empty(u, dtype=torch.float32, device=self.device)
+            self._gemm_now(a=shift, lda=u, b=plain.wpk, ldb=plain.cin_pad, out=bias2, ldo=u, m=1, n=u, k=u, bias=plain.bias)
+            folded = self._pack(s[f"{n}.proj_in.kernel"], None, in_scale=scale)
+            folded.bias = bias2
+            P[f"{n}.proj_in"] = folded
+            P[f"{n}.proj_out"] = self._pack(s[f"{n}.proj_out.kernel"], s[f"{n}.proj_out.bias"])
+            for ln in ("ln1", "ln2", "ln3"):
+                P[f"{n}.{ln}"] = (self._dev(s[f"{n}.{ln}.gamma"]), self._dev(s[f"{n}.{ln}.beta"]))
+            P[f"{n}.mlp.0"] = self._pack(s[f"{n}.mlp.0.kernel"], s[f"{n}.mlp.0.bias"])
+            P[f"{n}.mlp.1"] = self._pack(s[f"{n}.mlp.1.kernel"], s[f"{n}.mlp.1.bias"])
+            P[f"{n}.key"] = self._pack(s[f"{n}.key.kernel"], s[f"{n}.key.bias"])
+        else:
+            P[f"{n}.norm"] = self._fold_bn(f"{n}.norm")
+            P[f"{n}.proj"] = self._pack(s[f"{n}.proj.kernel"], s[f"{n}.proj.bias"])
+        # query|key share one GEMM (rows 0..u-1 are the query weights and also serve the query-only call)
+        P[f"{n}.qk"] = self._pack(np.concatenate([s[f"{n}.query.kernel"], s[f"{n}.key.kernel"]], axis=1),
+                                  np.concatenate([s[f"{n}.query.bias"], s[f"{n}.key.bias"]]))
+        P[f"{n}.value"] = self._pack(s[f"{n}.value.kernel"], s[f"{n}.value.bias"])
+
+    def _gemm_now(self, **kw):
+        d = _gemm_desc(**kw)
+        check(lib().dm3d_gemm_tn(C.byref(d), _stream()), "gemm")
+
+    def _prepare_context_tables(self):
+        """ContextMLP + key/value projections for both context ids (conditional_dm3d.py:310-318, 168-169, 358):
+        per attention block  kctx [ids, L, u]  and  vctx_t [ids, u, L]  (value kept transposed: K-contiguous operand
+        of the P.V contraction)."""
+        s, td = self.state, self.cfg.temb_dim
+        ids = s["ctx_embed.table"].shape[0]
+        cemb = self._dev(s["ctx_embed.table"])                               # Embedding rows [ids, td]
+        self.ctx_tables = {}
+        for blk in self.blocks:
+            if blk.kind != "attn":
+                continue
+            n, u, L = blk.name, blk.cout, blk.edge ** 3
+            w = self._pack(s[f"{n}.ctx_mlp.kernel"], s[f"{n}.ctx_mlp.bias"])
+            feat = torch.empty(ids, L * u, dtype=torch.float32, device=self.device)
+            self._gemm_now(a=cemb, lda=td, b=w.wpk, ldb=w.cin_pad, out=feat, ldo=L * u, m=ids, n=L * u, k=td,
+                           bias=w.bias, act=ACT_SILU)
+            key, val = self.P[f"{n}.key"], self.P[f"{n}.value"]
+            kctx = torch.empty(ids, L, u, dtype=torch.float32, device=self.device)
+            self._gemm_now(a=feat, lda=u, b=key.wpk, ldb=key.cin_pad, out=kctx, ldo=u, m=ids * L, n=u, k=u, bias=key.bias)
+            vctx_t = torch.empty(ids, u, L, dtype=torch.float32, device=self.device)
+            self._gemm_now(a=val.wpk, lda=val.cin_pad, b=feat, ldb=u, stride_b=L * u, out=vctx_t, ldo=L, stride_o=u * L,
+                           m=u, n=L, k=u, batch=ids, bias=val.bias, bias_along_m=1)
+            self.ctx_tables[n] = (kctx, vctx_t)
+            del w, feat
+
+    # ---- time path -------------------------------------------------------------------------------------------------
+    def fill_time_table(self, t_values: Sequence[int], out: torch.Tensor):
+        """out[r, :] = concat over ResidualBlocks of Dense_blk(swish(TimeMLP(TimeEmbedding(t_values[r]))))."""
+        self.prepare()
+        td, R = self.cfg.temb_dim, len(t_values)
+        emb = self._dev(time_embedding_table(np.asarray(t_values), td))
+        h = torch.empty(R, td, dtype=torch.float32, device=self.device)
+        h2 = torch.empty_like(h)
+        m0, m1, ta = self.P["time_mlp.0"], self.P["time_mlp.1"], self.P["temb_all"]
+        self._gemm_now(a=emb, lda=td, b=m0.wpk, ldb=m0.cin_pad, out=h, ldo=td, m=R, n=td, k=td, bias=m0.bias, act=ACT_SILU)
+        # Dense_1 then the ResidualBlocks' swish: the activation is fused into this GEMM's epilogue
+        self._gemm_now(a=h, lda=td, b=m1.wpk, ldb=m1.cin_pad, out=h2, ldo=td, m=R, n=td, k=td, bias=m1.bias, act=ACT_SILU)
+        self._gemm_now(a=h2, lda=td, b=ta.wpk, ldb=ta.cin_pad, out=out, ldo=self.temb_ld, m=R, n=self.temb_ld, k=td,
+                       bias=ta.bias)
+
+    # ---- plans -----------------------------------------------------------------------------------------------------
+    def plan(self, batch: int, vec_rows: int, per_sample_context: bool = False) -> "Plan":
+        self.prepare()
+        key = (int(batch), int(vec_rows), bool(per_sample_context))
+        if key not in self._plans:
+            self._plans[key] = Plan(self, *key)
+        return self._plans[key]
+
+    def __call__(self, inputs, training: bool = False) -> torch.Tensor:
+        """``network([x, t, context])`` / ``network([x, t])`` as in conditional_dm3d.py:493, 568 (dm3d.py:525)."""
+        if training:
+            raise NotImplementedError("training=True (batch-statistics BatchNormalization + backward) is not built yet; "
+                                      "SURVEY.md §8(f) next-2")
+        cfg = self.cfg
+        if cfg.conditional:
+            if len(inputs) != 3:
+                raise ValueError("the conditional network takes [image, time, context]")
+            x, t, ctx = inputs
+        else:
+            if len(inputs) != 2:
+                raise ValueError("the unconditional network takes [image, time]")
+            (x, t), ctx = inputs, None
+        x = torch.as_tensor(x)
+        want = (cfg.img_size,) * 3 + (cfg.img_channels,)
+        if x.dim() != 5 or tuple(x.shape[1:]) != want:
+            raise ValueError(f"image_input must be [B,{','.join(map(str, want))}] (NDHWC), got {tuple(x.shape)}")
+        if x.dtype != torch.float32:
+            raise ValueError("image_input must be float32")
+        B = x.shape[0]
+        t_host = torch.as_tensor(t).reshape(-1).to("cpu", torch.int64).numpy()
+        if t_host.shape[0] != B:
+            raise ValueError(f"time_input must have {B} entries")
+        per_sample = False
+        ctx_host = None
+        if cfg.conditional:
+            ctx_host = torch.as_tensor(ctx).reshape(-1).to("cpu", torch.int64).numpy()
+            if ctx_host.shape[0] not in (1, B):
+                raise ValueError(f"context_input must have 1 or {B} rows")
+            ids = self.state["ctx_embed.table"].shape[0]
+            if ctx_host.min() < 0 or ctx_host.max() >= ids:
+                raise ValueError(f"context ids must be in [0,{ids})")
+            per_sample = ctx_host.shape[0] == B and B > 1 and len(set(ctx_host.tolist())) > 1
+        plan = self.plan(B, B, per_sample)
+        self.fill_time_table(t_host, plan.vec)
+        plan.t_idx.copy_(torch.arange(B, dtype=torch.int32))
+        if cfg.conditional:
+            plan.set_context(ctx_host if per_sample else ctx_host[:1])
+        plan.x.copy_(x.to(self.device))
+        plan.run()
+        return plan.eps.clone()
+
+
+def _gemm_desc(a, lda, b, ldb, out, ldo, m, n, k, batch=1, stride_a=0, stride_b=0, stride_o=0, alpha=1.0, bias=None,
+               bias_along_m=0, act=ACT_NONE, res=None, ldr=0, stride_r=0, a_off=0, b_off=0, out_off=0, res_off=0) -> GemmDesc:
+    d = GemmDesc()
+    d.a, d.lda, d.stride_a = _ptr(a, a_off), lda, stride_a
+    d.b, d.ldb, d.stride_b = _ptr(b, b_off), ldb, stride_b
+    d.out, d.ldo, d.stride_o = _ptr(out, out_off), ldo, stride_o
+    d.m, d.n, d.k, d.batch = m, n, k, batch
+    d.alpha = alpha
+    d.bias, d.bias_along_m, d.act = _ptr(bias), bias_along_m, act
+    d.res, d.ldr, d.stride_r = _ptr(res, res_off), ldr, stride_r
+    return d
+
+
+class Plan:
+    """All launches of one U-Net forward for a fixed batch, with fixed buffers.
+
+    Inputs live in ``x`` [B,S,S,S,C], ``t_idx`` [B] int32 (row of ``vec`` per sample) and, for the conditional model,
+    the per-block context key/value buffers filled by ``set_context``.  Output in ``eps``."""
+
+    def __init__(self, net: UNet, batch: int, vec_rows: int, per_sample_context: bool):
+        self.net, self.B, self.per_sample_context = net, batch, per_sample_context
+        cfg, dev = net.cfg, net.device
+        S, Cc = cfg.img_size, cfg.img_channels
+        self.ops: List[tuple] = []
+        self._keep: List[object] = []
+        self.x = torch.empty(batch, S, S, S, Cc, dtype=torch.float32, device=dev)
+        self.eps = torch.empty_like(self.x)
+        self.t_idx = torch.zeros(batch, dtype=torch.int32, device=dev)
+        self.vec = torch.empty(vec_rows, net.temb_ld, dtype=torch.float32, device=dev)
+        self.ctx_bufs: Dict[str, tuple] = {}
+        self._build()
+
+    # -- buffer / op helpers ---------------------------------------------------------------------------------------
+    def _buf(self, *shape) -> torch.Tensor:
+        t = torch.empty(*shape, dtype=torch.float32, device=self.net.device)
+        self._keep.append(t)
+        return t
+
+    def _conv(self, w: _Conv, x1, out, edge_in, x2=None, c1=None, c2=0, upsample=0, stride=1, pro=None, vec_off=None,
+              relu=0, res=None):
+        d = ConvDesc()
+        d.x1, d.x2 = _ptr(x1), _ptr(x2)
+        d.c1, d.c2 = (c1 if c1 is not None else w.cin), c2
+        d.batch = self.B
+        d.in_d = d.in_h = d.in_w = edge_in
+        d.upsample, d.stride = upsample, stride
+        d.ksize = {1: 1, 27: 3}[w.taps]
+        d.wpk, d.bias = _ptr(w.wpk), _ptr(w.bias)
+        if pro is not None:
+            d.pro_scale, d.pro_shift = _ptr(pro[0]), _ptr(pro[1])
+        if vec_off is not None:
+            d.vec, d.vec_idx, d.vec_ld = _ptr(self.vec, vec_off), _ptr(self.t_idx), self.net.temb_ld
+        d.relu, d.res, d.out, d.cout = relu, _ptr(res), _ptr(out), w.cout
+        if d.c1 + d.c2 != w.cin:
+            raise ValueError(f"conv input channels {d.c1}+{d.c2} != weight cin {w.cin}")
+        self._keep.append(d)
+        up = 2 if upsample else 1
+        eo = -(-edge_in * up // stride)
+        kind = "conv_k1" if w.taps == 1 else ("conv_k3s2" if stride == 2 else "conv_k3s1")
+        self.ops.append((lib().dm3d_conv3d_ndhwc, (C.byref(d),), kind,
+                         {"flops": 2.0 * w.taps * w.cin * w.cout * self.B * eo ** 3,
+                          "bytes": 4.0 * self.B * (edge_in ** 3 * w.cin + eo ** 3 * w.cout)}))
+
+    def _gemm(self, **kw):
+        d = _gemm_desc(**kw)
+        self._keep.append(d)
+        self.ops.append((lib().dm3d_gemm_tn, (C.byref(d),), "gemm", {"flops": 2.0 * d.m * d.n * d.k * d.batch}))
+
+    # -- graph -----------------------------------------------------------------------------------------------------
+    def _build(self):
+        net, cfg, B = self.net, self.net.cfg, self.B
+        P = net.P
+        S = cfg.img_size
+        h = self._buf(B, S, S, S, cfg.first_conv_channels)
+        self._conv(P["conv_in"], self.x, h, S)
+        skips = [(h, cfg.first_conv_channels)]
+        cur, cur_c, edge = h, cfg.first_conv_channels, S
+        for blk in net.blocks:
+            if blk.kind == "push":
+                skips.append((cur, cur_c))
+            elif blk.kind == "res":
+                x2, c2 = (None, 0)
+                if blk.cskip:
+                    x2, c2 = skips.pop()
+                    if c2 != blk.cskip:
+                        raise AssertionError("skip channel mismatch")
+                cur = self._res_block(blk, cur, blk.cin, x2, c2, edge)
+                cur_c = blk.cout
+            elif blk.kind == "attn":
+                cur = self._cross_block(blk, cur, edge) if cfg.conditional else self._self_block(blk, cur, edge)
+            elif blk.kind == "down":
+                out = self._buf(B, blk.edge, blk.edge, blk.edge, blk.cout)
+                self._conv(P[blk.name], cur, out, edge, stride=2)
+                cur, edge = out, blk.edge
+            elif blk.kind == "up":
+                out = self._buf(B, blk.edge, blk.edge, blk.edge, blk.cout)
+                self._conv(P[blk.name], cur, out, edge, upsample=1)
+                cur, edge = out, blk.edge
+        self._conv(P["out.conv"], cur, self.eps, edge, pro=P["out.norm"])
+
+    def _res_block(self, blk, x1, c1, x2, c2, edge):
+        """ResidualBlock (conditional_dm3d.py:238-271): three launches (two when the widths match)."""
+        P, B, n, w = self.net.P, self.B, blk.name, blk.cout
+        if f"{n}.skip" in P:
+            res = self._buf(B, edge, edge, edge, w)
+            self._conv(P[f"{n}.skip"], x1, res, edge, x2=x2, c1=c1, c2=c2)
+        else:
+            res = x1
+        hmid = self._buf(B, edge, edge, edge, w)
+        self._conv(P[f"{n}.conv1"], x1, hmid, edge, x2=x2, c1=c1, c2=c2, pro=P[f"{n}.norm1"], vec_off=self.net.temb_off[n])
+        out = self._buf(B, edge, edge, edge, w)
+        self._conv(P[f"{n}.conv2"], hmid, out, edge, pro=P[f"{n}.norm2"], res=res)
+        return out
+
+    def _attn_core(self, q, q_ld, q_off, k, k_ld, k_off, k_stride, v_t, v_ld, v_off, v_stride, scores, res, out, L, u):
+        """softmax(q k^T * u^-0.5) v + res per sample (conditional_dm3d.py:171-180): two batched GEMMs around a
+        wavefront-shuffle row softmax."""
+        B = self.B
+        self._gemm(a=q, a_off=q_off, lda=q_ld, stride_a=L * q_ld, b=k, b_off=k_off, ldb=k_ld, stride_b=k_stride,
+                   out=scores, ldo=L, stride_o=L * L, m=L, n=L, k=u, batch=B, alpha=float(u) ** -0.5)
+        self.ops.append((lib().dm3d_softmax_rows, (scores.data_ptr(), B * L, L, L), "softmax", {}))
+        self._gemm(a=scores, lda=L, stride_a=L * L, b=v_t, b_off=v_off, ldb=v_ld, stride_b=v_stride, out=out, ldo=u,
+                   stride_o=L * u, m=L, n=u, k=L, batch=B, res=res, ldr=u, stride_r=L * u)
+
+    def _cross_block(self, blk, x, edge):
+        """CrossAttentionBlock (conditional_dm3d.py:186-195)."""
+        P, B, n, u = self.net.P, self.B, blk.name, blk.cout
+        L = edge ** 3
+        M = B * L
+        pin, pout, qk, val = P[f"{n}.proj_in"], P[f"{n}.proj_out"], P[f"{n}.qk"], P[f"{n}.value"]
+        m0, m1 = P[f"{n}.mlp.0"], P[f"{n}.mlp.1"]
+        y = self._buf(M, u)                                                   # relu(proj_in(BN(x)))
+        self._gemm(a=x, lda=u, b=pin.wpk, ldb=pin.cin_pad, out=y, ldo=u, m=M, n=u, k=u, bias=pin.bias, act=ACT_RELU)
+        n1, n2, n3 = self._buf(M, u), self._buf(M, u), self._buf(M, u)
+        (g1, b1), (g2, b2), (g3, b3) = P[f"{n}.ln1"], P[f"{n}.ln2"], P[f"{n}.ln3"]
+        self._keep += [g1, b1, g2, b2, g3, b3]
+        self.ops.append((lib().dm3d_layernorm3, (y.data_ptr(), M, u, LN_EPS, g1.data_ptr(), b1.data_ptr(), n1.data_ptr(),
+                                                 g2.data_ptr(), b2.data_ptr(), n2.data_ptr(), g3.data_ptr(), b3.data_ptr(),
+                                                 n3.data_ptr()), "layernorm", {}))
+        # self attention on norm1(y)
+        qkb = self._buf(M, 2 * u)
+        self._gemm(a=n1, lda=u, b=qk.wpk, ldb=qk.cin_pad, out=qkb, ldo=2 * u, m=M, n=2 * u, k=u, bias=qk.bias)
+        v_t = self._buf(u, M)                                                 # value projection, transposed
+        self._gemm(a=val.wpk, lda=val.cin_pad, b=n1, ldb=u, out=v_t, ldo=M, m=u, n=M, k=u, bias=val.bias, bias_along_m=1)
+        scores = self._buf(B, L, L)
+        a1 = self._buf(M, u)
+        self._attn_core(qkb, 2 * u, 0, qkb, 2 * u, u, L * 2 * u, v_t, M, 0, L, scores, y, a1, L, u)
+        # cross attention: queries from norm2(y), keys/values from the context (same key/value weights, :168-169)
+        q2 = self._buf(M, u)
+        self._gemm(a=n2, lda=u, b=qk.wpk, ldb=qk.cin_pad, out=q2, ldo=u, m=M, n=u, k=u, bias=qk.bias)
+        rows = B if self.per_sample_context else 1
+        kctx, vctx_t = self._buf(rows, L * u), self._buf(rows, u * L)
+        self.ctx_bufs[n] = (kctx, vctx_t)
+        a2 = self._buf(M, u)
+        ks, vs = (L * u, u * L) if self.per_sample_context else (0, 0)
+        self._attn_core(q2, u, 0, kctx, u, 0, ks, vctx_t, L, 0, vs, scores, a1, a2, L, u)
+        # MLP on norm3(y)
+        hid = self._buf(M, 4 * u)
+        self._gemm(a=n3, lda=u, b=m0.wpk, ldb=m0.cin_pad, out=hid, ldo=4 * u, m=M, n=4 * u, k=u, bias=m0.bias, act=ACT_RELU)
+        a3 = self._buf(M, u)
+        self._gemm(a=hid, lda=4 * u, b=m1.wpk, ldb=m1.cin_pad, out=a3, ldo=u, m=M, n=u, k=4 * u, bias=m1.bias, res=a2, ldr=u)
+        out = self._buf(B, edge, edge, edge, u)
+        self._gemm(a=a3, lda=u, b=pout.wpk, ldb=pout.cin_pad, out=out, ldo=u, m=M, n=u, k=u, bias=pout.bias, act=ACT_RELU,
+                   res=x, ldr=u)
+        return out
+
+    def _self_block(self, blk, x, edge):
+        """AttentionBlock (dm3d.py:39-63): BN(x) + proj(softmax(q k^T u^-0.5) v)."""
+        P, B, n, u = self.net.P, self.B, blk.name, blk.cout
+        L = edge ** 3
+        M = B * L
+        qk, val, proj = P[f"{n}.qk"], P[f"{n}.value"], P[f"{n}.proj"]
+        scale, shift = P[f"{n}.norm"]
+        self._keep += [scale, shift]
+        xn = self._buf(M, u)
+        self.ops.append((lib().dm3d_affine_act, (x.data_ptr(), xn.data_ptr(), M, u, scale.data_ptr(), shift.data_ptr(),
+                                                 ACT_NONE), "affine", {}))
+        qkb = self._buf(M, 2 * u)
+        self._gemm(a=xn, lda=u, b=qk.wpk, ldb=qk.cin_pad, out=qkb, ldo=2 * u, m=M, n=2 * u, k=u, bias=qk.bias)
+        v_t = self._buf(u, M)
+        self._gemm(a=val.wpk, lda=val.cin_pad, b=xn, ldb=u, out=v_t, ldo=M, m=u, n=M, k=u, bias=val.bias, bias_along_m=1)
+        scores, o = self._buf(B, L, L), self._buf(M, u)
+        self._attn_core(qkb, 2 * u, 0, qkb, 2 * u, u, L * 2 * u, v_t, M, 0, L, scores, None, o, L, u)
+        out = self._buf(B, edge, edge, edge, u)
+        self._gemm(a=o, lda=u, b=proj.wpk, ldb=proj.cin_pad, out=out, ldo=u, m=M, n=u, k=u, bias=proj.bias, res=xn, ldr=u)
+        return out
+
+    # -- run ---------------------------------------------------------------------------------------------------------
+    def set_context(self, ctx_ids):
+        """Copies the context key / transposed-value rows for the given ids (1 row: broadcast over the batch)."""
+        ids = torch.as_tensor(np.asarray(ctx_ids, dtype=np.int32)).to(self.net.device)
+        self._keep_ids = ids
+        st = _stream()
+        for n, (kbuf, vbuf) in self.ctx_bufs.items():
+            ktab, vtab = self.net.ctx_tables[n]
+            for tab, buf in ((ktab, kbuf), (vtab, vbuf)):
+                check(lib().dm3d_gather_rows(tab.data_ptr(), tab.shape[0], ids.data_ptr(), buf.data_ptr(), buf.shape[0],
+                                             buf.shape[1], st), "gather_rows")
+
+    def run(self, stream: Optional[int] = None):
+        st = _stream() if stream is None else stream
+        for fn, args, what, _ in self.ops:
+            rc = fn(*args, st)
+            if rc != 0:
+                check(rc, what)
+
+    def run_timed(self):
+        """Eager run on the current stream with a HIP event pair around every launch.
+        Returns [(kind, meta, milliseconds)] in launch order (synchronises once, at the end)."""
+        st = _stream()
+        evs = []
+        for fn, args, what, meta in self.ops:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args, st)
+            e1.record()
+            if rc != 0:
+                check(rc, what)
+            evs.append((what, meta, e0, e1))
+        torch.cuda.synchronize()
+        return [(what, meta, e0.elapsed_time(e1)) for what, meta, e0, e1 in evs]
+
+    def count(self) -> Dict[str, int]:
+        out: Dict[str, int] = {}
+        for _, _, what, _ in self.ops:
+            out[what] = out.get(what, 0) + 1
+        return out

@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py — latent volumes/sec of the conditional 3D U-Net DDPM sampler at 32^3 x 8ch, T=1000 on MI355X.
+
+Contract (one JSON line from rank 0):  python bench.py --gpus N --steps K --warmup W
+  * workload: BASELINE.json configs[2] per GPU — conditional_dm3d U-Net (widths 64/128/256), 32^3 x 8ch latents,
+    B=32 volumes per GPU, T=1000 DDPM.  A "step" is one denoising step of the whole per-GPU batch: U-Net eps
+    prediction + posterior update (+ Philox noise) — every one of the T steps of a chain does exactly this work, so
+    value = volumes/sec for full T=1000 chains = N*B / (T * seconds_per_step); K steps of real chains are timed
+    (x_T ~ N(0,1), t = T-1, T-2, ...), nothing is skipped inside a step.
+  * N>1: one process per GPU (torchrun), rank 0's weights broadcast once over RCCL, batch sharded, no per-step
+    collective ("weak" scaling: B per GPU fixed).
+  * roofline: the dominant kernel is the k3/stride-1 Conv3d implicit GEMM (38 launches/step, 98 % of the FLOPs);
+    achieved = algorithmic FLOPs (2*27*Cin*Cout*B*Dout^3 per launch) / HIP-event time of those launches,
+    measured live on the launch stream; peak = fp32 MFMA 157.3 TFLOP/s (MI355X_MICROARCH.md) since the kernel uses
+    v_mfma_f32_32x32x2_f32.
+  * cpu_baseline: the CPU oracle (PyTorch-CPU restatement of the reference path; TensorFlow is not installed) on the
+    host cores, a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+T_FULL = 1000
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="volumes per GPU (BASELINE configs[2]: 32)")
+    ap.add_argument("--channels", type=int, default=8)
+    ap.add_argument("--size", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import dm3d_amd
+    from dm3d_amd import _lib, parallel
+    from dm3d_amd.networks import conditional_dm3d as cdm
+
+    rank, local_rank, world = parallel.env_rank()
+    if world != args.gpus:
+        if args.gpus != 1 and world == 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} processes (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    _lib.require_device()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B, S, Cc = args.batch, args.size, args.channels
+    cfg = dm3d_amd.UNetConfig(img_size=S, img_channels=Cc)
+    spec = dm3d_amd.param_spec(cfg)
+    W = dm3d_amd.synthetic_weights(cfg, seed=0) if rank == 0 else None
+    W = parallel.broadcast_state(W, spec, src=0, device=dev)              # RCCL broadcast over xGMI (no-op at N=1)
+    margs = SimpleNamespace(timesteps=T_FULL, num_gpus=world, kernel_resize=False, bs=B * world)
+    model = cdm.DiffusionModel(S, 1024, Cc, None, margs, device=dev, weights=W)
+    smp = model.sampler((B, S, S, S, Cc), context_value=1, seed=parallel.rank_seed(1234, rank),
+                        use_graph=not args.no_graph)
+    smp.reset()
+    K, Wm = args.steps, args.warmup
+    if K + Wm > T_FULL:
+        raise SystemExit("steps + warmup must not exceed T=1000")
+    for _ in range(Wm):
+        smp.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        smp.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    s_per_step = elapsed / K
+    value = world * B / (T_FULL * s_per_step)
+
+    # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream (rank 0) --------------
+    roofline = None
+    per_kind = {}
+    if rank == 0:
+        plan = smp.plan
+        plan.run_timed()                                                   # warm
+        reps = 2
+        acc = {}
+        for _ in range(reps):
+            for kind, meta, ms in plan.run_timed():
+                a = acc.setdefault(kind, [0, 0.0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += ms
+                a[2] += meta.get("flops", 0.0)
+                a[3] += meta.get("bytes", 0.0)
+        for kind, (n, ms, fl, by) in acc.items():
+            per_kind[kind] = {"launches_per_step": n // reps, "ms_per_step": round(ms / reps, 4),
+                              "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if fl else None}
+        n, ms, fl, by = acc["conv_k3s1"]
+        achieved = fl / (ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "conv3d_igemm_f32<4,8,8,1,3,4,1> (k3 stride-1 Conv3d, v_mfma_f32_32x32x2_f32)",
+                    "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(ms / n, 4), "launches_per_step": n // reps,
+                    "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
+                    "algorithmic_mb_per_launch": round(by / n / 1e6, 2)}
+
+    # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only) ----------------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ref_torch as rt
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        ocfg = rt.UNetConfig(img_size=S, img_channels=Cc)
+        Wt = {k: torch.from_numpy(v) for k, v in W.items()}
+        cb, csteps = 2, 4
+        g = torch.Generator().manual_seed(1234)
+        x = torch.randn(cb, S, S, S, Cc, generator=g)
+        noises = {i: torch.randn(cb, S, S, S, Cc, generator=g) for i in range(T_FULL - csteps - 1, T_FULL)}
+        betas = rt.Betas(T_FULL)
+        ctx = torch.tensor([[[1]]])
+        tt = torch.full((cb,), T_FULL - 1, dtype=torch.int64)
+        rt.unet_forward(Wt, ocfg, x, tt, ctx)                             # warm-up (oneDNN primitive creation)
+        c0 = time.perf_counter()
+        for i in range(T_FULL - 1, T_FULL - 1 - csteps, -1):
+            tt = torch.full((cb,), i, dtype=torch.int64)
+            x = rt.ddpm_step(betas, x, rt.unet_forward(Wt, ocfg, x, tt, ctx), tt, noises[i])
+        c_step = (time.perf_counter() - c0) / csteps
+        cpu = {"value": cb / (T_FULL * c_step), "unit": "volumes/s", "cores": cores, "kind": "port",
+               "sample": f"oracle/ref_torch.py (PyTorch-CPU fp32, oneDNN conv3d), B={cb}, {csteps} denoising steps of the "
+                         f"T=1000 chain at {S}^3x{Cc}ch, extrapolated x{T_FULL}/{csteps} (steps are identical work); "
+                         f"{c_step:.2f} s/step"}
+
+    if rank == 0:
+        line = {
+            "metric": "latent volumes/sec at 32^3x8ch T=1000 DDPM", "value": value, "unit": "volumes/s",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": s_per_step * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"conditional_dm3d U-Net (widths 64/128/256) DDPM sampling, {S}^3x{Cc}ch latents, "
+                                   f"B={B} volumes per GPU, T={T_FULL}; step = one denoising step of the batch "
+                                   f"(U-Net eps + posterior update + Philox noise, HIP-graph replay); "
+                                   f"value = n_gpus*B/(T*s_per_step)",
+                       "batch_per_gpu": B, "global_batch": B * world, "timesteps": T_FULL,
+                       "weights": "seeded synthetic (seed 0), rank-0 broadcast", "parallelism": f"batch-shard x{world}"},
+            "roofline": roofline, "cpu_baseline": cpu, "per_kernel_kind": per_kind,
+            "conv_mfma_util_pct": None if roofline is None else round(100 * roofline["frac"], 2),
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+/* dm3d.h — C ABI of libdm3d_hip.so: the MI355X (gfx950) kernels behind the 3D latent-diffusion denoising path.
+ *
+ * The reference (aayush9400/3D-Condtional-Stable-Diffusion) has no FFI / plugin boundary of its own: the path sits
+ * behind Keras layer objects (networks/conditional_dm3d.py:324-415 build_model, :517-575 sample/generate).  This
+ * header is therefore the build-defined replacement boundary: one entry point per stock
+ * TensorFlow/Keras op family the reference's hot path executes.  Each entry cites the reference call it replaces.
+ *
+ * Conventions
+ *   - plain C: raw device pointers, explicit sizes, a hipStream_t passed as void*; no torch types.
+ *   - every function enqueues on the caller's stream and returns without synchronising (graph-capturable);
+ *     nothing allocates, frees or retains pointers.  The caller owns every buffer.
+ *   - return 0 on success, a negative DM3D_E* code otherwise; dm3d_last_error() gives the thread-local text.
+ *   - all tensors float32, activations NDHWC (Keras channels_last), pointers 16-byte aligned.
+ */
+#ifndef DM3D_H
+#define DM3D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DM3D_VERSION 100          /* major*100 + minor */
+
+#define DM3D_OK            0
+#define DM3D_EINVAL       -1      /* bad argument (shape, alignment, null pointer) */
+#define DM3D_EUNSUPPORTED -2      /* valid request the kernels do not implement */
+#define DM3D_EHIP         -3      /* a HIP runtime call failed (text holds hipGetErrorString) */
+
+#define DM3D_ACT_NONE 0
+#define DM3D_ACT_RELU 1
+#define DM3D_ACT_SILU 2
+
+/* padded extents of packed weights */
+#define DM3D_COUT_PAD 64
+#define DM3D_CIN_PAD  16
+
+int         dm3d_version(void);
+const char* dm3d_last_error(void);
+/* 1 when a gfx950 device is visible to the calling process, 0 otherwise (never fails). */
+int         dm3d_device_ok(void);
+
+/* ---- weights ------------------------------------------------------------------------------------------------
+ * Keras kernels are [kd,kh,kw,Cin,Cout] (Conv3D, conditional_dm3d.py:257-259) or [in,out] (Dense, :251; taps=1).
+ * The kernels consume them as [taps][CoutPad][CinPad] (K contiguous per output channel, zero padded to
+ * DM3D_COUT_PAD / DM3D_CIN_PAD) so that one (tap, Cin-chunk) slice is a dense LDS image.
+ * in_scale (optional, [cin]) multiplies the rows — used to fold an inference BatchNormalization that directly
+ * precedes a 1x1 conv into its weights (CrossAttentionBlock norm -> proj_in, :187-188). */
+int64_t dm3d_packed_weight_elems(int32_t taps, int32_t cin, int32_t cout);
+int     dm3d_pack_weights(const float* keras_kernel, int32_t taps, int32_t cin, int32_t cout,
+                          const float* in_scale, float* packed, void* stream);
+
+/* ---- Conv3D(padding="same") as implicit GEMM on MFMA ---------------------------------------------------------
+ * Replaces layers.Conv3D for k=3/s=1 (:257-259, :348-353, :412-414), k=3/s=2 (DownSample :274-285, TF SAME pad 0
+ * before / 1 after on even sizes), k=1 (ResidualBlock skip :245-248) and UpSampling3D(2)+Conv3D (UpSample :288-296,
+ * upsample=1 reads the low-resolution tensor at index>>1).  Fused around it:
+ *   prologue  x -> silu(x*pro_scale[c] + pro_shift[c])   (inference BatchNormalization + swish, :255-256, 262-263,
+ *             410-411), applied before zero padding;
+ *   concat    channels of x1 then x2 (layers.Concatenate(axis=-1)([x, skip]), :396) without materialising it;
+ *   epilogue  + bias[co] + vec[row(b)][co] (the time-embedding Dense broadcast-add, :250-253, 260) then optional
+ *             ReLU, then + res (layers.Add with the residual, :268). */
+typedef struct dm3d_conv_desc {
+    const float* x1;            /* [batch, in_d, in_h, in_w, c1] */
+    const float* x2;            /* optional second input, same spatial shape, c2 channels (NULL if c2 == 0) */
+    int32_t c1, c2;             /* c1 % 4 == 0; with x2: c1 % 16 == 0 and c2 % 4 == 0 */
+    int32_t batch;
+    int32_t in_d, in_h, in_w;   /* physical extent of x1/x2 */
+    int32_t upsample;           /* 1: convolve the nearest-2x upsampled tensor (stride must be 1) */
+    int32_t ksize;              /* 1 or 3 */
+    int32_t stride;             /* 1 or 2 */
+    const float* wpk;           /* dm3d_pack_weights output for (ksize^3, c1+c2, cout) */
+    const float* bias;          /* [cout] or NULL */
+    const float* pro_scale;     /* [c1+c2] or NULL (both or neither) */
+    const float* pro_shift;
+    const float* vec;           /* [rows, vec_ld] or NULL */
+    const int32_t* vec_idx;     /* [batch] row of vec per sample, or NULL for row = sample index */
+    int32_t vec_ld;
+    int32_t relu;               /* 1: ReLU after bias/vec, before res */
+    const float* res;           /* [batch, out_d, out_h, out_w, cout] or NULL */
+    float* out;                 /* [batch, out_d, out_h, out_w, cout], out = ceil(in*(upsample?2:1)/stride) */
+    int32_t cout;
+} dm3d_conv_desc;
+
+int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream);
+
+/* ---- Dense / einsum contractions: out[b][m][n] = act(alpha * sum_k A[b][m][k]*B[b][n][k] + bias) + res -------
+ * Both operands K-contiguous ("TN").  Replaces layers.Dense on the last axis (:131-137, 164-169, 251, 301-304, 313),
+ * the 1x1 Conv3D projections of CrossAttentionBlock (:129-130) and the two attention einsums "blc,bLc->blL" /
+ * "blL,bLc->blc" (:177-180; U:51-61) as batched calls (stride_* in elements; 0 broadcasts an operand). */
+typedef struct dm3d_gemm_desc {
+    const float* a; int64_t lda; int64_t stride_a;
+    const float* b; int64_t ldb; int64_t stride_b;
+    float* out;     int64_t ldo; int64_t stride_o;
+    int32_t m, n, k, batch;     /* k % 4 == 0, lda/ldb % 4 == 0 */
+    float alpha;
+    const float* bias;          /* [n] (or [m] when bias_along_m) or NULL */
+    int32_t bias_along_m;
+    int32_t act;                /* DM3D_ACT_* applied after bias */
+    const float* res; int64_t ldr; int64_t stride_r;   /* added after act, or NULL */
+} dm3d_gemm_desc;
+
+int dm3d_gemm_tn(const dm3d_gemm_desc* d, void* stream);
+
+/* ---- LayerNormalization (eps passed; Keras default 1e-3) ------------------------------------------------------
+ * CrossAttentionBlock normalises the same tensor three times (norm1/2/3, :191-193): one pass computes the row
+ * statistics once and writes up to three affine outputs.  c % 4 == 0, c <= 1024. */
+int dm3d_layernorm3(const float* x, int64_t rows, int32_t c, float eps,
+                    const float* g1, const float* b1, float* o1,
+                    const float* g2, const float* b2, float* o2,
+                    const float* g3, const float* b3, float* o3, void* stream);
+
+/* ---- tf.nn.softmax(scores, -1) in place, one wavefront per row (shuffle reductions) (:178; U:56) ------------ */
+int dm3d_softmax_rows(float* s, int64_t rows, int32_t cols, int64_t ld, void* stream);
+
+/* ---- y = act(x*scale[c] + shift[c]) over the last axis (inference BatchNormalization of AttentionBlock, U:45;
+ * swish of the time embedding, :250); scale/shift may be NULL (identity). */
+int dm3d_affine_act(const float* x, float* y, int64_t rows, int32_t c, const float* scale, const float* shift,
+                    int32_t act, void* stream);
+
+/* ---- DDPM posterior step: DiffusionModel.sample + the loop body of generate (:517-548, 571-573) --------------
+ * Coefficients are gathered at t[b] and combined in float32 in the reference's order.
+ *   mode 0 (sample):   mean_out = posterior mean, var_out[b] = posterior variance (no clip, no noise).
+ *   mode 1 (generate): x <- clip(mean,-1,1) + sqrt(max(var,1e-20)) * z, z = noise (if given) or Philox N(0,1)
+ *                      keyed by (seed, t[b], element); z = 0 where t[b] == 0. */
+typedef struct dm3d_ddpm_desc {
+    float* x;                   /* [batch, per_sample] x_t (updated in place in mode 1) */
+    const float* eps;           /* predicted noise */
+    const float* noise;         /* optional injected z, same shape */
+    int32_t batch; int64_t per_sample;     /* per_sample % 4 == 0 */
+    const int32_t* t;           /* [batch] device */
+    int32_t timesteps;
+    const float *beta, *sqrt_alpha, *alpha_bar, *alpha_bar_prev, *sqrt_alpha_bar, *sqrt_alpha_bar_prev,
+                *sqrt_one_minus_alpha_bar;     /* [timesteps] device (Betas, :215-235) */
+    uint64_t seed;
+    int32_t mode;
+    float* mean_out; float* var_out;
+} dm3d_ddpm_desc;
+
+int dm3d_ddpm_update(const dm3d_ddpm_desc* d, void* stream);
+
+/* p[i] += delta (the loop counter of generate kept on the device so a captured step replays unchanged). */
+int dm3d_add_i32(int32_t* p, int32_t n, int32_t delta, void* stream);
+/* x ~ N(0,1) from Philox keyed by (seed, stream_id): the x_T draw of generate (:555). n % 4 == 0. */
+int dm3d_randn(float* x, int64_t n, uint64_t seed, uint32_t stream_id, void* stream);
+/* out[r][:] = table[idx[r]][:] (tf.gather / Embedding lookup, :358, 518-538). c % 4 == 0. */
+int dm3d_gather_rows(const float* table, int32_t table_rows, const int32_t* idx, float* out, int32_t rows,
+                     int32_t c, void* stream);
+
+/* ---- HIP graph capture of one denoising step (replaces the eager per-op Python loop of generate, :559-573) -- */
+int dm3d_graph_begin(void* stream);
+int dm3d_graph_end(void* stream, void** graph_exec_out);
+int dm3d_graph_launch(void* graph_exec, void* stream);
+int dm3d_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DM3D_H */

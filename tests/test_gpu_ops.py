@@ -1,0 +1,300 @@
+"""GPU parity tests, kernel by kernel, through the C ABI, against the CPU oracle (oracle/ref_torch.py) in float64.
+
+Tolerances: fp32 MFMA accumulates K products with one rounding each, so |err| <= ~K * 2^-24 * sum|a.b|; the checks use
+max|err| / max|ref| <= 2e-5 for contractions (1e-3 is the end-to-end budget north_star states) and 1e-6 for elementwise.
+"""
+import ctypes as C
+import math
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from dm3d_amd import _lib
+    _lib.require_device()
+    torch.cuda.set_device(0)
+    return torch.device("cuda:0")
+
+
+def _rel(a, ref):
+    ref = ref.double()
+    return float((a.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def _conv_ref(x1, kern, bias, *, x2=None, stride=1, upsample=False, pro=None, vec=None, vec_idx=None, relu=False, res=None):
+    from oracle import ref_torch as rt
+    x = x1.double() if x2 is None else torch.cat([x1.double(), x2.double()], -1)
+    if pro is not None:
+        x = rt._swish(x * pro[0].double() + pro[1].double())
+    if upsample:
+        x = rt._upsample2(x)
+    y = rt._conv3d(x, kern.double(), None if bias is None else bias.double(), stride=stride)
+    if vec is not None:
+        rows = vec_idx.long() if vec_idx is not None else torch.arange(x1.shape[0])
+        y = y + vec.double()[rows][:, None, None, None, :y.shape[-1]]
+    if relu:
+        y = torch.relu(y)
+    if res is not None:
+        y = y + res.double()
+    return y
+
+
+CONV_CASES = [
+    # name, B, (D,H,W), c1, c2, cout, ksize, stride, upsample, extras
+    ("k3_exact_tile", 2, (8, 8, 8), 16, 0, 64, 3, 1, False, ""),
+    ("k3_noncubic_coutmask_bias", 1, (4, 8, 16), 32, 0, 40, 3, 1, False, "bias"),
+    ("k3_all_epilogue", 2, (8, 8, 8), 32, 0, 64, 3, 1, False, "bias pro vec res relu"),
+    ("k3_vec_idx", 3, (8, 8, 8), 16, 0, 64, 3, 1, False, "bias vec vecidx"),
+    ("k3_dual_input_pro", 2, (8, 8, 8), 16, 32, 64, 3, 1, False, "bias pro"),
+    ("k3_conv_in_c8", 2, (8, 8, 8), 8, 0, 32, 3, 1, False, "bias"),
+    ("k3_conv_in_c4", 1, (8, 8, 8), 4, 0, 32, 3, 1, False, "bias"),
+    ("k3_conv_out_c8", 1, (8, 8, 8), 64, 0, 8, 3, 1, False, "bias pro"),
+    ("k3_cout128", 1, (8, 8, 8), 32, 0, 128, 3, 1, False, "bias"),
+    ("k3_partial_brick_4", 2, (4, 4, 4), 32, 0, 64, 3, 1, False, "bias res"),
+    ("k3_partial_brick_2", 2, (2, 2, 2), 16, 0, 64, 3, 1, False, "bias"),
+    ("k3_16cube", 1, (16, 16, 16), 16, 0, 64, 3, 1, False, "bias"),
+    ("k3s2_8to4", 2, (8, 8, 8), 16, 0, 64, 3, 2, False, "bias"),
+    ("k3s2_16to8", 1, (16, 16, 16), 32, 0, 32, 3, 2, False, "bias"),
+    ("k3s2_4to2", 1, (4, 4, 4), 16, 0, 64, 3, 2, False, "bias"),
+    ("k3_upsample_4to8", 2, (4, 4, 4), 32, 0, 32, 3, 1, True, "bias"),
+    ("k3_upsample_8to16", 1, (8, 8, 8), 16, 0, 64, 3, 1, True, "bias"),
+    ("k1_dual", 2, (8, 8, 8), 32, 16, 64, 1, 1, False, "bias"),
+    ("k1_relu_res", 1, (4, 4, 4), 64, 0, 64, 1, 1, False, "bias relu res"),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv3d(dev, case):
+    from dm3d_amd import ops
+    name, B, (D, H, W), c1, c2, cout, ks, stride, ups, extras = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    cin = c1 + c2
+    x1 = rnd(B, D, H, W, c1)
+    x2 = rnd(B, D, H, W, c2) if c2 else None
+    kern = rnd(ks, ks, ks, cin, cout) / math.sqrt(cin * ks ** 3)
+    bias = rnd(cout) if "bias" in extras else None
+    pro = (torch.rand(cin, generator=g) + 0.5, rnd(cin) * 0.1) if "pro" in extras else None
+    up = 2 if ups else 1
+    od, oh, ow = (-(-D * up // stride), -(-H * up // stride), -(-W * up // stride))
+    vec = rnd(5, cout + 8) if "vec" in extras else None
+    vec_idx = torch.tensor([4, 0, 2][:B], dtype=torch.int32) if "vecidx" in extras else None
+    res = rnd(B, od, oh, ow, cout) if "res" in extras else None
+    ref = _conv_ref(x1, kern, bias, x2=x2, stride=stride, upsample=ups, pro=pro, vec=vec, vec_idx=vec_idx,
+                    relu="relu" in extras, res=res)
+    c = lambda t: None if t is None else t.to(dev).contiguous()
+    wpk = ops.pack_weights(c(kern))
+    out = ops.conv3d(c(x1), wpk, cout, ks, x2=c(x2), bias=c(bias), stride=stride, upsample=ups,
+                     pro_scale=c(pro[0]) if pro else None, pro_shift=c(pro[1]) if pro else None,
+                     vec=c(vec), vec_idx=c(vec_idx), relu="relu" in extras, res=c(res))
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == tuple(ref.shape)
+    err = _rel(out, ref)
+    assert err < 2e-5, f"{name}: rel err {err:.3e}"
+
+
+def test_conv3d_argument_errors(dev):
+    from dm3d_amd import ops
+    from dm3d_amd._lib import Dm3dError
+    x = torch.zeros(1, 4, 4, 4, 6, device=dev)
+    w = torch.zeros(27 * 64 * 16, device=dev)
+    with pytest.raises(Dm3dError):
+        ops.conv3d(x, w, 8, 3)                      # c1 % 4 != 0
+    x = torch.zeros(1, 4, 4, 4, 8, device=dev)
+    with pytest.raises(Dm3dError):
+        ops.conv3d(x, w, 8, 2)                      # ksize 2
+    with pytest.raises(Dm3dError):
+        ops.conv3d(x, w, 8, 3, stride=2, upsample=True)
+
+
+GEMM_CASES = [
+    ("plain", dict(m=256, n=64, k=32)),
+    ("guards", dict(m=300, n=70, k=36)),
+    ("tiny_m", dict(m=2, n=200, k=128)),
+    ("bias_relu_res", dict(m=130, n=96, k=64, bias=True, act=1, res=True)),
+    ("bias_m_silu", dict(m=96, n=130, k=64, bias=True, bias_m=True, act=2)),
+    ("alpha_batched", dict(m=64, n=64, k=48, batch=3, alpha=0.0625)),
+    ("batched_broadcast_b", dict(m=64, n=40, k=64, batch=4, bcast_b=True, res=True)),
+    ("long_k", dict(m=64, n=64, k=1024)),
+]
+
+
+@pytest.mark.parametrize("case", GEMM_CASES, ids=[c[0] for c in GEMM_CASES])
+def test_gemm_tn(dev, case):
+    from dm3d_amd import ops
+    name, kw = case
+    m, n, k, batch = kw["m"], kw["n"], kw["k"], kw.get("batch", 1)
+    g = torch.Generator().manual_seed(len(name) * 7919)
+    a = torch.randn(batch, m, k, generator=g)
+    b = torch.randn(1 if kw.get("bcast_b") else batch, n, k, generator=g)
+    bias = torch.randn(m if kw.get("bias_m") else n, generator=g) if kw.get("bias") else None
+    res = torch.randn(batch, m, n, generator=g) if kw.get("res") else None
+    alpha = kw.get("alpha", 1.0)
+    ref = torch.einsum("bmk,bnk->bmn", a.double(), b.double().expand(batch, n, k)) * alpha
+    if bias is not None:
+        ref = ref + (bias.double()[None, :, None] if kw.get("bias_m") else bias.double())
+    act = kw.get("act", 0)
+    if act == 1:
+        ref = torch.relu(ref)
+    elif act == 2:
+        ref = ref * torch.sigmoid(ref)
+    if res is not None:
+        ref = ref + res.double()
+    c = lambda t: None if t is None else t.to(dev).contiguous()
+    out = ops.gemm_tn(c(a), c(b), m=m, n=n, k=k, batch=batch, stride_a=m * k, stride_b=0 if kw.get("bcast_b") else n * k,
+                      alpha=alpha, bias=c(bias), bias_along_m=bool(kw.get("bias_m")), act=act, res=c(res),
+                      out=torch.empty(batch, m, n, device=dev))
+    torch.cuda.synchronize()
+    err = _rel(out, ref)
+    assert err < 2e-5, f"{name}: rel err {err:.3e}"
+
+
+def test_gemm_strided_views(dev):
+    """q|k packed in one [M, 2u] buffer, scores = q k^T per sample (the layout the attention blocks use)."""
+    from dm3d_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, L, u = 2, 64, 32
+    qk = torch.randn(B * L, 2 * u, generator=g)
+    ref = torch.einsum("blc,bmc->blm", qk[:, :u].reshape(B, L, u).double(), qk[:, u:].reshape(B, L, u).double())
+    qkd = qk.to(dev)
+    out = torch.empty(B, L, L, device=dev)
+    from dm3d_amd._lib import GemmDesc, lib, check
+    d = GemmDesc()
+    d.a, d.lda, d.stride_a = qkd.data_ptr(), 2 * u, L * 2 * u
+    d.b, d.ldb, d.stride_b = qkd.data_ptr() + 4 * u, 2 * u, L * 2 * u
+    d.out, d.ldo, d.stride_o = out.data_ptr(), L, L * L
+    d.m, d.n, d.k, d.batch, d.alpha = L, L, u, B, 1.0
+    check(lib().dm3d_gemm_tn(C.byref(d), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert _rel(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("rows,c", [(37, 256), (5, 48), (1024, 256), (3, 1024)])
+def test_layernorm3(dev, rows, c):
+    from dm3d_amd import ops
+    g = torch.Generator().manual_seed(rows * c)
+    x = torch.randn(rows, c, generator=g) * 2 + 0.3
+    params = [(torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)) for _ in range(3)]
+    outs = ops.layernorm3(x.to(dev), [(a.to(dev), b.to(dev)) for a, b in params], eps=1e-3)
+    torch.cuda.synchronize()
+    for (ga, be), o in zip(params, outs):
+        ref = torch.nn.functional.layer_norm(x.double(), (c,), ga.double(), be.double(), 1e-3)
+        assert _rel(o, ref) < 3e-6
+    only2 = ops.layernorm3(x.to(dev), [(a.to(dev), b.to(dev)) for a, b in params[:2]], eps=1e-3)
+    assert len(only2) == 2 and _rel(only2[1], torch.nn.functional.layer_norm(
+        x.double(), (c,), params[1][0].double(), params[1][1].double(), 1e-3)) < 3e-6
+
+
+@pytest.mark.parametrize("rows,cols", [(9, 512), (130, 64), (7, 100), (4, 8), (3, 1500), (2, 1024)])
+def test_softmax_rows(dev, rows, cols):
+    from dm3d_amd import ops
+    g = torch.Generator().manual_seed(cols)
+    s = torch.randn(rows, cols, generator=g) * 4
+    s[0, 0] = 30.0                                  # a dominant logit
+    out = ops.softmax_rows_(s.to(dev).clone())
+    torch.cuda.synchronize()
+    ref = torch.softmax(s.double(), -1)
+    assert float((out.double().cpu() - ref).abs().max()) < 2e-6
+    assert torch.allclose(out.sum(-1).cpu(), torch.ones(rows), atol=1e-5)
+
+
+def test_affine_act(dev):
+    from dm3d_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(33, 64, generator=g) * 3
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    y = x.double() * sc.double() + sh.double()
+    for act, ref in ((0, y), (1, torch.relu(y)), (2, y * torch.sigmoid(y))):
+        out = ops.affine_act(x.to(dev), sc.to(dev), sh.to(dev), act)
+        assert _rel(out, ref) < 1e-6
+    assert _rel(ops.affine_act(x.to(dev), None, None, 2), x.double() * torch.sigmoid(x.double())) < 1e-6
+
+
+def _model(dev, T=50, S=8, Cc=4, weights=None):
+    from types import SimpleNamespace
+    from dm3d_amd.networks import conditional_dm3d as cdm
+    return cdm.DiffusionModel(S, 1024, Cc, None, SimpleNamespace(timesteps=T, num_gpus=1, kernel_resize=False, bs=1),
+                              weights=weights)
+
+
+def test_ddpm_sample_matches_oracle(dev):
+    """DiffusionModel.sample (conditional_dm3d.py:517-548) incl. the t=0 variance known answer."""
+    from oracle import ref_torch as rt
+    m = _model(dev, T=1000)
+    g = torch.Generator().manual_seed(11)
+    x, e = torch.randn(4, 8, 8, 8, 4, generator=g), torch.randn(4, 8, 8, 8, 4, generator=g)
+    t = torch.tensor([0, 1, 500, 999])
+    mean, var = m.sample(x.to(dev), e.to(dev), t, x.shape)
+    rm, rv = rt.ddpm_sample(rt.Betas(1000), x, e, t)
+    assert tuple(var.shape) == (4, 1, 1, 1, 1)
+    assert float((mean.cpu() - rm).abs().max() / rm.abs().max()) < 1e-6
+    assert float((var.cpu() - rv).abs().max()) < 1e-9
+    assert float(var[0]) == 0.0                      # alpha_bar_prev[0] == 1 -> posterior variance 0 at t=0
+
+
+def test_ddpm_step_kernel(dev):
+    from dm3d_amd._lib import lib, check
+    from oracle import ref_torch as rt
+    m = _model(dev, T=1000)
+    g = torch.Generator().manual_seed(12)
+    x, e, z = (torch.randn(3, 8, 8, 8, 4, generator=g) for _ in range(3))
+    t = torch.tensor([0, 7, 999])
+    ref = rt.ddpm_step(rt.Betas(1000), x, e, t, z * (t > 0).float().reshape(3, 1, 1, 1, 1))
+    xd, td = x.to(dev).clone(), t.to(torch.int32).to(dev)
+    d = m._ddpm_desc(xd, e.to(dev), td, 1, noise=z.to(dev))
+    check(lib().dm3d_ddpm_update(C.byref(d), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert float((xd.cpu() - ref).abs().max()) < 2e-6
+    # in-kernel Philox: deterministic per (seed, t), zero noise at t == 0, unit variance elsewhere
+    big = torch.zeros(2, 32, 32, 32, 8, device=dev)
+    outs = []
+    for seed in (1, 1, 2):
+        xb = big.clone()
+        d = m._ddpm_desc(xb, torch.zeros_like(xb), torch.tensor([0, 500], dtype=torch.int32, device=dev), 1, seed=seed)
+        check(lib().dm3d_ddpm_update(C.byref(d), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        outs.append(xb.cpu())
+    assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0][1], outs[2][1])
+    assert float(outs[0][0].abs().max()) == 0.0
+    b = rt.Betas(1000)
+    sigma = math.sqrt(float((1 - b.alpha_bar_prev[500]) * b.beta[500] / (1 - b.alpha_bar[500])))
+    zs = outs[0][1] / sigma
+    assert abs(float(zs.mean())) < 0.01 and abs(float(zs.std()) - 1) < 0.01
+
+
+def test_randn_statistics(dev):
+    from dm3d_amd import ops
+    x = ops.randn((1 << 20,), seed=7, stream_id=3, device=dev).cpu().double()
+    assert abs(float(x.mean())) < 5e-3 and abs(float(x.std()) - 1) < 5e-3
+    assert abs(float((x ** 3).mean())) < 2e-2 and abs(float((x ** 4).mean()) - 3) < 5e-2
+    assert torch.equal(ops.randn((4096,), 7, 3, dev), ops.randn((4096,), 7, 3, dev))
+    assert not torch.equal(ops.randn((4096,), 7, 3, dev), ops.randn((4096,), 8, 3, dev))
+
+
+def test_gather_add_graph(dev):
+    from dm3d_amd._lib import lib, check
+    st = torch.cuda.current_stream().cuda_stream
+    tab = torch.arange(5 * 8, dtype=torch.float32, device=dev).reshape(5, 8)
+    idx = torch.tensor([4, 0, 3], dtype=torch.int32, device=dev)
+    out = torch.empty(3, 8, device=dev)
+    check(lib().dm3d_gather_rows(tab.data_ptr(), 5, idx.data_ptr(), out.data_ptr(), 3, 8, st))
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), tab.cpu()[[4, 0, 3]])
+    cnt = torch.full((3,), 10, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    cap = torch.cuda.Stream()
+    g = C.c_void_p()
+    check(lib().dm3d_graph_begin(cap.cuda_stream))
+    check(lib().dm3d_add_i32(cnt.data_ptr(), 3, -1, cap.cuda_stream))
+    check(lib().dm3d_graph_end(cap.cuda_stream, C.byref(g)))
+    for _ in range(4):
+        check(lib().dm3d_graph_launch(g, st))
+    torch.cuda.synchronize()
+    assert cnt.cpu().tolist() == [6, 6, 6]
+    check(lib().dm3d_graph_destroy(g))
