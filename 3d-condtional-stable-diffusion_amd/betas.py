@@ -44,10 +44,14 @@ class Betas:
 
 
 def time_embedding_table(t, dim: int) -> np.ndarray:
-    """TimeEmbedding(dim)(t) for an integer vector t, float32 throughout:
-    f = exp(arange(half) * -(ln(10000)/(half-1))), emb = [sin(t*f), cos(t*f)]."""
+    """TimeEmbedding(dim)(t) for an integer vector t, float32 throughout, on the host:
+    f = exp(arange(half) * -(ln(10000)/(half-1))), emb = [sin(t*f), cos(t*f)].
+
+    At t ~ 1000 one ulp in f moves the argument by ~6e-5 rad, so the exp/sin/cos implementation matters at the 1e-5
+    level; PyTorch's CPU float32 kernels are used (host-side table construction, not the device path)."""
+    import torch
     half = dim // 2
     emb = math.log(10000) / (half - 1)
-    freqs = np.exp(np.arange(half, dtype=np.float32) * np.float32(-emb)).astype(np.float32)
-    arg = np.asarray(t).astype(np.float32)[:, None] * freqs[None, :]
-    return np.concatenate([np.sin(arg), np.cos(arg)], axis=-1).astype(np.float32)
+    freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -emb)
+    arg = torch.as_tensor(np.asarray(t)).to(torch.float32)[:, None] * freqs[None, :]
+    return torch.cat([torch.sin(arg), torch.cos(arg)], dim=-1).numpy().astype(np.float32)

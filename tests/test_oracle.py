@@ -1,0 +1,144 @@
+"""CPU tier: the oracle against its own golden vectors, the second restatement and the reference-derived known answers
+(SURVEY.md §8(c) i-vi).  PARITY UNPINNED: the reference has no golden data; see oracle/ref_torch.py."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import ref_numpy as rn
+from oracle import ref_torch as rt
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_betas_known_answers_and_golden():
+    g = np.load(os.path.join(GOLD, "tables.npz"))
+    for T in (50, 1000):
+        b = rt.Betas(T)
+        assert abs(float(b.beta[0]) - 1e-4) < 1e-10 and abs(float(b.beta[-1]) - 0.02) < 1e-8      # (i)
+        assert float(b.alpha_bar_prev[0]) == 1.0
+        ab = b.alpha_bar.numpy()
+        assert np.all(np.diff(ab) < 0)
+        tab = rn.betas(T)
+        for n in b.NAMES:
+            assert np.array_equal(getattr(b, n).numpy(), g[f"betas{T}.{n}"])
+            assert np.allclose(getattr(b, n).numpy(), tab[n], rtol=1e-6, atol=0)
+
+
+def test_time_embedding_known_answers_and_golden():
+    g = np.load(os.path.join(GOLD, "tables.npz"))
+    e0 = rt.time_embedding(torch.tensor([0]), 128)[0]
+    assert torch.equal(e0[:64], torch.zeros(64)) and torch.equal(e0[64:], torch.ones(64))           # (ii)
+    e = rt.time_embedding(torch.tensor(g["temb128.t"]), 128).numpy()
+    assert np.allclose(e, g["temb128"], atol=1e-6)
+    assert np.allclose(e, rn.time_embedding(g["temb128.t"], 128), atol=2e-4)   # fp32 argument rounding at t~1000
+    one = rt.time_embedding(torch.tensor([1]), 128)[0]
+    assert abs(float(one[0]) - np.sin(1.0)) < 1e-6 and abs(float(one[63]) - np.sin(1e-4)) < 1e-9   # f_0=1, f_last=1e-4
+
+
+def test_last_step_is_deterministic():
+    b = rt.Betas(10)                                                                                 # (iii)
+    x, e = torch.randn(2, 2, 2, 2, 3), torch.randn(2, 2, 2, 2, 3)
+    t0 = torch.zeros(2, dtype=torch.int64)
+    _, var = rt.ddpm_sample(b, x, e, t0)
+    assert float(var.abs().max()) == 0.0
+    a = rt.ddpm_step(b, x, e, t0, torch.randn_like(x))
+    c = rt.ddpm_step(b, x, e, t0, torch.zeros_like(x))
+    assert float((a - c).abs().max()) < 1e-9                     # sqrt(1e-20) * z
+
+
+def test_fresh_keras_init_outputs_near_zero():
+    cfg = rt.UNetConfig(img_size=4, img_channels=4, widths=(16, 32), has_attention=(False, True), first_conv_channels=16)
+    W = rt.keras_default_weights(cfg, seed=0)                                                        # (iv)
+    x = torch.randn(1, 4, 4, 4, 4)
+    y = rt.unet_forward(W, cfg, x, torch.tensor([5]), torch.tensor([[[1]]]))
+    assert float(y.abs().max()) < 1e-2
+    assert float(rt.unet_forward(rt.synthetic_weights(cfg, 0), cfg, x, torch.tensor([5]), torch.tensor([[[1]]])).abs().max()) > 0.1
+
+
+def test_param_inventory_matches_survey():
+    spec = rt.param_spec(rt.UNetConfig(img_size=32, img_channels=8))                                 # (v)
+    assert abs(sum(int(np.prod(s)) for s in spec.values()) / 1e6 - 145.84) < 0.01
+    assert spec["up2.res0.conv1.kernel"] == (3, 3, 3, 512, 256) and spec["up0.res2.conv1.kernel"] == (3, 3, 3, 96, 64)
+    assert spec["mid.attn.ctx_mlp.kernel"] == (128, 512 * 256)
+    u = rt.param_spec(rt.UNetConfig(img_size=16, img_channels=4, conditional=False))
+    assert abs(sum(int(np.prod(s)) for s in u.values()) / 1e6 - 41.38) < 0.01
+    assert u["up0.res2.conv1.kernel"] == (3, 3, 3, 128, 64) and "mid.attn.depth.kernel" not in u
+
+
+def test_stride2_same_padding():
+    x = torch.arange(2 * 4 * 4 * 4 * 1, dtype=torch.float32).reshape(2, 4, 4, 4, 1)                  # (vi)
+    k = torch.zeros(3, 3, 3, 1, 1)
+    k[0, 0, 0] = 1.0                                   # picks x[2o + 0]: pad 0 before
+    y = rt._conv3d(x, k, torch.zeros(1), stride=2)
+    assert y.shape == (2, 2, 2, 2, 1) and torch.equal(y, x[:, ::2, ::2, ::2])
+    k = torch.zeros(3, 3, 3, 1, 1)
+    k[2, 2, 2] = 1.0                                   # picks x[2o + 2]: the last one falls in the trailing pad
+    y = rt._conv3d(x, k, torch.zeros(1), stride=2)
+    assert float(y[:, 1].abs().max()) == 0.0 and torch.equal(y[:, 0, 0, 0], x[:, 2, 2, 2])
+
+
+def test_oracle_matches_golden_and_second_restatement():
+    for cond, name in ((True, "unet_cond_s8c4.npz"), (False, "unet_uncond_s8c4.npz")):
+        g = np.load(os.path.join(GOLD, name))
+        cfg = rt.UNetConfig(img_size=8, img_channels=4, conditional=cond)
+        W = rt.synthetic_weights(cfg, seed=0)
+        x, t = torch.from_numpy(g["x"]), torch.from_numpy(g["t"])
+        ctx = torch.from_numpy(g["ctx"]) if cond else None
+        taps = {}
+        eps = rt.unet_forward(W, cfg, x[:2], t[:2], None if ctx is None else ctx[:2], taps=taps)
+        ref = torch.from_numpy(g["eps"][:2])
+        assert float((eps - ref).abs().max() / ref.abs().max()) < 2e-5
+        for k in ("down0.res0", "down0.ds", "mid.attn", "up2.res0", "up1.us"):
+            r = torch.from_numpy(g["tap." + k])
+            assert float((taps[k][:1] - r).abs().max() / r.abs().max()) < 2e-5
+        # independent NumPy/fp64 restatement on sample 0 (t = 0: exact sinusoid)
+        en = rn.unet_forward({k: v.numpy() for k, v in W.items()}, cfg, g["x"][:1], g["t"][:1],
+                             None if ctx is None else g["ctx"][:1])
+        assert np.abs(en - g["eps64"][:1]).max() / np.abs(en).max() < 1e-10
+
+
+def test_blocks_torch_vs_numpy_small():
+    cfg = rt.UNetConfig(img_size=4, img_channels=4, widths=(8, 16), has_attention=(False, True), first_conv_channels=8)
+    W = rt.synthetic_weights(cfg, seed=2)
+    W64 = {k: v.double() for k, v in W.items()}
+    Wn = rn.to_f64({k: v.numpy() for k, v in W.items()})
+    x = torch.randn(2, 4, 4, 4, 8, dtype=torch.float64)
+    temb = torch.randn(2, 32, dtype=torch.float64)
+    a = rt.residual_block(W64, "down0.res1", x, temb).numpy()
+    b = rn.residual_block(Wn, "down0.res1", x.numpy(), temb.numpy())
+    assert np.abs(a - b).max() < 1e-11
+    y = torch.randn(2, 2, 2, 2, 16, dtype=torch.float64)
+    ctx = torch.randn(1, 2, 2, 2, 16, dtype=torch.float64)
+    a = rt.cross_attention_block(W64, "mid.attn", y, ctx).numpy()
+    b = rn.cross_block(Wn, "mid.attn", y.numpy(), ctx.numpy())
+    assert np.abs(a - b).max() < 1e-11
+    # stride-2 and upsample convs
+    k = torch.randn(3, 3, 3, 8, 8, dtype=torch.float64)
+    bias = torch.randn(8, dtype=torch.float64)
+    assert np.abs(rt._conv3d(x, k, bias, stride=2).numpy() - rn.conv3d_same(x.numpy(), k.numpy(), bias.numpy(), stride=2)).max() < 1e-12
+    assert np.abs(rt._conv3d(rt._upsample2(x), k, bias).numpy()
+                  - rn.conv3d_same(x.numpy(), k.numpy(), bias.numpy(), upsample=True)).max() < 1e-12
+
+
+def test_generate_golden_trajectory():
+    g = np.load(os.path.join(GOLD, "generate_cond_s8c4_T5.npz"))
+    cfg = rt.UNetConfig(img_size=8, img_channels=4)
+    W = rt.synthetic_weights(cfg, seed=0)
+    traj = []
+    out = rt.generate(W, cfg, rt.Betas(5), 5, torch.from_numpy(g["x_T"]), torch.from_numpy(g["noises"]),
+                      context_value=1, trajectory=traj)
+    assert float((traj[0] - torch.from_numpy(g["step0"])).abs().max()) < 1e-4
+    assert float((out - torch.from_numpy(g["final"])).abs().max()) < 1e-3
+    # numpy restatement of one update
+    tab = rn.betas(5)
+    x, e, z = np.random.default_rng(0).normal(size=(3, 2, 2, 2, 2, 1))
+    ref = rt.ddpm_step(rt.Betas(5), torch.from_numpy(x).float(), torch.from_numpy(e).float(),
+                       torch.full((2,), 3), torch.from_numpy(z).float()).numpy()
+    assert np.abs(ref - rn.ddpm_step(tab, x, e, 3, z)).max() < 1e-5
+
+
+def test_train_loss_definition():
+    n, p = torch.randn(2, 2, 2, 2, 4), torch.randn(2, 2, 2, 2, 4)
+    lo = rt.train_loss(n, p, global_bs=8, lc=4)
+    assert abs(float(lo) - float(((n - p) ** 2).sum() / 4 / (8 * 256))) < 1e-7
