@@ -28,6 +28,24 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 T_FULL = 1000
+_T0 = time.time()
+
+
+def log(msg):
+    """Progress on stderr (stdout carries exactly one JSON line)."""
+    print(f"[bench +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores() -> int:
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
 
 
 def main():
@@ -61,6 +79,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B, S, Cc = args.batch, args.size, args.channels
+    log(f"rank {rank}/{world}: building weights and model (B={B}, {S}^3x{Cc})")
     cfg = dm3d_amd.UNetConfig(img_size=S, img_channels=Cc)
     spec = dm3d_amd.param_spec(cfg)
     W = dm3d_amd.synthetic_weights(cfg, seed=0) if rank == 0 else None
@@ -70,12 +89,15 @@ def main():
     smp = model.sampler((B, S, S, S, Cc), context_value=1, seed=parallel.rank_seed(1234, rank),
                         use_graph=not args.no_graph)
     smp.reset()
+    torch.cuda.synchronize()
+    log("model prepared; warm-up")
     K, Wm = args.steps, args.warmup
     if K + Wm > T_FULL:
         raise SystemExit("steps + warmup must not exceed T=1000")
     for _ in range(Wm):
         smp.step()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        log("warm-up step done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -88,6 +110,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
     s_per_step = elapsed / K
+    log(f"timed {K} steps: {s_per_step * 1e3:.2f} ms/step")
     value = world * B / (T_FULL * s_per_step)
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream (rank 0) --------------
@@ -121,11 +144,12 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import ref_torch as rt
-        cores = os.cpu_count() or 1
+        cores = host_cores()
+        log(f"cpu baseline on {cores} threads (os.cpu_count()={os.cpu_count()})")
         torch.set_num_threads(cores)
         ocfg = rt.UNetConfig(img_size=S, img_channels=Cc)
         Wt = {k: torch.from_numpy(v) for k, v in W.items()}
-        cb, csteps = 2, 4
+        cb, csteps = 2, 3
         g = torch.Generator().manual_seed(1234)
         x = torch.randn(cb, S, S, S, Cc, generator=g)
         noises = {i: torch.randn(cb, S, S, S, Cc, generator=g) for i in range(T_FULL - csteps - 1, T_FULL)}
@@ -137,6 +161,7 @@ def main():
         for i in range(T_FULL - 1, T_FULL - 1 - csteps, -1):
             tt = torch.full((cb,), i, dtype=torch.int64)
             x = rt.ddpm_step(betas, x, rt.unet_forward(Wt, ocfg, x, tt, ctx), tt, noises[i])
+            log(f"cpu step t={i} done")
         c_step = (time.perf_counter() - c0) / csteps
         cpu = {"value": cb / (T_FULL * c_step), "unit": "volumes/s", "cores": cores, "kind": "port",
                "sample": f"oracle/ref_torch.py (PyTorch-CPU fp32, oneDNN conv3d), B={cb}, {csteps} denoising steps of the "

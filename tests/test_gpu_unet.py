@@ -148,7 +148,7 @@ def test_unet_eps_full_size_32cube(dev):
     g = torch.Generator().manual_seed(21)
     x = torch.randn(1, 32, 32, 32, 8, generator=g)
     t, ctx = torch.tensor([637]), torch.tensor([[[1]]])
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     ref = rt.unet_forward({k: torch.from_numpy(v) for k, v in W.items()}, rt.UNetConfig(img_size=32, img_channels=8), x, t, ctx)
     eps = net([x.to(dev), t, ctx])
     torch.cuda.synchronize()
