@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdm3d_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
+PREC_F32, PREC_H3 = 0, 1
 COUT_PAD, CIN_PAD = 64, 16
 
 _f32p = C.c_void_p      # device pointers travel as integers
@@ -25,6 +26,7 @@ class ConvDesc(C.Structure):
         ("ksize", C.c_int32), ("stride", C.c_int32), ("wpk", _f32p), ("bias", _f32p),
         ("pro_scale", _f32p), ("pro_shift", _f32p), ("vec", _f32p), ("vec_idx", _i32p), ("vec_ld", C.c_int32),
         ("relu", C.c_int32), ("res", _f32p), ("out", _f32p), ("cout", C.c_int32),
+        ("precision", C.c_int32), ("w_exp", C.c_int32),
     ]
 
 
@@ -56,6 +58,8 @@ SIGNATURES = {
     "dm3d_device_ok": (C.c_int, []),
     "dm3d_packed_weight_elems": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "dm3d_pack_weights": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, _f32p, _f32p, C.c_void_p]),
+    "dm3d_packed_weight_h3_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "dm3d_pack_weights_h3": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p, C.c_void_p, C.c_void_p]),
     "dm3d_conv3d_ndhwc": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "dm3d_gemm_tn": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "dm3d_layernorm3": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_float] + [_f32p] * 9 + [C.c_void_p]),

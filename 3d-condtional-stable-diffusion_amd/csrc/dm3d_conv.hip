@@ -13,23 +13,10 @@
 // Every input element is fetched from HBM/L2 once per workgroup and chunk (halo overhead 2.3x for a 4x8x8 brick) instead
 // of k^3 times, and activation tensors are read in their raw form, so norm/activation/concat/upsample never round-trip
 // through HBM.  LDS: 600*20*4 + 2*64*20*4 = 58 KB -> two workgroups per CU, whose staging and MFMA phases overlap.
-#include "dm3d_common.h"
+#include "dm3d_conv_args.h"
+#include <math.h>
 
 namespace {
-
-struct ConvArgs {
-    const float* x1; const float* x2; int c1, c2;
-    int ind, inh, inw;        // physical input extent
-    int lgd, lgh, lgw;        // logical extent seen by the conv (2x when upsampling)
-    int od, oh, ow;
-    int ups, pad;             // pad = zero voxels in front of index 0 (TF SAME)
-    const float* wpk; int cinpad, coutpad;
-    const float* bias; const float* pscale; const float* pshift;
-    const float* vec; const int* vec_idx; int vec_ld;
-    int relu; const float* res; float* out; int cout;
-    int bd, bh, bw;           // bricks per volume along d, h, w
-    int nchunks;
-};
 
 template <int TD, int TH, int TW, int S, int KS, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv3d_igemm_f32(const ConvArgs p) {
@@ -102,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_f32(const ConvArgs p) {
             for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.0f;
 
     // weight slice (tap, chunk): row n = tid>>2 of 64, float4 piece tid&3 of the 16 input channels
-    const float* w_thread = p.wpk + (size_t)(n0 + (tid >> 2)) * p.cinpad + piece * 4;
+    const float* w_thread = static_cast<const float*>(p.wpk) + (size_t)(n0 + (tid >> 2)) * p.cinpad + piece * 4;
     const size_t w_tap_stride = (size_t)p.coutpad * p.cinpad;
     const int w_lds_off = (tid >> 2) * LDV + piece * 4;
     f32x4 wreg = *reinterpret_cast<const f32x4*>(w_thread);      // (tap 0, chunk 0)
@@ -194,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_f32(const ConvArgs p) {
 }
 
 template <int TD, int TH, int TW, int S, int KS, int WM, int WN>
-int launch_conv(ConvArgs& a, int batch, hipStream_t st) {
+int launch_conv(ConvArgs& a, hipStream_t st) {
     constexpr int LDV = 20;
     constexpr int HVOX = ((TD - 1) * S + KS) * ((TH - 1) * S + KS) * ((TW - 1) * S + KS);
     constexpr size_t lds = (size_t)(HVOX * LDV + 2 * 64 * LDV) * sizeof(float);
@@ -207,7 +194,7 @@ int launch_conv(ConvArgs& a, int batch, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    dim3 grid((unsigned)(batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64));
+    dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64));
     hipLaunchKernelGGL((conv3d_igemm_f32<TD, TH, TW, S, KS, WM, WN>), grid, dim3(256), lds, st, a);
     return dm3d_launch_check("conv3d_igemm_f32");
 }
@@ -254,8 +241,17 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
     a.wpk = d->wpk; a.bias = d->bias; a.pscale = d->pro_scale; a.pshift = d->pro_shift;
     a.vec = d->vec; a.vec_idx = d->vec_idx; a.vec_ld = d->vec_ld;
     a.relu = d->relu; a.res = d->res; a.out = d->out; a.cout = d->cout;
+    a.batch = d->batch;
+    DM3D_REQUIRE(d->precision == DM3D_PREC_F32 || d->precision == DM3D_PREC_H3, "conv: unknown precision %d", d->precision);
+    DM3D_REQUIRE(d->w_exp >= -100 && d->w_exp <= 100, "conv: w_exp %d out of range", d->w_exp);
+    a.out_scale = d->precision == DM3D_PREC_H3 ? ldexpf(1.0f, -d->w_exp) : 1.0f;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (d->ksize == 1) return launch_conv<4, 8, 8, 1, 1, 4, 1>(a, d->batch, st);
-    if (d->stride == 2) return launch_conv<2, 4, 8, 2, 3, 2, 2>(a, d->batch, st);
-    return launch_conv<4, 8, 8, 1, 3, 4, 1>(a, d->batch, st);
+    const int which = d->ksize == 1 ? DM3D_CONV_K1 : (d->stride == 2 ? DM3D_CONV_K3S2 : DM3D_CONV_K3S1);
+    return d->precision == DM3D_PREC_H3 ? dm3d_conv_launch_h3(a, which, st) : dm3d_conv_launch_f32(a, which, st);
+}
+
+int dm3d_conv_launch_f32(ConvArgs& a, int which, hipStream_t st) {
+    if (which == DM3D_CONV_K1) return launch_conv<4, 8, 8, 1, 1, 4, 1>(a, st);
+    if (which == DM3D_CONV_K3S2) return launch_conv<2, 4, 8, 2, 3, 2, 2>(a, st);
+    return launch_conv<4, 8, 8, 1, 3, 4, 1>(a, st);
 }

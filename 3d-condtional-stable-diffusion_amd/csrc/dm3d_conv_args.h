@@ -1,0 +1,25 @@
+// dm3d_conv_args.h — launch arguments shared by the fp32 and the split-fp16 ("H3") implicit-GEMM Conv3d kernels.
+#pragma once
+#include "dm3d_common.h"
+
+struct ConvArgs {
+    const float* x1; const float* x2; int c1, c2;
+    int ind, inh, inw;        // physical input extent
+    int lgd, lgh, lgw;        // logical extent seen by the conv (2x when upsampling)
+    int od, oh, ow;
+    int ups, pad;             // pad = zero voxels in front of index 0 (TF SAME)
+    const void* wpk; int cinpad, coutpad;
+    const float* bias; const float* pscale; const float* pshift;
+    const float* vec; const int* vec_idx; int vec_ld;
+    int relu; const float* res; float* out; int cout;
+    int bd, bh, bw;           // bricks per volume along d, h, w
+    int nchunks;
+    int batch;
+    float out_scale;          // H3: 2^-w_exp, applied to the accumulator
+};
+
+// which tile configuration a (ksize, stride) pair uses
+enum { DM3D_CONV_K3S1 = 0, DM3D_CONV_K3S2 = 1, DM3D_CONV_K1 = 2 };
+
+int dm3d_conv_launch_f32(ConvArgs& a, int which, hipStream_t st);
+int dm3d_conv_launch_h3(ConvArgs& a, int which, hipStream_t st);

@@ -41,8 +41,24 @@ def pack_weights(kernel: torch.Tensor, in_scale: Optional[torch.Tensor] = None) 
     return out
 
 
+def pack_weights_h3(kernel: torch.Tensor, in_scale: Optional[torch.Tensor] = None):
+    """Keras kernel -> (float16 hi/lo image for the H3 conv kernels, w_exp).  max|w|*2^w_exp lands in [2^13, 2^14)."""
+    _f32c(kernel, "kernel")
+    if kernel.dim() not in (2, 5):
+        raise ValueError("kernel must be [in,out] or [kd,kh,kw,cin,cout]")
+    taps = 1 if kernel.dim() == 2 else kernel.shape[0] * kernel.shape[1] * kernel.shape[2]
+    cin, cout = kernel.shape[-2], kernel.shape[-1]
+    wmax = float(kernel.abs().max())
+    import math
+    w_exp = 0 if wmax == 0.0 or not math.isfinite(wmax) else int(13 - math.floor(math.log2(wmax)))
+    out = torch.empty(lib().dm3d_packed_weight_h3_bytes(taps, cin, cout) // 2, dtype=torch.float16, device=kernel.device)
+    check(lib().dm3d_pack_weights_h3(kernel.data_ptr(), taps, cin, cout, w_exp, _p(in_scale), out.data_ptr(), _st()),
+          "pack_weights_h3")
+    return out, w_exp
+
+
 def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False, pro_scale=None, pro_shift=None,
-           vec=None, vec_idx=None, relu=False, res=None) -> torch.Tensor:
+           vec=None, vec_idx=None, relu=False, res=None, precision=_lib.PREC_F32, w_exp=0) -> torch.Tensor:
     """Conv3D(padding="same") on NDHWC with the fused prologue / concat / upsample / epilogue of dm3d_conv3d_ndhwc."""
     _f32c(x1, "x1")
     if x1.dim() != 5:
@@ -66,6 +82,7 @@ def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False
     if res is not None and tuple(res.shape) != tuple(out.shape):
         raise ValueError("res must have the output's shape")
     d.relu, d.res, d.out, d.cout = int(bool(relu)), _p(res), out.data_ptr(), cout
+    d.precision, d.w_exp = precision, w_exp
     check(lib().dm3d_conv3d_ndhwc(C.byref(d), _st()), "conv3d")
     return out
 

@@ -44,15 +44,25 @@ def _ptr(t: Optional[torch.Tensor], offset_elems: int = 0) -> Optional[int]:
 class _Conv:
     """Packed Conv3D / Dense weights on the device."""
 
-    def __init__(self, wpk, bias, taps, cin, cout):
+    def __init__(self, wpk, bias, taps, cin, cout, precision=_lib.PREC_F32, w_exp=0):
         self.wpk, self.bias, self.taps, self.cin, self.cout = wpk, bias, taps, cin, cout
+        self.precision, self.w_exp = precision, w_exp
         self.cin_pad = -(-cin // _lib.CIN_PAD) * _lib.CIN_PAD
 
 
 class UNet:
     """Callable like the Keras model returned by ``build_model``: ``net([x, t, context]) -> eps`` (NDHWC float32)."""
 
-    def __init__(self, cfg: UNetConfig, device="cuda", weights: Optional[Dict[str, np.ndarray]] = None, seed: int = 0):
+    def __init__(self, cfg: UNetConfig, device="cuda", weights: Optional[Dict[str, np.ndarray]] = None, seed: int = 0,
+                 precision: Optional[str] = None):
+        """``precision``: arithmetic of the Conv3d kernels — "fp32" (exact float32 MFMA) or "h3" (float16 hi+lo split,
+        three 16-bit MFMA passes, float32 accumulate: float32-grade results, see include/dm3d.h).  Default: the
+        DM3D_PRECISION environment variable, else "h3"."""
+        import os
+        precision = precision or os.environ.get("DM3D_PRECISION", "h3")
+        if precision not in ("fp32", "h3"):
+            raise ValueError("precision must be 'fp32' or 'h3'")
+        self.precision = precision
         self.cfg = cfg
         self.blocks, self.spec = walk(cfg)
         self.device = torch.device(device)
@@ -94,11 +104,23 @@ class UNet:
     def _dev(self, arr: np.ndarray) -> torch.Tensor:
         return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(self.device)
 
-    def _pack(self, kernel: np.ndarray, bias: Optional[np.ndarray], in_scale: Optional[torch.Tensor] = None) -> _Conv:
+    def _pack(self, kernel: np.ndarray, bias: Optional[np.ndarray], in_scale: Optional[torch.Tensor] = None,
+              conv: bool = False) -> _Conv:
+        """``conv=True``: weights of a dm3d_conv3d_ndhwc launch (packed for self.precision); otherwise GEMM operand."""
         shape = kernel.shape
         taps = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
         cin, cout = int(shape[-2]), int(shape[-1])
         raw = self._dev(kernel)
+        if conv and self.precision == "h3":
+            # power-of-two pre-scale so that max|w| lands in [2^13, 2^14): hi stays finite, lo stays a normal float16
+            wmax = float(np.abs(kernel).max())
+            w_exp = 0 if wmax == 0.0 or not np.isfinite(wmax) else int(13 - np.floor(np.log2(wmax)))
+            w_exp = max(-100, min(100, w_exp))
+            nbytes = lib().dm3d_packed_weight_h3_bytes(taps, cin, cout)
+            wpk = torch.empty(nbytes // 2, dtype=torch.float16, device=self.device)
+            check(lib().dm3d_pack_weights_h3(raw.data_ptr(), taps, cin, cout, w_exp, _ptr(in_scale), wpk.data_ptr(),
+                                             _stream()), "pack_weights_h3")
+            return _Conv(wpk, self._dev(bias) if bias is not None else None, taps, cin, cout, _lib.PREC_H3, w_exp)
         n = lib().dm3d_packed_weight_elems(taps, cin, cout)
         wpk = torch.empty(n, dtype=torch.float32, device=self.device)
         check(lib().dm3d_pack_weights(raw.data_ptr(), taps, cin, cout, _ptr(in_scale), wpk.data_ptr(), _stream()),
@@ -118,7 +140,7 @@ class UNet:
         _lib.require_device()
         s, cfg = self.state, self.cfg
         P: Dict[str, object] = {}
-        P["conv_in"] = self._pack(s["conv_in.kernel"], s["conv_in.bias"])
+        P["conv_in"] = self._pack(s["conv_in.kernel"], s["conv_in.bias"], conv=True)
         P["time_mlp.0"] = self._pack(s["time_mlp.0.kernel"], s["time_mlp.0.bias"])
         P["time_mlp.1"] = self._pack(s["time_mlp.1.kernel"], s["time_mlp.1.bias"])
         temb_k, temb_b, self.temb_off, off = [], [], {}, 0
@@ -126,9 +148,9 @@ class UNet:
             n = blk.name
             if blk.kind == "res":
                 if f"{n}.skip.kernel" in s:
-                    P[f"{n}.skip"] = self._pack(s[f"{n}.skip.kernel"], s[f"{n}.skip.bias"])
-                P[f"{n}.conv1"] = self._pack(s[f"{n}.conv1.kernel"], s[f"{n}.conv1.bias"])
-                P[f"{n}.conv2"] = self._pack(s[f"{n}.conv2.kernel"], s[f"{n}.conv2.bias"])
+                    P[f"{n}.skip"] = self._pack(s[f"{n}.skip.kernel"], s[f"{n}.skip.bias"], conv=True)
+                P[f"{n}.conv1"] = self._pack(s[f"{n}.conv1.kernel"], s[f"{n}.conv1.bias"], conv=True)
+                P[f"{n}.conv2"] = self._pack(s[f"{n}.conv2.kernel"], s[f"{n}.conv2.bias"], conv=True)
                 P[f"{n}.norm1"] = self._fold_bn(f"{n}.norm1")
                 P[f"{n}.norm2"] = self._fold_bn(f"{n}.norm2")
                 temb_k.append(s[f"{n}.temb.kernel"])
@@ -136,13 +158,13 @@ class UNet:
                 self.temb_off[n] = off
                 off += blk.cout
             elif blk.kind in ("down", "up"):
-                P[n] = self._pack(s[f"{n}.kernel"], s[f"{n}.bias"])
+                P[n] = self._pack(s[f"{n}.kernel"], s[f"{n}.bias"], conv=True)
             elif blk.kind == "attn":
                 self._prepare_attn(P, blk)
         self.temb_ld = off
         P["temb_all"] = self._pack(np.concatenate(temb_k, axis=1), np.concatenate(temb_b))
         P["out.norm"] = self._fold_bn("out.norm")
-        P["out.conv"] = self._pack(s["out.conv.kernel"], s["out.conv.bias"])
+        P["out.conv"] = self._pack(s["out.conv.kernel"], s["out.conv.bias"], conv=True)
         self.P = P
         self._prepared = True
         if cfg.conditional:
@@ -316,7 +338,8 @@ class Plan:
         d.in_d = d.in_h = d.in_w = edge_in
         d.upsample, d.stride = upsample, stride
         d.ksize = {1: 1, 27: 3}[w.taps]
-        d.wpk, d.bias = _ptr(w.wpk), _ptr(w.bias)
+        d.wpk, d.bias = w.wpk.data_ptr(), _ptr(w.bias)
+        d.precision, d.w_exp = w.precision, w.w_exp
         if pro is not None:
             d.pro_scale, d.pro_shift = _ptr(pro[0]), _ptr(pro[1])
         if vec_off is not None:

@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 T_FULL = 1000
 _T0 = time.time()
 
@@ -58,6 +59,9 @@ def main():
     ap.add_argument("--size", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--precision", choices=["h3", "fp32"], default="h3",
+                    help="Conv3d arithmetic: h3 = float16 hi+lo split, 3 MFMA passes, fp32 accumulate (default); "
+                         "fp32 = exact float32 MFMA")
     args = ap.parse_args()
 
     import numpy as np
@@ -85,7 +89,7 @@ def main():
     W = dm3d_amd.synthetic_weights(cfg, seed=0) if rank == 0 else None
     W = parallel.broadcast_state(W, spec, src=0, device=dev)              # RCCL broadcast over xGMI (no-op at N=1)
     margs = SimpleNamespace(timesteps=T_FULL, num_gpus=world, kernel_resize=False, bs=B * world)
-    model = cdm.DiffusionModel(S, 1024, Cc, None, margs, device=dev, weights=W)
+    model = cdm.DiffusionModel(S, 1024, Cc, None, margs, device=dev, weights=W, precision=args.precision)
     smp = model.sampler((B, S, S, S, Cc), context_value=1, seed=parallel.rank_seed(1234, rank),
                         use_graph=not args.no_graph)
     smp.reset()
@@ -133,9 +137,19 @@ def main():
                               "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if fl else None}
         n, ms, fl, by = acc["conv_k3s1"]
         achieved = fl / (ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "conv3d_igemm_f32<4,8,8,1,3,4,1> (k3 stride-1 Conv3d, v_mfma_f32_32x32x2_f32)",
-                    "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+        if args.precision == "h3":
+            kname = ("conv3d_igemm_h3<4,8,8,1,3,4,1,2> (k3 stride-1 Conv3d; float16 hi+lo split, 3 x "
+                     "v_mfma_f32_32x32x16_f16 per algorithmic product, fp32 accumulate)")
+            peak, passes = PEAK_F16_MFMA_TFLOPS, 3
+        else:
+            kname, peak, passes = "conv3d_igemm_f32<4,8,8,1,3,4,1> (k3 stride-1 Conv3d, v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS, 1
+        roofline = {"bound": "mfma", "kernel": kname,
+                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": None,
+                    "mfma_passes_per_product": passes,
+                    "executed_mfma_tflops": round(achieved * passes, 2),
+                    "executed_mfma_frac_of_peak": round(achieved * passes / peak, 4),
+                    "achieved_vs_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                     "avg_launch_ms": round(ms / n, 4), "launches_per_step": n // reps,
                     "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
                     "algorithmic_mb_per_launch": round(by / n / 1e6, 2)}
@@ -172,7 +186,7 @@ def main():
         line = {
             "metric": "latent volumes/sec at 32^3x8ch T=1000 DDPM", "value": value, "unit": "volumes/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": s_per_step * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f32 (f16 hi+lo x3 MFMA, f32 accumulate)", "data": "synthetic",
             "config": {"workload": f"conditional_dm3d U-Net (widths 64/128/256) DDPM sampling, {S}^3x{Cc}ch latents, "
                                    f"B={B} volumes per GPU, T={T_FULL}; step = one denoising step of the batch "
                                    f"(U-Net eps + posterior update + Philox noise, HIP-graph replay); "
@@ -180,7 +194,8 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "timesteps": T_FULL,
                        "weights": "seeded synthetic (seed 0), rank-0 broadcast", "parallelism": f"batch-shard x{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "per_kernel_kind": per_kind,
-            "conv_mfma_util_pct": None if roofline is None else round(100 * roofline["frac"], 2),
+            "conv_mfma_util_pct": None if roofline is None else round(100 * roofline["executed_mfma_frac_of_peak"], 2),
+            "precision": args.precision,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -32,6 +32,16 @@ extern "C" {
 #define DM3D_ACT_RELU 1
 #define DM3D_ACT_SILU 2
 
+/* arithmetic of the contraction kernels.
+ *   F32: v_mfma_f32_32x32x2_f32, exact float32 products and accumulation (157 TFLOP/s peak).
+ *   H3 : every float32 operand x is split on the fly into two float16 terms x = hi + lo (|x - hi - lo| <= 2^-22 |x|),
+ *        and a.b is evaluated as ah.bh + ah.bl + al.bh with three v_mfma_f32_32x32x16_f16 passes accumulating in
+ *        float32 (dropped term al.bl <= 2^-22 |a.b|): float32-grade results at 1/3 of the 16-bit MFMA rate.  Weights
+ *        are pre-scaled by 2^w_exp (undone exactly in the epilogue) so their lo terms stay normal float16 numbers;
+ *        activations are clamped to +-65504 before the split. */
+#define DM3D_PREC_F32 0
+#define DM3D_PREC_H3  1
+
 /* padded extents of packed weights */
 #define DM3D_COUT_PAD 64
 #define DM3D_CIN_PAD  16
@@ -50,6 +60,13 @@ int         dm3d_device_ok(void);
 int64_t dm3d_packed_weight_elems(int32_t taps, int32_t cin, int32_t cout);
 int     dm3d_pack_weights(const float* keras_kernel, int32_t taps, int32_t cin, int32_t cout,
                           const float* in_scale, float* packed, void* stream);
+
+/* H3 image: [CoutPad/64][CinPad/16][taps][64][40 halfs] = per output channel 16 hi, 16 lo, 8 pad float16 (an 80-byte LDS
+ * record), weights multiplied by 2^w_exp before the split.  Same element count as dm3d_packed_weight_elems * 5/4 halfs;
+ * dm3d_packed_weight_h3_bytes gives the buffer size. */
+int64_t dm3d_packed_weight_h3_bytes(int32_t taps, int32_t cin, int32_t cout);
+int     dm3d_pack_weights_h3(const float* keras_kernel, int32_t taps, int32_t cin, int32_t cout, int32_t w_exp,
+                             const float* in_scale, void* packed, void* stream);
 
 /* ---- Conv3D(padding="same") as implicit GEMM on MFMA ---------------------------------------------------------
  * Replaces layers.Conv3D for k=3/s=1 (:257-259, :348-353, :412-414), k=3/s=2 (DownSample :274-285, TF SAME pad 0
@@ -80,6 +97,8 @@ typedef struct dm3d_conv_desc {
     const float* res;           /* [batch, out_d, out_h, out_w, cout] or NULL */
     float* out;                 /* [batch, out_d, out_h, out_w, cout], out = ceil(in*(upsample?2:1)/stride) */
     int32_t cout;
+    int32_t precision;          /* DM3D_PREC_F32: wpk from dm3d_pack_weights; DM3D_PREC_H3: wpk from dm3d_pack_weights_h3 */
+    int32_t w_exp;              /* H3 only: the power-of-two exponent the weights were packed with */
 } dm3d_conv_desc;
 
 int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream);

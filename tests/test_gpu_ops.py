@@ -69,9 +69,10 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("prec", ["fp32", "h3"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv3d(dev, case):
-    from dm3d_amd import ops
+def test_conv3d(dev, case, prec):
+    from dm3d_amd import ops, _lib
     name, B, (D, H, W), c1, c2, cout, ks, stride, ups, extras = case
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
     rnd = lambda *s: torch.randn(*s, generator=g)
@@ -89,14 +90,36 @@ def test_conv3d(dev, case):
     ref = _conv_ref(x1, kern, bias, x2=x2, stride=stride, upsample=ups, pro=pro, vec=vec, vec_idx=vec_idx,
                     relu="relu" in extras, res=res)
     c = lambda t: None if t is None else t.to(dev).contiguous()
-    wpk = ops.pack_weights(c(kern))
+    if prec == "h3":
+        wpk, w_exp = ops.pack_weights_h3(c(kern))
+        pk = dict(precision=_lib.PREC_H3, w_exp=w_exp)
+    else:
+        wpk, pk = ops.pack_weights(c(kern)), {}
     out = ops.conv3d(c(x1), wpk, cout, ks, x2=c(x2), bias=c(bias), stride=stride, upsample=ups,
                      pro_scale=c(pro[0]) if pro else None, pro_shift=c(pro[1]) if pro else None,
-                     vec=c(vec), vec_idx=c(vec_idx), relu="relu" in extras, res=c(res))
+                     vec=c(vec), vec_idx=c(vec_idx), relu="relu" in extras, res=c(res), **pk)
     torch.cuda.synchronize()
     assert tuple(out.shape) == tuple(ref.shape)
     err = _rel(out, ref)
+    print(f"{name}[{prec}] rel err {err:.2e}")
     assert err < 2e-5, f"{name}: rel err {err:.3e}"
+
+
+def test_conv3d_h3_extreme_magnitudes(dev):
+    """H3 split: tiny and huge activations / weights keep float32-grade relative accuracy (power-of-two weight scaling,
+    float16 subnormal lo terms, clamp at 65504)."""
+    from dm3d_amd import ops, _lib
+    g = torch.Generator().manual_seed(99)
+    for xs, ws in ((1e-3, 1e-4), (300.0, 30.0), (1.0, 1e3), (1e-2, 1.0)):
+        x = torch.randn(1, 8, 8, 8, 32, generator=g) * xs
+        k = torch.randn(3, 3, 3, 32, 64, generator=g) * ws
+        ref = _conv_ref(x, k, None)
+        wpk, w_exp = ops.pack_weights_h3(k.to(dev))
+        out = ops.conv3d(x.to(dev), wpk, 64, 3, precision=_lib.PREC_H3, w_exp=w_exp)
+        torch.cuda.synchronize()
+        err = _rel(out, ref)
+        print(f"h3 magnitudes x~{xs} w~{ws}: rel err {err:.2e}")
+        assert err < 2e-5
 
 
 def test_conv3d_argument_errors(dev):

@@ -33,22 +33,23 @@ def _args(T, bs=1):
     return SimpleNamespace(timesteps=T, num_gpus=1, kernel_resize=False, bs=bs)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "h3"])
 @pytest.mark.parametrize("cond", [True, False], ids=["conditional", "unconditional"])
-def test_unet_eps_golden_s8(dev, cond):
+def test_unet_eps_golden_s8(dev, cond, prec):
     import dm3d_amd
     from dm3d_amd.networks import conditional_dm3d, dm3d
     g = np.load(os.path.join(GOLD, "unet_cond_s8c4.npz" if cond else "unet_uncond_s8c4.npz"))
     cfg = dm3d_amd.UNetConfig(img_size=8, img_channels=4, conditional=cond)
     W = dm3d_amd.synthetic_weights(cfg, seed=0)
     mod = conditional_dm3d if cond else dm3d
-    net = mod.build_model(8, 4, [64, 128, 256], [False, False, True, True])
+    net = mod.build_model(8, 4, [64, 128, 256], [False, False, True, True], precision=prec)
     net.load_state_dict(W)
     x, t = torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["t"])
     inputs = [x, t, torch.from_numpy(g["ctx"])] if cond else [x, t]
     eps = net(inputs)
     torch.cuda.synchronize()
     err32, err64 = _rel(eps, g["eps"]), _rel(eps, g["eps64"])
-    print(f"eps rel err vs oracle fp32 {err32:.3e}, vs oracle fp64 {err64:.3e}")
+    print(f"[{prec}] eps rel err vs oracle fp32 {err32:.3e}, vs oracle fp64 {err64:.3e}")
     assert err32 < TOL and err64 < TOL
     # a second call with a different batch composition reuses/rebuilds plans correctly
     eps1 = net([x[1:2], t[1:2]] + ([torch.from_numpy(g["ctx"])[1:2]] if cond else []))
@@ -137,14 +138,15 @@ def test_unconditional_config1_generate(dev):
     assert torch.isfinite(full).all()
 
 
-def test_unet_eps_full_size_32cube(dev):
+@pytest.mark.parametrize("prec", ["fp32", "h3"])
+def test_unet_eps_full_size_32cube(dev, prec):
     """BASELINE configs 2-4 shape (32^3 x 8ch, real widths) at B=1 against the oracle run on this box's CPU."""
     import dm3d_amd
     from dm3d_amd.unet import UNet
     from oracle import ref_torch as rt
     cfg = dm3d_amd.UNetConfig(img_size=32, img_channels=8)
     W = dm3d_amd.synthetic_weights(cfg, seed=0)
-    net = UNet(cfg, weights=W)
+    net = UNet(cfg, weights=W, precision=prec)
     g = torch.Generator().manual_seed(21)
     x = torch.randn(1, 32, 32, 32, 8, generator=g)
     t, ctx = torch.tensor([637]), torch.tensor([[[1]]])
@@ -153,7 +155,7 @@ def test_unet_eps_full_size_32cube(dev):
     eps = net([x.to(dev), t, ctx])
     torch.cuda.synchronize()
     err = _rel(eps, ref)
-    print(f"32^3x8 eps rel err {err:.3e}")
+    print(f"[{prec}] 32^3x8 eps rel err {err:.3e}")
     assert err < TOL
     # linearity of the DDPM posterior in (x_t, eps) at full size: sample(a x + b y) = a sample(x) + b sample(y)
     from dm3d_amd.networks import conditional_dm3d as cdm
