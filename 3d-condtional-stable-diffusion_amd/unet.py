@@ -352,13 +352,15 @@ class Plan:
         eo = -(-edge_in * up // stride)
         kind = "conv_k1" if w.taps == 1 else ("conv_k3s2" if stride == 2 else "conv_k3s1")
         self.ops.append((lib().dm3d_conv3d_ndhwc, (C.byref(d),), kind,
-                         {"flops": 2.0 * w.taps * w.cin * w.cout * self.B * eo ** 3,
+                         {"desc": f"{kind} {edge_in}^3{'x2up' if upsample else ''} cin={w.cin} cout={w.cout}",
+                          "flops": 2.0 * w.taps * w.cin * w.cout * self.B * eo ** 3,
                           "bytes": 4.0 * self.B * (edge_in ** 3 * w.cin + eo ** 3 * w.cout)}))
 
     def _gemm(self, **kw):
         d = _gemm_desc(**kw)
         self._keep.append(d)
-        self.ops.append((lib().dm3d_gemm_tn, (C.byref(d),), "gemm", {"flops": 2.0 * d.m * d.n * d.k * d.batch}))
+        self.ops.append((lib().dm3d_gemm_tn, (C.byref(d),), "gemm",
+                         {"desc": f"gemm m={d.m} n={d.n} k={d.k} batch={d.batch}", "flops": 2.0 * d.m * d.n * d.k * d.batch}))
 
     # -- graph -----------------------------------------------------------------------------------------------------
     def _build(self):
