@@ -31,8 +31,9 @@ static inline int64_t dm3d_round_up(int64_t v, int64_t m) { return (v + m - 1) /
 
 // ---- device helpers -----------------------------------------------------------------------------------------------
 __device__ __forceinline__ float dm3d_silu(float y) {
-    // y * sigmoid(y); v_exp/v_rcp are ~1 ulp, far inside the 1e-3 parity budget
-    return y * __frcp_rn(1.0f + __expf(-y));
+    // y * sigmoid(y) as mul, v_exp_f32, add, v_rcp_f32, mul (both ~1 ulp, far inside the 1e-3 parity budget).
+    // __frcp_rn / 1.0f/x would expand to the ~10-instruction correctly-rounded division sequence.
+    return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.4426950408889634f));
 }
 __device__ __forceinline__ float dm3d_act(float v, int act) {
     if (act == DM3D_ACT_RELU) return fmaxf(v, 0.0f);

@@ -106,17 +106,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_f32(const ConvArgs p) {
             sc = *reinterpret_cast<const f32x4*>(p.pscale + c0 + piece * 4);
             sh = *reinterpret_cast<const f32x4*>(p.pshift + c0 + piece * 4);
         }
+        // unconditional loads on clamped addresses, masked afterwards: a load inside a divergent branch costs one
+        // serialized memory round trip each (hipcc waits vmcnt(0) per branch)
+        const int coff = chan_ok ? cb + piece * 4 : 0;
         f32x4 hval[NSLOT];
 #pragma unroll
-        for (int j = 0; j < NSLOT; ++j) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gvox[j] >= 0 && chan_ok) {
-                v = *reinterpret_cast<const f32x4*>(src + (size_t)gvox[j] * ldc + cb + piece * 4);
-                if (pro) {
+        for (int j = 0; j < NSLOT; ++j)
+            hval[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(gvox[j] >= 0 ? gvox[j] : 0) * ldc + coff);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = dm3d_silu(fmaf(v[e], sc[e], sh[e]));
-                }
+        for (int j = 0; j < NSLOT; ++j) {
+            f32x4 v = hval[j];
+            if (pro) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = dm3d_silu(fmaf(v[e], sc[e], sh[e]));
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (gvox[j] >= 0 && chan_ok) ? v[e] : 0.0f;
             hval[j] = v;
         }
         __syncthreads();                        // every wave is done with the previous chunk's halo and weight slots
@@ -131,10 +136,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_f32(const ConvArgs p) {
         for (int tap = 0; tap < TAPS; ++tap) {
             // prefetch the next weight slice (next tap, or tap 0 of the next chunk)
             const bool last_tap = tap + 1 == TAPS;
-            if (!last_tap)
-                wreg = *reinterpret_cast<const f32x4*>(w_thread + (size_t)(tap + 1) * w_tap_stride + c0);
-            else if (ch + 1 < p.nchunks)
-                wreg = *reinterpret_cast<const f32x4*>(w_thread + c0 + CK);
+            {   // unconditional, clamped: a load behind a branch is waited for on the spot
+                int nt = tap + 1, nc = c0;
+                if (last_tap) { nt = 0; nc = (ch + 1 < p.nchunks) ? c0 + CK : c0; }
+                wreg = *reinterpret_cast<const f32x4*>(w_thread + (size_t)nt * w_tap_stride + nc);
+            }
 
             const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
             const int tap_off = ((kd * HH + kh) * HW + kw) * LDV;
@@ -155,26 +161,37 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_f32(const ConvArgs p) {
     }
 
     // epilogue: + bias + vec[row(b)] -> relu -> + res -> store.  Lanes 0..31 cover 32 consecutive output channels.
+    // Loads are unconditional on clamped indices; only the stores are predicated.
     const int vrow = p.vec ? (p.vec_idx ? p.vec_idx[b] : b) : 0;
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         const int n = n0 + wn * (NT / WN) + nr * 32 + l32;
-        if (n >= p.cout) continue;
-        float add = p.bias ? p.bias[n] : 0.0f;
-        if (p.vec) add += p.vec[(size_t)vrow * p.vec_ld + n];
+        const bool n_ok = n < p.cout;
+        const int nc = n_ok ? n : p.cout - 1;
+        float add = p.bias ? p.bias[nc] : 0.0f;
+        if (p.vec) add += p.vec[(size_t)vrow * p.vec_ld + nc];
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
+            size_t o[16];
+            bool ok[16];
+            float rv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * (TM / WM) + mr * 32 + dm3d_acc_row(r, half);
                 const int oz = oz0 + row / (TH * TW), oy = oy0 + (row / TW) % TH, ox = ox0 + row % TW;
-                if (oz < p.od && oy < p.oh && ox < p.ow) {
-                    const size_t o = ((((size_t)b * p.od + oz) * p.oh + oy) * p.ow + ox) * p.cout + n;
-                    float v = acc[mr][nr][r] + add;
-                    if (p.relu) v = fmaxf(v, 0.0f);
-                    if (p.res) v += p.res[o];
-                    p.out[o] = v;
-                }
+                ok[r] = n_ok && oz < p.od && oy < p.oh && ox < p.ow;
+                o[r] = ok[r] ? ((((size_t)b * p.od + oz) * p.oh + oy) * p.ow + ox) * p.cout + n : 0;
+            }
+            if (p.res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = p.res[o[r]];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[mr][nr][r] + add;
+                if (p.relu) v = fmaxf(v, 0.0f);
+                if (p.res) v += rv[r];
+                if (ok[r]) p.out[o[r]] = v;
             }
         }
     }

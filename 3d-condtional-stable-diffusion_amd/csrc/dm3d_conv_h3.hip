@@ -11,26 +11,63 @@
 //     numbers; the epilogue multiplies the accumulator by 2^-w_exp (exact).
 //
 // Tile structure (see dm3d_conv.hip for the rationale): workgroup = 256 threads, TD x TH x TW output voxels x 64 output
-// channels; per 16-channel chunk the input halo lives in LDS as 80-byte records [16 hi | 16 lo | pad]; the k^3 taps walk it
-// by address only; weight slices arrive in groups of 3 taps (one (kd,kh) row), double-buffered, one barrier per group.
-// One k3 tap = 12 MFMAs (384 cycles) per wave against 8 ds_read_b128.
+// channels; per 16-channel chunk the input halo lives in LDS as 64-byte records of four 16-byte slots
+// [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15]; the k^3 taps walk it by address only; weight slices arrive in groups of 3 taps
+// (one (kd,kh) row), double-buffered, one barrier per group.  One k3 tap = 12 MFMAs (384 cycles) per wave against 8
+// ds_read_b128, so LDS bandwidth is the scarce resource and every read is laid out conflict-free:
+//   * slot s of record v is stored at physical slot s ^ ((v >> 2) & 3): a 16-lane ds_read_b128 group is conflict-free
+//     iff its 16 record indices are distinct mod 16;
+//   * the halo row stride is padded from 10 to 12 voxels, which makes every residue mod 16 occur exactly twice in a
+//     4 x 8 voxel tile, and the MFMA row -> voxel map (row_to_yx) hands one copy to each of the two hardware lane
+//     groups {0-3,12-15,20-27} and {4-11,16-19,28-31}.  Weight rows (record = output channel) are conflict-free as is.
 #include "dm3d_conv_args.h"
 
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
-constexpr int REC = 40;            // halfs per LDS record: 16 hi, 16 lo, 8 pad (80 B keeps ds_read_b128 banks spread)
+constexpr int REC = 32;            // halfs per LDS record: 4 slots of 8 halfs (hi0 hi1 lo0 lo1), XOR-swizzled by the record index
 
-__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, h8& hi, h8& lo) {
-    // 8 consecutive channels -> float16 hi and lo terms, x = hi + lo up to 2^-22 |x|
+__device__ __forceinline__ int swz(int v) { return (v >> 2) & 3; }
+
+// MFMA tile row i (0..31) -> (dy, dx) inside a 4 x 8 voxel tile.  PAIR = 0: natural order.  PAIR = 2 / 1: the lanes of
+// the first ds_read_b128 lane group {0-3,12-15,20-27} take rows dy in {0,PAIR}, the second group takes the other two.
+template <int PAIR>
+__device__ __forceinline__ void row_to_yx(int i, int& dy, int& dx) {
+    if (PAIR == 0) { dy = i >> 3; dx = i & 7; return; }
+    const bool g1 = (i >= 4 && i < 12) || (i >= 16 && i < 20) || i >= 28;
+    const int idx = g1 ? (i < 12 ? i - 4 : (i < 20 ? i - 8 : i - 16)) : (i < 4 ? i : (i < 16 ? i - 8 : i - 12));
+    const int sel = idx >> 3;
+    dx = idx & 7;
+    if (PAIR == 2) dy = g1 ? 1 + 2 * sel : 2 * sel;
+    else dy = g1 ? 2 + sel : sel;
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 8 consecutive channels -> float16 hi and lo terms, x = hi + lo up to 2^-22 |x|; lim0/lim1 are 65504 (clamp to the
+// float16 range) or 0 (padding / out-of-range position -> exact zero), so one v_med3_f32 clamps and masks.  Per pair:
+// v_cvt_pk_f16_f32 (hi, RNE), 2 x v_fma_mix_f32 (x - hi with hi read as f16 straight from the packed register),
+// v_cvt_pk_f16_f32 (lo) — 3 VALU per element; hipcc's own lowering of the same arithmetic takes 7.  VALU issue slots
+// are what this kernel runs out of first (4.7 VALU per MFMA before this diet, measured with SQ_INSTS_VALU).
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, float lim0, float lim1, h8& hi, h8& lo) {
+    u32x4 ph, pl;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float x = fminf(fmaxf(e < 4 ? v0[e] : v1[e - 4], -65504.0f), 65504.0f);
-        const _Float16 a = (_Float16)x;
-        hi[e] = a;
-        lo[e] = (_Float16)(x - (float)a);
+    for (int e = 0; e < 8; e += 2) {
+        const float lim = e < 4 ? lim0 : lim1;
+        const float x0 = __builtin_amdgcn_fmed3f(e < 4 ? v0[e] : v1[e - 4], -lim, lim);
+        const float x1 = __builtin_amdgcn_fmed3f(e < 4 ? v0[e + 1] : v1[e - 3], -lim, lim);
+        unsigned int a, r;
+        float r0, r1;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(a) : "v"(x0), "v"(x1));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(a), "v"(x0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(a), "v"(x1));
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(r0), "v"(r1));
+        ph[e >> 1] = a;
+        pl[e >> 1] = r;
     }
+    hi = __builtin_bit_cast(h8, ph);
+    lo = __builtin_bit_cast(h8, pl);
 }
 
 template <int TD, int TH, int TW, int S, int KS, int WM, int WN, int MINW>
@@ -38,7 +75,14 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
     constexpr int CK = 16, NT = 64;
     constexpr int TM = TD * TH * TW;
     constexpr int HD = (TD - 1) * S + KS, HH = (TH - 1) * S + KS, HW = (TW - 1) * S + KS;
-    constexpr int HVOX = HD * HH * HW;
+    constexpr int HVOX = HD * HH * HW;                      // real halo voxels (staged)
+    constexpr bool CF = (S == 1 && TH % 4 == 0 && TW == 8); // conflict-free layout available
+    constexpr int HWP = (CF && KS == 3) ? 12 : HW;          // padded row stride of the LDS image
+    constexpr int PAIR = CF ? (KS == 3 ? 2 : 1) : 0;
+    constexpr int HREC = HD * HH * HWP;                     // records in the LDS image
+    constexpr int MRSTEP = 4 * S * HWP;                     // records between consecutive 32-row tiles of a wave (4 y rows)
+    static_assert(TM / WM <= 32 || MRSTEP % 16 == 0, "row tiles of a wave must share the swizzle term");
+    static_assert(TM / WM <= TH * TW, "a wave's rows stay inside one z slice");
     constexpr int TAPS = KS * KS * KS;
     constexpr int G = KS;                       // taps per weight group (one kw row), TAPS / G groups per chunk
     constexpr int NG = TAPS / G;
@@ -46,12 +90,15 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
     constexpr int NSLOT = (HVOX * 2 + 255) / 256;          // (voxel, 8-channel piece) slots per thread
     constexpr int WGRP = G * NT * REC;                      // halfs per weight group
     constexpr int WPIECES = WGRP * 2 / 16;                  // 16-byte pieces per group
-    constexpr int WSLOT = (WPIECES + 255) / 256;
+    constexpr int WSLOT = WPIECES / 256;
+    static_assert(WPIECES % 256 == 0, "a weight group is a whole number of 16-byte pieces per thread (no guards: a guarded "
+                                      "load costs a serialized vmcnt(0))");
     static_assert(WM * WN == 4, "kernel assumes 4 waves");
+    static_assert(TW == 8 && (TM / WM) % 32 == 0 && (TH * TW) % 32 == 0, "a 32-row MFMA tile is 4 x 8 voxels of one z");
 
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
-    _Float16* lds_in = smem_h;                  // [HVOX][REC]
-    _Float16* lds_w = smem_h + HVOX * REC;      // [2][G][NT][REC]
+    _Float16* lds_in = smem_h;                  // [HREC][REC]
+    _Float16* lds_w = smem_h + HREC * REC;      // [2][G][NT][REC]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -85,17 +132,34 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
         gvox[j] = g;
     }
 
-    // per-lane record of the A operand for each 32-row tile at tap (0,0,0); lane half h reads hi at +8h, lo at +16+8h
-    int a_off[MR];
+    // LDS write position (halfs) of each staging slot's hi piece; the lo piece sits at the same place ^ 16 halfs (slot ^ 2)
+    int st_off[NSLOT];
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+        const int hv = (tid >> 1) + j * 128;
+        const int v = (hv / HW) * HWP + hv % HW;                    // (hz*HH + hy)*HWP + hx
+        st_off[j] = hv < HVOX ? v * REC + ((piece ^ swz(v)) << 3) : -1;
+    }
+
+    // per-lane record index of the A operand for each 32-row tile at tap (0,0,0)
+    int a_rec[MR];
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
-        const int r = wm * (TM / WM) + mr * 32 + l32;
-        const int dz = r / (TH * TW), dy = (r / TW) % TH, dx = r % TW;
-        a_off[mr] = ((dz * S * HH + dy * S) * HW + dx * S) * REC + half * 8;
+        const int r0 = wm * (TM / WM) + mr * 32;
+        int dy, dx;
+        row_to_yx<PAIR>(l32, dy, dx);
+        const int dz = r0 / (TH * TW);
+        dy += (r0 / TW) % TH;
+        a_rec[mr] = (dz * S * HH + dy * S) * HWP + dx * S;
     }
-    int b_off[NR];
+    // weight rows: record = output channel n; slot half (hi) / 2+half (lo), swizzled by n (tap offsets are multiples of 64)
+    int b_hi[NR], b_lo[NR];
 #pragma unroll
-    for (int nr = 0; nr < NR; ++nr) b_off[nr] = (wn * (NT / WN) + nr * 32 + l32) * REC + half * 8;
+    for (int nr = 0; nr < NR; ++nr) {
+        const int n = wn * (NT / WN) + nr * 32 + l32;
+        b_hi[nr] = n * REC + ((half ^ swz(n)) << 3);
+        b_lo[nr] = n * REC + (((2 + half) ^ swz(n)) << 3);
+    }
 
     f32x16 acc[MR][NR];
 #pragma unroll
@@ -112,90 +176,108 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
     auto fetch_w = [&](int group_index) {
         const f32x4* src = w_img + (size_t)group_index * WPIECES;
 #pragma unroll
-        for (int i = 0; i < WSLOT; ++i) {
-            const int q = tid + i * 256;
-            if (q < WPIECES) wreg[i] = src[q];
-        }
+        for (int i = 0; i < WSLOT; ++i) wreg[i] = src[tid + i * 256];
     };
     auto store_w = [&](int buf) {
         f32x4* dst = reinterpret_cast<f32x4*>(lds_w + buf * WGRP);
 #pragma unroll
-        for (int i = 0; i < WSLOT; ++i) {
-            const int q = tid + i * 256;
-            if (q < WPIECES) dst[q] = wreg[i];
-        }
+        for (int i = 0; i < WSLOT; ++i) dst[tid + i * 256] = wreg[i];
     };
     fetch_w(0);
 
+    // Halo prefetch state: the raw float32 values of the NEXT chunk travel in registers while the current chunk's MFMAs run.
+    // Every load is unconditional on a clamped address and masked afterwards: a load inside a divergent branch (or a
+    // prefetch whose result is merged across branches) makes hipcc wait vmcnt(0) on the spot, which serialises the
+    // round trips; the sched_barrier after each batch keeps the scheduler from sinking the loads to their first use.
     const bool pro = p.pscale != nullptr;
-    for (int ch = 0; ch < p.nchunks; ++ch) {
+    f32x4 raw0[NSLOT], raw1[NSLOT];
+    f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
+    bool ok0 = false, ok1 = false;
+    auto load_halo = [&](int ch) {
         const int c0 = ch * CK;
         const float* src;
         int ldc, cb;
         if (c0 < p.c1) { src = p.x1; ldc = p.c1; cb = c0; } else { src = p.x2; ldc = p.c2; cb = c0 - p.c1; }
         const int cpos = cb + piece * 8;
-        const bool ok0 = cpos < ldc, ok1 = cpos + 4 < ldc;
-        f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
-        if (pro) {
-            if (ok0) { sc0 = *reinterpret_cast<const f32x4*>(p.pscale + c0 + piece * 8);
-                       sh0 = *reinterpret_cast<const f32x4*>(p.pshift + c0 + piece * 8); }
-            if (ok1) { sc1 = *reinterpret_cast<const f32x4*>(p.pscale + c0 + piece * 8 + 4);
-                       sh1 = *reinterpret_cast<const f32x4*>(p.pshift + c0 + piece * 8 + 4); }
-        }
-        h8 shi[NSLOT], slo[NSLOT];              // converted before the barrier: the VALU work overlaps the other waves' MFMAs
+        ok0 = cpos < ldc;
+        ok1 = cpos + 4 < ldc;
+        const int off0 = ok0 ? cpos : 0, off1 = ok1 ? cpos + 4 : 0;
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) {
-            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-            if (gvox[j] >= 0) {
-                const float* q = src + (size_t)gvox[j] * ldc + cpos;
-                if (ok0) v0 = *reinterpret_cast<const f32x4*>(q);
-                if (ok1) v1 = *reinterpret_cast<const f32x4*>(q + 4);
-                if (pro) {
+            const float* q = src + (size_t)(gvox[j] >= 0 ? gvox[j] : 0) * ldc;
+            raw0[j] = *reinterpret_cast<const f32x4*>(q + off0);
+            raw1[j] = *reinterpret_cast<const f32x4*>(q + off1);
+        }
+        if (pro) {      // uniform branch; channel offsets clamped the same way (c1+c2 >= 8 is guaranteed by the host)
+            const int s0 = ok0 ? c0 + piece * 8 : 0, s1 = ok1 ? c0 + piece * 8 + 4 : 0;
+            sc0 = *reinterpret_cast<const f32x4*>(p.pscale + s0);
+            sh0 = *reinterpret_cast<const f32x4*>(p.pshift + s0);
+            sc1 = *reinterpret_cast<const f32x4*>(p.pscale + s1);
+            sh1 = *reinterpret_cast<const f32x4*>(p.pshift + s1);
+        }
+    };
+    load_halo(0);
+
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        // convert the prefetched halo (fused silu(x*scale+shift), zero padding, float16 hi/lo split) ...
+        h8 shi[NSLOT], slo[NSLOT];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (ok0) v0[e] = dm3d_silu(fmaf(v0[e], sc0[e], sh0[e]));
-                        if (ok1) v1[e] = dm3d_silu(fmaf(v1[e], sc1[e], sh1[e]));
-                    }
+        for (int j = 0; j < NSLOT; ++j) {
+            const bool in = gvox[j] >= 0;
+            f32x4 v0 = raw0[j], v1 = raw1[j];
+            if (pro) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v0[e] = dm3d_silu(fmaf(v0[e], sc0[e], sh0[e]));
+                    v1[e] = dm3d_silu(fmaf(v1[e], sc1[e], sh1[e]));
                 }
             }
-            split8(v0, v1, shi[j], slo[j]);
+            split8(v0, v1, (in && ok0) ? 65504.0f : 0.0f, (in && ok1) ? 65504.0f : 0.0f, shi[j], slo[j]);
         }
         __syncthreads();                        // all waves are done with the previous chunk's halo and weight buffers
+        // ... and publish it
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) {
-            const int hv = (tid >> 1) + j * 128;
-            if (hv < HVOX) {
-                _Float16* rec = lds_in + hv * REC + piece * 8;
-                *reinterpret_cast<h8*>(rec) = shi[j];
-                *reinterpret_cast<h8*>(rec + 16) = slo[j];
+            if (st_off[j] >= 0) {
+                *reinterpret_cast<h8*>(lds_in + st_off[j]) = shi[j];
+                *reinterpret_cast<h8*>(lds_in + (st_off[j] ^ 16)) = slo[j];
             }
         }
         store_w(0);
         __syncthreads();
+        load_halo(ch + 1 < p.nchunks ? ch + 1 : ch);            // in flight for the whole chunk (clamped: never behind a branch)
+        __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll 1
         for (int g = 0; g < NG; ++g) {
             const bool last_group = g + 1 == NG;
-            if (!last_group) fetch_w(ch * NG + g + 1);
-            else if (ch + 1 < p.nchunks) fetch_w((ch + 1) * NG);
+            {   // prefetch the next weight group (next (kd,kh) row, or row 0 of the next chunk), clamped at the very end
+                const int nxt = ch * NG + g + 1, lastg = p.nchunks * NG - 1;
+                fetch_w(nxt < lastg ? nxt : lastg);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 
             const int kd = g / KS, kh = g % KS;                     // KS == 1: g == 0
             const _Float16* wbuf = lds_w + (g & 1) * WGRP;
 #pragma unroll
             for (int t = 0; t < G; ++t) {
-                const int tap_off = ((kd * HH + kh) * HW + t) * REC;
+                const int tap_rec = (kd * HH + kh) * HWP + t;
                 h8 ah[MR], al[MR], bh[NR], bl[NR];
+                {   // row tiles of one wave are MRSTEP records apart, a multiple of 16, so they share the swizzle term: one
+                    // address computation per tap, the rest are immediate offsets (lo slot = hi slot ^ 2)
+                    const int v = a_rec[0] + tap_rec;
+                    const int hi_off = v * REC + ((half ^ swz(v)) << 3);
+                    const int lo_off = hi_off ^ 16;
 #pragma unroll
-                for (int mr = 0; mr < MR; ++mr) {
-                    const _Float16* q = lds_in + a_off[mr] + tap_off;
-                    ah[mr] = *reinterpret_cast<const h8*>(q);
-                    al[mr] = *reinterpret_cast<const h8*>(q + 16);
+                    for (int mr = 0; mr < MR; ++mr) {
+                        ah[mr] = *reinterpret_cast<const h8*>(lds_in + hi_off + mr * (MRSTEP * REC));
+                        al[mr] = *reinterpret_cast<const h8*>(lds_in + lo_off + mr * (MRSTEP * REC));
+                    }
                 }
 #pragma unroll
                 for (int nr = 0; nr < NR; ++nr) {
-                    const _Float16* q = wbuf + t * (NT * REC) + b_off[nr];
-                    bh[nr] = *reinterpret_cast<const h8*>(q);
-                    bl[nr] = *reinterpret_cast<const h8*>(q + 16);
+                    bh[nr] = *reinterpret_cast<const h8*>(wbuf + t * (NT * REC) + b_hi[nr]);
+                    bl[nr] = *reinterpret_cast<const h8*>(wbuf + t * (NT * REC) + b_lo[nr]);
                 }
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr)
@@ -206,6 +288,7 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
                         acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mr], bh[nr], acc[mr][nr], 0, 0, 0);
                     }
             }
+            __builtin_amdgcn_sched_barrier(0);
             if (!last_group) {
                 store_w((g + 1) & 1);
                 __syncthreads();
@@ -213,26 +296,60 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
         }
     }
 
+    // epilogue: + bias + vec[row(b)] -> relu -> + res -> store.  A wave's rows lie in one z slice, so addresses are a
+    // uniform 64-bit slice base plus 32-bit per-lane offsets: accumulator register r = 4q + c of lane half h is the voxel
+    // (dy, dx0 + c) given by row_to_yx(8q + 4h).  Loads are unconditional on clamped indices; stores are predicated only
+    // in partial bricks (uniform branch).
     const int vrow = p.vec ? (p.vec_idx ? p.vec_idx[b] : b) : 0;
     const int n0 = ntile * NT;
+    const bool full = oz0 + TD <= p.od && oy0 + TH <= p.oh && ox0 + TW <= p.ow && n0 + NT <= p.cout;
 #pragma unroll
-    for (int nr = 0; nr < NR; ++nr) {
-        const int n = n0 + wn * (NT / WN) + nr * 32 + l32;
-        if (n >= p.cout) continue;
-        float add = p.bias ? p.bias[n] : 0.0f;
-        if (p.vec) add += p.vec[(size_t)vrow * p.vec_ld + n];
+    for (int mr = 0; mr < MR; ++mr) {
+        const int r0 = wm * (TM / WM) + mr * 32;
+        const int oz = oz0 + r0 / (TH * TW), oyb = oy0 + (r0 / TW) % TH;
+        const bool z_ok = oz < p.od;
+        const size_t zbase = (((size_t)b * p.od + (z_ok ? oz : 0)) * p.oh) * p.ow * p.cout;
+        float* outz = p.out + zbase;
+        const float* resz = p.res ? p.res + zbase : nullptr;
+        int rowoff[4], oyq[4], oxq[4];
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) {
+        for (int q = 0; q < 4; ++q) {
+            int dy, dx;
+            row_to_yx<PAIR>(8 * q + 4 * half, dy, dx);
+            oyq[q] = oyb + dy;
+            oxq[q] = ox0 + dx;
+            rowoff[q] = (oyq[q] * p.ow + oxq[q]) * p.cout;
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * (TM / WM) + mr * 32 + dm3d_acc_row(r, half);
-                const int oz = oz0 + row / (TH * TW), oy = oy0 + (row / TW) % TH, ox = ox0 + row % TW;
-                if (oz < p.od && oy < p.oh && ox < p.ow) {
-                    const size_t o = ((((size_t)b * p.od + oz) * p.oh + oy) * p.ow + ox) * p.cout + n;
+        for (int nr = 0; nr < NR; ++nr) {
+            const int n = n0 + wn * (NT / WN) + nr * 32 + l32;
+            const bool n_ok = n < p.cout;
+            const int nc = n_ok ? n : p.cout - 1;
+            float add = p.bias ? p.bias[nc] : 0.0f;
+            if (p.vec) add += p.vec[(size_t)vrow * p.vec_ld + nc];
+            if (full) {
+                float rv[16];
+                if (resz) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = resz[rowoff[r >> 2] + (r & 3) * p.cout + n];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
                     float v = fmaf(acc[mr][nr][r], p.out_scale, add);
                     if (p.relu) v = fmaxf(v, 0.0f);
-                    if (p.res) v += p.res[o];
-                    p.out[o] = v;
+                    if (resz) v += rv[r];
+                    outz[rowoff[r >> 2] + (r & 3) * p.cout + n] = v;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q = r >> 2, c = r & 3;
+                    const bool ok = n_ok && z_ok && oyq[q] < p.oh && oxq[q] + c < p.ow;
+                    const int o = ok ? rowoff[q] + c * p.cout + n : 0;
+                    float v = fmaf(acc[mr][nr][r], p.out_scale, add);
+                    if (p.relu) v = fmaxf(v, 0.0f);
+                    if (resz) v += resz[o];
+                    if (ok) outz[o] = v;
                 }
             }
         }
@@ -241,8 +358,10 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
 
 template <int TD, int TH, int TW, int S, int KS, int WM, int WN, int MINW>
 int launch_h3(ConvArgs& a, hipStream_t st) {
-    constexpr int HVOX = ((TD - 1) * S + KS) * ((TH - 1) * S + KS) * ((TW - 1) * S + KS);
-    constexpr size_t lds = (size_t)(HVOX * REC + 2 * KS * 64 * REC) * sizeof(_Float16);
+    constexpr int HW = (TW - 1) * S + KS;
+    constexpr int HWP = (S == 1 && TH % 4 == 0 && TW == 8 && KS == 3) ? 12 : HW;
+    constexpr int HREC = ((TD - 1) * S + KS) * ((TH - 1) * S + KS) * HWP;
+    constexpr size_t lds = (size_t)(HREC * REC + 2 * KS * 64 * REC) * sizeof(_Float16);
     static_assert(lds <= 160 * 1024, "LDS budget");
     a.bd = (a.od + TD - 1) / TD;
     a.bh = (a.oh + TH - 1) / TH;
@@ -258,7 +377,8 @@ int launch_h3(ConvArgs& a, hipStream_t st) {
     return dm3d_launch_check("conv3d_igemm_h3");
 }
 
-// Keras [taps][cin][cout] -> [coutpad/64][cinpad/16][taps][64][REC] halfs: 16 hi | 16 lo | 8 zero, scaled by 2^w_exp
+// Keras [taps][cin][cout] -> [coutpad/64][cinpad/16][taps][64][REC] halfs, scaled by 2^w_exp: the LDS image of a weight
+// group, i.e. slots (hi c0-7, hi c8-15, lo c0-7, lo c8-15) of output channel n stored at physical slot s ^ swz(n)
 __global__ __launch_bounds__(256) void pack_weights_h3_kernel(const float* __restrict__ w, int taps, int cin, int cout,
                                                               int nchunks, int ntiles, float scale, const float* in_scale,
                                                               _Float16* __restrict__ out) {
@@ -280,9 +400,9 @@ __global__ __launch_bounds__(256) void pack_weights_h3_kernel(const float* __res
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)hi);
         _Float16* r = out + rec * REC;
-        r[k] = hi;
-        r[16 + k] = lo;
-        if (k < 8) r[32 + k] = (_Float16)0.0f;
+        const int sw = (nn >> 2) & 3;
+        r[(((k >> 3) ^ sw) << 3) + (k & 7)] = hi;
+        r[(((2 + (k >> 3)) ^ sw) << 3) + (k & 7)] = lo;
     }
 }
 
@@ -290,7 +410,7 @@ __global__ __launch_bounds__(256) void pack_weights_h3_kernel(const float* __res
 
 int dm3d_conv_launch_h3(ConvArgs& a, int which, hipStream_t st) {
     if (which == DM3D_CONV_K1) return launch_h3<4, 8, 8, 1, 1, 4, 1, 2>(a, st);
-    if (which == DM3D_CONV_K3S2) return launch_h3<2, 4, 8, 2, 3, 2, 2, 1>(a, st);
+    if (which == DM3D_CONV_K3S2) return launch_h3<2, 4, 8, 2, 3, 2, 2, 2>(a, st);
     return launch_h3<4, 8, 8, 1, 3, 4, 1, 2>(a, st);
 }
 
