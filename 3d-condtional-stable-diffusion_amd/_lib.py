@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libdm3d_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 PREC_F32, PREC_H3 = 0, 1
+FMT_F32, FMT_H2 = 0, 1
 COUT_PAD, CIN_PAD = 64, 16
 
 _f32p = C.c_void_p      # device pointers travel as integers
@@ -38,6 +39,7 @@ class GemmDesc(C.Structure):
         ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("batch", C.c_int32),
         ("alpha", C.c_float), ("bias", _f32p), ("bias_along_m", C.c_int32), ("act", C.c_int32),
         ("res", _f32p), ("ldr", C.c_int64), ("stride_r", C.c_int64),
+        ("precision", C.c_int32), ("a_fmt", C.c_int32), ("b_fmt", C.c_int32), ("out_fmt", C.c_int32),
     ]
 
 
@@ -62,6 +64,9 @@ SIGNATURES = {
     "dm3d_pack_weights_h3": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p, C.c_void_p, C.c_void_p]),
     "dm3d_conv3d_ndhwc": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "dm3d_gemm_tn": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "dm3d_split_h2": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dm3d_layernorm3_h2": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_float] + [_f32p] * 9 + [C.c_void_p]),
+    "dm3d_softmax_rows_h2": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]),
     "dm3d_layernorm3": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_float] + [_f32p] * 9 + [C.c_void_p]),
     "dm3d_softmax_rows": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]),
     "dm3d_affine_act": (C.c_int, [_f32p, _f32p, C.c_int64, C.c_int32, _f32p, _f32p, C.c_int32, C.c_void_p]),

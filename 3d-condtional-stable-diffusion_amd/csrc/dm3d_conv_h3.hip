@@ -21,14 +21,11 @@
 //     4 x 8 voxel tile, and the MFMA row -> voxel map (row_to_yx) hands one copy to each of the two hardware lane
 //     groups {0-3,12-15,20-27} and {4-11,16-19,28-31}.  Weight rows (record = output channel) are conflict-free as is.
 #include "dm3d_conv_args.h"
+#include "dm3d_h3.h"
 
 namespace {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-
-constexpr int REC = 32;            // halfs per LDS record: 4 slots of 8 halfs (hi0 hi1 lo0 lo1), XOR-swizzled by the record index
-
-__device__ __forceinline__ int swz(int v) { return (v >> 2) & 3; }
+constexpr int REC = DM3D_REC;
 
 // MFMA tile row i (0..31) -> (dy, dx) inside a 4 x 8 voxel tile.  PAIR = 0: natural order.  PAIR = 2 / 1: the lanes of
 // the first ds_read_b128 lane group {0-3,12-15,20-27} take rows dy in {0,PAIR}, the second group takes the other two.
@@ -41,33 +38,6 @@ __device__ __forceinline__ void row_to_yx(int i, int& dy, int& dx) {
     dx = idx & 7;
     if (PAIR == 2) dy = g1 ? 1 + 2 * sel : 2 * sel;
     else dy = g1 ? 2 + sel : sel;
-}
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// 8 consecutive channels -> float16 hi and lo terms, x = hi + lo up to 2^-22 |x|; lim0/lim1 are 65504 (clamp to the
-// float16 range) or 0 (padding / out-of-range position -> exact zero), so one v_med3_f32 clamps and masks.  Per pair:
-// v_cvt_pk_f16_f32 (hi, RNE), 2 x v_fma_mix_f32 (x - hi with hi read as f16 straight from the packed register),
-// v_cvt_pk_f16_f32 (lo) — 3 VALU per element; hipcc's own lowering of the same arithmetic takes 7.  VALU issue slots
-// are what this kernel runs out of first (4.7 VALU per MFMA before this diet, measured with SQ_INSTS_VALU).
-__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, float lim0, float lim1, h8& hi, h8& lo) {
-    u32x4 ph, pl;
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-        const float lim = e < 4 ? lim0 : lim1;
-        const float x0 = __builtin_amdgcn_fmed3f(e < 4 ? v0[e] : v1[e - 4], -lim, lim);
-        const float x1 = __builtin_amdgcn_fmed3f(e < 4 ? v0[e + 1] : v1[e - 3], -lim, lim);
-        unsigned int a, r;
-        float r0, r1;
-        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(a) : "v"(x0), "v"(x1));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(a), "v"(x0));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(a), "v"(x1));
-        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(r0), "v"(r1));
-        ph[e >> 1] = a;
-        pl[e >> 1] = r;
-    }
-    hi = __builtin_bit_cast(h8, ph);
-    lo = __builtin_bit_cast(h8, pl);
 }
 
 template <int TD, int TH, int TW, int S, int KS, int WM, int WN, int MINW>

@@ -1,7 +1,7 @@
 // dm3d_elem.hip — the HBM-bound companions of the conv/GEMM kernels: LayerNormalization, row softmax (wavefront
 // shuffle reductions), per-channel affine+activation, the DDPM posterior update with in-kernel Philox noise, and small
 // index utilities.  All accesses are 16 B per lane, coalesced.
-#include "dm3d_common.h"
+#include "dm3d_h3.h"
 
 namespace {
 
@@ -109,6 +109,110 @@ __global__ __launch_bounds__(256) void softmax_rows_stream_kernel(float* __restr
     for (int i = lane; i < cols; i += 64) sum += __expf(r[i] - mx);
     const float inv = 1.0f / wave_sum(sum);
     for (int i = lane; i < cols; i += 64) r[i] = __expf(r[i] - mx) * inv;
+}
+
+// ---- LayerNormalization with DM3D_FMT_H2 outputs: lane owns 8 consecutive channels per group (c <= 1024 -> <= 2 groups) ----
+__global__ __launch_bounds__(256) void layernorm3_h2_kernel(const float* __restrict__ x, long rows, int c, float eps,
+                                                            const float* g1, const float* b1, _Float16* o1,
+                                                            const float* g2, const float* b2, _Float16* o2,
+                                                            const float* g3, const float* b3, _Float16* o3) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int ng = c >> 3;                          // 8-channel groups per row
+    const float* xr = x + row * c;
+    f32x4 v[2][2];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int g = lane + j * 64;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        v[j][0] = g < ng ? *reinterpret_cast<const f32x4*>(xr + g * 8) : z;
+        v[j][1] = g < ng ? *reinterpret_cast<const f32x4*>(xr + g * 8 + 4) : z;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += v[j][0][e] + v[j][1][e];
+    }
+    const float mean = wave_sum(s) / (float)c;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (lane + j * 64 < ng) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d0 = v[j][0][e] - mean, d1 = v[j][1][e] - mean;
+                q += d0 * d0 + d1 * d1;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)c + eps);
+    const float* gs[3] = {g1, g2, g3};
+    const float* bs[3] = {b1, b2, b3};
+    _Float16* os[3] = {o1, o2, o3};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (!os[k]) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int g = lane + j * 64;
+            if (g < ng) {
+                f32x4 y0, y1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y0[e] = (v[j][0][e] - mean) * rstd * gs[k][g * 8 + e] + bs[k][g * 8 + e];
+                    y1[e] = (v[j][1][e] - mean) * rstd * gs[k][g * 8 + 4 + e] + bs[k][g * 8 + 4 + e];
+                }
+                h8 hi, lo;
+                split8(y0, y1, 65504.0f, 65504.0f, hi, lo);
+                _Float16* rec = os[k] + row * c * 2 + (g >> 1) * DM3D_REC;
+                *reinterpret_cast<h8*>(rec + (g & 1) * 8) = hi;
+                *reinterpret_cast<h8*>(rec + 16 + (g & 1) * 8) = lo;
+            }
+        }
+    }
+}
+
+// ---- softmax over the last axis, result left in place in DM3D_FMT_H2.  One wavefront owns a row: every load of the row has
+// completed (the max / sum reductions need them) before the first store, so the in-place format change is race free. ----
+__global__ __launch_bounds__(256) void softmax_rows_h2_kernel(float* __restrict__ s, long rows, int cols, long ld) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* r = s + row * ld;
+    const int ng = cols >> 3;
+    f32x4 v[2][2];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int g = lane + j * 64;
+        const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        v[j][0] = g < ng ? *reinterpret_cast<const f32x4*>(r + g * 8) : ninf;
+        v[j][1] = g < ng ? *reinterpret_cast<const f32x4*>(r + g * 8 + 4) : ninf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fmaxf(v[j][0][e], v[j][1][e]));
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[j][0][e] = __expf(v[j][0][e] - mx);       // exp(-inf) = 0 for the padding groups
+            v[j][1][e] = __expf(v[j][1][e] - mx);
+            sum += v[j][0][e] + v[j][1][e];
+        }
+    const float inv = 1.0f / wave_sum(sum);
+    _Float16* rh = reinterpret_cast<_Float16*>(r);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int g = lane + j * 64;
+        if (g < ng) {
+            h8 hi, lo;
+            split8(v[j][0] * inv, v[j][1] * inv, 65504.0f, 65504.0f, hi, lo);
+            _Float16* rec = rh + (g >> 1) * DM3D_REC;
+            *reinterpret_cast<h8*>(rec + (g & 1) * 8) = hi;
+            *reinterpret_cast<h8*>(rec + 16 + (g & 1) * 8) = lo;
+        }
+    }
 }
 
 // ---- y = act(x*scale[c] + shift[c]) ---------------------------------------------------------------------------------
@@ -344,4 +448,29 @@ extern "C" int dm3d_pack_weights(const float* keras_kernel, int32_t taps, int32_
     hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), keras_kernel,
                        taps, cin, cout, cinpad, coutpad, in_scale, packed);
     return dm3d_launch_check("pack_weights_kernel");
+}
+
+extern "C" int dm3d_layernorm3_h2(const float* x, int64_t rows, int32_t c, float eps,
+                                  const float* g1, const float* b1, void* o1,
+                                  const float* g2, const float* b2, void* o2,
+                                  const float* g3, const float* b3, void* o3, void* stream) {
+    DM3D_REQUIRE(x && rows > 0, "layernorm_h2: x null or rows <= 0");
+    DM3D_REQUIRE(c > 0 && c % 16 == 0 && c <= 1024, "layernorm_h2: c=%d must be a multiple of 16 and <= 1024", c);
+    DM3D_REQUIRE(o1 || o2 || o3, "layernorm_h2: no output");
+    DM3D_REQUIRE((!o1 || (g1 && b1)) && (!o2 || (g2 && b2)) && (!o3 || (g3 && b3)), "layernorm_h2: output without gamma/beta");
+    const void* ptrs[] = {x, o1, o2, o3};
+    for (const void* q : ptrs) DM3D_REQUIRE(dm3d_aligned16(q), "layernorm_h2: pointer %p is not 16-byte aligned", q);
+    hipLaunchKernelGGL(layernorm3_h2_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x, (long)rows, c, eps, g1, b1, static_cast<_Float16*>(o1), g2, b2, static_cast<_Float16*>(o2), g3, b3,
+                       static_cast<_Float16*>(o3));
+    return dm3d_launch_check("layernorm3_h2_kernel");
+}
+
+extern "C" int dm3d_softmax_rows_h2(float* s, int64_t rows, int32_t cols, int64_t ld, void* stream) {
+    DM3D_REQUIRE(s && rows > 0 && cols > 0 && ld >= cols, "softmax_h2: bad arguments");
+    DM3D_REQUIRE(cols % 16 == 0 && cols <= 1024 && ld % 16 == 0 && dm3d_aligned16(s),
+                 "softmax_h2: cols=%d must be a multiple of 16 and <= 1024, ld %% 16 == 0, s 16-byte aligned", cols);
+    hipLaunchKernelGGL(softmax_rows_h2_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       s, (long)rows, cols, (long)ld);
+    return dm3d_launch_check("softmax_rows_h2_kernel");
 }

@@ -104,6 +104,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32(const GemmArgs p) {
 
 }  // namespace
 
+int dm3d_gemm_h3_launch(const dm3d_gemm_desc* d, hipStream_t st);     // dm3d_gemm_h3.hip
+
 extern "C" int dm3d_gemm_tn(const dm3d_gemm_desc* d, void* stream) {
     DM3D_REQUIRE(d != nullptr, "gemm: null descriptor");
     DM3D_REQUIRE(d->a && d->b && d->out, "gemm: a/b/out must be non-null");
@@ -117,6 +119,10 @@ extern "C" int dm3d_gemm_tn(const dm3d_gemm_desc* d, void* stream) {
     DM3D_REQUIRE(dm3d_aligned16(d->a) && dm3d_aligned16(d->b), "gemm: a/b must be 16-byte aligned");
     DM3D_REQUIRE(d->act >= DM3D_ACT_NONE && d->act <= DM3D_ACT_SILU, "gemm: unknown act %d", d->act);
     DM3D_REQUIRE(d->batch <= 65535, "gemm: batch %d exceeds grid.z", d->batch);
+    DM3D_REQUIRE(d->precision == DM3D_PREC_F32 || d->precision == DM3D_PREC_H3, "gemm: unknown precision %d", d->precision);
+    if (d->precision == DM3D_PREC_H3) return dm3d_gemm_h3_launch(d, static_cast<hipStream_t>(stream));
+    DM3D_REQUIRE(d->a_fmt == DM3D_FMT_F32 && d->b_fmt == DM3D_FMT_F32 && d->out_fmt == DM3D_FMT_F32,
+                 "gemm: the float32 kernel takes float32 operands only");
     GemmArgs a{};
     a.a = d->a; a.lda = d->lda; a.sa = d->stride_a;
     a.b = d->b; a.ldb = d->ldb; a.sb = d->stride_b;

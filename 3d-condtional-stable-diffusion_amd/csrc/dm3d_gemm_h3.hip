@@ -1,0 +1,314 @@
+// dm3d_gemm_h3.hip — batched "TN" contraction out[b][m][n] = act(alpha * sum_k A[b][m][k] B[b][n][k] + bias) + res on the
+// 16-bit matrix pipe with float32-grade results (split-float16 arithmetic, see dm3d_h3.h).
+//
+// Replaces the same reference ops as dm3d_gemm.hip (layers.Dense, 1x1 Conv3D, the attention einsums; reference
+// networks/conditional_dm3d.py:129-137, 164-180).  A GEMM re-stages its operands for every 64 output columns, so — unlike the
+// conv, which amortises one halo over 27 taps — splitting float32 operands while staging would make the kernel VALU-bound
+// (5 VALU per MFMA).  Operands therefore normally arrive pre-split in DM3D_FMT_H2 (written by the producing kernel's
+// epilogue, by the LayerNorm / softmax kernels, or once at load time for weights) and staging is plain 16-byte copies into
+// the XOR-swizzled LDS records; a float32 operand is still accepted (split on the fly) for the tensors that enter a block
+// from a convolution.
+//
+// Workgroup = 256 threads, tile 256 (m) x 64 (n), K in chunks of 32 (two 16-k records per row), LDS double-buffered
+// (2 x 40 KB -> two workgroups per CU), next chunk prefetched into registers during the MFMAs, one barrier per chunk.
+#include "dm3d_h3.h"
+
+namespace {
+
+struct GemmH3Args {
+    const void* a; long lda, sa;        // leading dimensions / batch strides in elements (4 bytes each in both formats)
+    const void* b; long ldb, sb;
+    void* out; long ldo, so;
+    int m, n, k;
+    float alpha;
+    const float* bias; int bias_m; int act;
+    const float* res; long ldr, sr;
+    int out_h2;
+};
+
+constexpr int REC = DM3D_REC;
+constexpr int KC = 32, TM = 256, NT = 64;
+constexpr int A_BUF = 2 * TM * REC, B_BUF = 2 * NT * REC;      // halfs per buffer (two records per row)
+
+template <bool A_F32, bool B_F32>
+__global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmH3Args p) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_g[];
+    _Float16* lds_a = smem_g;                   // [2][2][TM][REC]
+    _Float16* lds_b = smem_g + 2 * A_BUF;       // [2][2][NT][REC]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * NT, bz = blockIdx.z;
+    const char* A = static_cast<const char*>(p.a) + (size_t)bz * p.sa * 4;
+    const char* B = static_cast<const char*>(p.b) + (size_t)bz * p.sb * 4;
+
+    // ---- staging maps (all loads unconditional on clamped rows; rows beyond m / n only feed outputs that are never stored)
+    // H2 source: a row's chunk is 128 contiguous bytes = 8 pieces (record kk = w >> 2, slot w & 3)
+    // F32 source: item = (row, 8-k group g): two float4 -> hi slot g & 1, lo slot 2 + (g & 1) of record g >> 1
+    constexpr int A_ITEMS = A_F32 ? 4 : 8, B_ITEMS = A_F32 ? 1 : 2;
+    constexpr int BI = B_F32 ? 1 : 2;
+    f32x4 ra[8], rb[2];
+    size_t a_src[A_F32 ? 4 : 8];
+    int a_dst[A_F32 ? 4 : 8];
+#pragma unroll
+    for (int i = 0; i < A_ITEMS; ++i) {
+        const int q = tid + i * 256;
+        if (A_F32) {
+            const int row = q >> 2, g = q & 3;
+            const int mrow = m0 + row < p.m ? m0 + row : p.m - 1;
+            a_src[i] = ((size_t)mrow * p.lda + g * 8) * 4;
+            a_dst[i] = ((g >> 1) * TM + row) * REC + (((g & 1) ^ swz(row)) << 3);
+        } else {
+            const int row = q >> 3, w = q & 7;
+            const int mrow = m0 + row < p.m ? m0 + row : p.m - 1;
+            a_src[i] = (size_t)mrow * p.lda * 4 + w * 16;
+            a_dst[i] = ((w >> 2) * TM + row) * REC + (((w & 3) ^ swz(row)) << 3);
+        }
+    }
+    size_t b_src[2];
+    int b_dst[2];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int q = tid + i * 256;
+        if (B_F32) {
+            const int row = q >> 2, g = q & 3;
+            const int nrow = n0 + row < p.n ? n0 + row : p.n - 1;
+            b_src[i] = ((size_t)nrow * p.ldb + g * 8) * 4;
+            b_dst[i] = ((g >> 1) * NT + row) * REC + (((g & 1) ^ swz(row)) << 3);
+        } else {
+            const int row = q >> 3, w = q & 7;
+            const int nrow = n0 + row < p.n ? n0 + row : p.n - 1;
+            b_src[i] = (size_t)nrow * p.ldb * 4 + w * 16;
+            b_dst[i] = ((w >> 2) * NT + row) * REC + (((w & 3) ^ swz(row)) << 3);
+        }
+    }
+    (void)B_ITEMS;
+
+    auto fetch = [&](int k0) {                  // k0 is clamped by the caller to the last chunk
+        // when k % 32 == 16 the last chunk has no second record: its loads re-read the first one (64 bytes earlier)
+        // instead of running past the end of the row; publish() zero-fills the LDS image
+        const bool sec = k0 + 16 < p.k;
+#pragma unroll
+        for (int i = 0; i < A_ITEMS; ++i) {
+            const bool second = A_F32 ? (((tid + i * 256) & 3) >= 2) : (((tid + i * 256) & 7) >= 4);
+            const size_t koff = (size_t)k0 * 4 - ((!sec && second) ? 64 : 0);
+            if (A_F32) {
+                ra[2 * i] = *reinterpret_cast<const f32x4*>(A + a_src[i] + koff);
+                ra[2 * i + 1] = *reinterpret_cast<const f32x4*>(A + a_src[i] + koff + 16);
+            } else {
+                ra[i] = *reinterpret_cast<const f32x4*>(A + a_src[i] + koff);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const bool second = B_F32 ? (((tid + i * 256) & 3) >= 2) : (((tid + i * 256) & 7) >= 4);
+            const size_t koff = (size_t)k0 * 4 - ((!sec && second) ? 64 : 0);
+            if (B_F32) {
+                rb[0] = *reinterpret_cast<const f32x4*>(B + b_src[i] + koff);
+                rb[1] = *reinterpret_cast<const f32x4*>(B + b_src[i] + koff + 16);
+            } else {
+                rb[i] = *reinterpret_cast<const f32x4*>(B + b_src[i] + koff);
+            }
+        }
+    };
+    // k tail: the chunk's second record is absent when k % 32 == 16; its LDS image is zero filled
+    auto publish = [&](int buf, bool second_rec) {
+        _Float16* da = lds_a + buf * A_BUF;
+        _Float16* db = lds_b + buf * B_BUF;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < A_ITEMS; ++i) {
+            if (A_F32) {
+                const bool ok = second_rec || ((tid + i * 256) & 3) < 2;
+                h8 hi, lo;
+                split8(ra[2 * i], ra[2 * i + 1], ok ? 65504.0f : 0.0f, ok ? 65504.0f : 0.0f, hi, lo);
+                *reinterpret_cast<h8*>(da + a_dst[i]) = hi;
+                *reinterpret_cast<h8*>(da + (a_dst[i] ^ 16)) = lo;
+            } else {
+                const bool ok = second_rec || ((tid + i * 256) & 7) < 4;
+                *reinterpret_cast<f32x4*>(da + a_dst[i]) = ok ? ra[i] : z;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            if (B_F32) {
+                const bool ok = second_rec || ((tid + i * 256) & 3) < 2;
+                h8 hi, lo;
+                split8(rb[0], rb[1], ok ? 65504.0f : 0.0f, ok ? 65504.0f : 0.0f, hi, lo);
+                *reinterpret_cast<h8*>(db + b_dst[i]) = hi;
+                *reinterpret_cast<h8*>(db + (b_dst[i] ^ 16)) = lo;
+            } else {
+                const bool ok = second_rec || ((tid + i * 256) & 7) < 4;
+                *reinterpret_cast<f32x4*>(db + b_dst[i]) = ok ? rb[i] : z;
+            }
+        }
+    };
+
+    // fragment addresses: record = row, hi slot = half ^ swz(row), lo slot = that ^ 2; 32-row tiles are 32 records apart
+    int a_hi, b_hi;
+    {
+        const int row = wave * 64 + l32;
+        a_hi = row * REC + ((half ^ swz(row)) << 3);
+        b_hi = l32 * REC + ((half ^ swz(l32)) << 3);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mr = 0; mr < 2; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < 2; ++nr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.0f;
+
+    const int nchunks = (p.k + KC - 1) / KC;
+    fetch(0);
+    for (int it = 0; it < nchunks; ++it) {
+        const int buf = it & 1;
+        publish(buf, it * KC + 16 < p.k);
+        __syncthreads();                        // chunk `it` visible; everyone has left chunk it-1 (other buffer)
+        fetch((it + 1 < nchunks ? it + 1 : it) * KC);
+        __builtin_amdgcn_sched_barrier(0);
+        const _Float16* la = lds_a + buf * A_BUF;
+        const _Float16* lb = lds_b + buf * B_BUF;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            h8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int mr = 0; mr < 2; ++mr) {
+                ah[mr] = *reinterpret_cast<const h8*>(la + a_hi + (kk * TM + mr * 32) * REC);
+                al[mr] = *reinterpret_cast<const h8*>(la + (a_hi ^ 16) + (kk * TM + mr * 32) * REC);
+            }
+#pragma unroll
+            for (int nr = 0; nr < 2; ++nr) {
+                bh[nr] = *reinterpret_cast<const h8*>(lb + b_hi + (kk * NT + nr * 32) * REC);
+                bl[nr] = *reinterpret_cast<const h8*>(lb + (b_hi ^ 16) + (kk * NT + nr * 32) * REC);
+            }
+#pragma unroll
+            for (int mr = 0; mr < 2; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < 2; ++nr) {
+                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mr], bh[nr], acc[mr][nr], 0, 0, 0);
+                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mr], bl[nr], acc[mr][nr], 0, 0, 0);
+                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mr], bh[nr], acc[mr][nr], 0, 0, 0);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue: lane (l32, half) holds column n and rows acc_row(r, half) of each 32 x 32 tile.  Addresses are a uniform
+    // 64-bit tile base plus 32-bit lane offsets; a small-K GEMM has only ~200 MFMAs per wave, so per-element 64-bit index
+    // arithmetic and predicates would cost more issue slots than the contraction itself.
+    const bool full = m0 + TM <= p.m && n0 + NT <= p.n;
+    char* O = static_cast<char*>(p.out) + ((size_t)bz * p.so + (size_t)m0 * p.ldo) * 4;
+    const float* R = p.res ? p.res + (size_t)bz * p.sr + (size_t)m0 * p.ldr : nullptr;
+    const int lrow = wave * 64 + 4 * half;                     // + mr*32 + (r&3) + 8*(r>>2)
+    const int ldo = (int)p.ldo, ldr = (int)p.ldr;
+#pragma unroll
+    for (int nr = 0; nr < 2; ++nr) {
+        const int n = n0 + nr * 32 + l32;
+        const bool n_ok = n < p.n;
+        const int nc = n_ok ? n : p.n - 1;
+        const float bn = (p.bias && !p.bias_m) ? p.bias[nc] : 0.0f;
+        // H2 column position inside its row: record n >> 4, slot (n >> 3) & 1 (+2 for lo), element n & 7; lanes n and n^1
+        // exchange halves so that every lane stores one dword: even lanes the hi pair, odd lanes the lo pair
+        const int h2col = (n >> 4) * 64 + ((n >> 3) & 1) * 16 + ((n & 7) >> 1) * 4 + (n & 1) * 32;
+        const int ocol = p.out_h2 ? h2col : n * 4;
+#pragma unroll
+        for (int mr = 0; mr < 2; ++mr) {
+            float rv[16], bm[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = lrow + mr * 32 + (r & 3) + 8 * (r >> 2);
+                const int rc = full ? row : (m0 + row < p.m ? row : p.m - 1 - m0);
+                rv[r] = R ? R[rc * ldr + nc] : 0.0f;
+                bm[r] = (p.bias && p.bias_m) ? p.bias[m0 + rc] : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = lrow + mr * 32 + (r & 3) + 8 * (r >> 2);
+                const bool ok = full || (n_ok && m0 + row < p.m);
+                float v = dm3d_act(acc[mr][nr][r] * p.alpha + bn + bm[r], p.act) + rv[r];
+                if (p.out_h2) {
+                    const unsigned int mine = split1_bits(v);
+                    const unsigned int oth = (unsigned int)__shfl_xor((int)mine, 1, 64);
+                    const unsigned int word = (n & 1) ? ((oth >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (oth << 16));
+                    if (ok) *reinterpret_cast<unsigned int*>(O + (size_t)(unsigned)(row * ldo) * 4 + ocol) = word;
+                } else {
+                    if (ok) *reinterpret_cast<float*>(O + (size_t)(unsigned)(row * ldo) * 4 + ocol) = v;
+                }
+            }
+        }
+    }
+}
+
+// float32 [rows][k] (ld_src) -> DM3D_FMT_H2 [rows][ld_dst], scaled by 2^exp2, zero filled up to round_up(k, 16)
+__global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__ src, long rows, int k, long ld_src, float scale,
+                                                       _Float16* __restrict__ dst, long ld_dst) {
+    const int groups = (int)((k + 15) / 16) * 2;                    // 8-k groups per row incl. padding
+    const long total = rows * groups;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long row = i / groups;
+        const int g = (int)(i % groups);
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        const float* s = src + row * ld_src + g * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (g * 8 + e < k) v0[e] = s[e] * scale;
+            if (g * 8 + 4 + e < k) v1[e] = s[4 + e] * scale;
+        }
+        h8 hi, lo;
+        split8(v0, v1, 65504.0f, 65504.0f, hi, lo);
+        _Float16* rec = dst + row * ld_dst * 2 + (g >> 1) * REC;     // ld_dst elements = 2 halfs each
+        *reinterpret_cast<h8*>(rec + (g & 1) * 8) = hi;
+        *reinterpret_cast<h8*>(rec + 16 + (g & 1) * 8) = lo;
+    }
+}
+
+}  // namespace
+
+int dm3d_gemm_h3_launch(const dm3d_gemm_desc* d, hipStream_t st) {
+    DM3D_REQUIRE(d->k % 16 == 0 && d->lda % 4 == 0 && d->ldb % 4 == 0, "gemm(h3): k=%d must be a multiple of 16", d->k);
+    DM3D_REQUIRE(d->a_fmt == DM3D_FMT_F32 || d->a_fmt == DM3D_FMT_H2, "gemm(h3): bad a_fmt");
+    DM3D_REQUIRE(d->b_fmt == DM3D_FMT_F32 || d->b_fmt == DM3D_FMT_H2, "gemm(h3): bad b_fmt");
+    DM3D_REQUIRE(d->a_fmt == DM3D_FMT_F32 || (d->lda % 16 == 0 && d->stride_a % 16 == 0), "gemm(h3): H2 operand a needs lda, stride %% 16 == 0");
+    DM3D_REQUIRE(d->b_fmt == DM3D_FMT_F32 || (d->ldb % 16 == 0 && d->stride_b % 16 == 0), "gemm(h3): H2 operand b needs ldb, stride %% 16 == 0");
+    DM3D_REQUIRE(d->out_fmt == DM3D_FMT_F32 || (d->out_fmt == DM3D_FMT_H2 && d->n % 16 == 0 && d->ldo % 16 == 0 && d->stride_o % 16 == 0),
+                 "gemm(h3): H2 output needs n, ldo, stride_o %% 16 == 0");
+    DM3D_REQUIRE(dm3d_aligned16(d->out) || d->out_fmt == DM3D_FMT_F32, "gemm(h3): H2 output must be 16-byte aligned");
+    GemmH3Args a{};
+    a.a = d->a; a.lda = d->lda; a.sa = d->stride_a;
+    a.b = d->b; a.ldb = d->ldb; a.sb = d->stride_b;
+    a.out = d->out; a.ldo = d->ldo; a.so = d->stride_o;
+    a.m = d->m; a.n = d->n; a.k = d->k; a.alpha = d->alpha;
+    a.bias = d->bias; a.bias_m = d->bias_along_m; a.act = d->act;
+    a.res = d->res; a.ldr = d->ldr; a.sr = d->stride_r;
+    a.out_h2 = d->out_fmt == DM3D_FMT_H2;
+    constexpr size_t lds = (size_t)(2 * A_BUF + 2 * B_BUF) * sizeof(_Float16);     // 81920
+    static bool attr_set = false;
+    if (!attr_set) {
+        const void* fns[] = {reinterpret_cast<const void*>(&gemm_tn_h3<false, false>), reinterpret_cast<const void*>(&gemm_tn_h3<true, false>),
+                             reinterpret_cast<const void*>(&gemm_tn_h3<false, true>), reinterpret_cast<const void*>(&gemm_tn_h3<true, true>)};
+        for (const void* f : fns) DM3D_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)((d->m + TM - 1) / TM), (unsigned)((d->n + NT - 1) / NT), (unsigned)d->batch);
+    const bool af = d->a_fmt == DM3D_FMT_F32, bf = d->b_fmt == DM3D_FMT_F32;
+    if (af && bf) hipLaunchKernelGGL((gemm_tn_h3<true, true>), grid, dim3(256), lds, st, a);
+    else if (af) hipLaunchKernelGGL((gemm_tn_h3<true, false>), grid, dim3(256), lds, st, a);
+    else if (bf) hipLaunchKernelGGL((gemm_tn_h3<false, true>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((gemm_tn_h3<false, false>), grid, dim3(256), lds, st, a);
+    return dm3d_launch_check("gemm_tn_h3");
+}
+
+extern "C" int dm3d_split_h2(const float* src, int64_t rows, int32_t k, int64_t ld_src, int32_t exp2, void* dst, int64_t ld_dst,
+                             void* stream) {
+    DM3D_REQUIRE(src && dst && rows > 0 && k > 0 && ld_src >= k, "split_h2: bad arguments");
+    DM3D_REQUIRE(ld_dst % 16 == 0 && ld_dst >= dm3d_round_up(k, 16), "split_h2: ld_dst=%lld must be a multiple of 16 covering k", (long long)ld_dst);
+    DM3D_REQUIRE(exp2 >= -100 && exp2 <= 100 && dm3d_aligned16(dst), "split_h2: exp2 out of range or dst unaligned");
+    const long total = rows * (long)(dm3d_round_up(k, 16) / 8);
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(split_h2_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream), src, (long)rows, k,
+                       (long)ld_src, ldexpf(1.0f, exp2), static_cast<_Float16*>(dst), (long)ld_dst);
+    return dm3d_launch_check("split_h2_kernel");
+}

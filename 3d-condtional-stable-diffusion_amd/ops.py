@@ -87,8 +87,27 @@ def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False
     return out
 
 
+def split_h2(src: torch.Tensor, exp2: int = 0) -> torch.Tensor:
+    """float32 [rows, k] -> DM3D_FMT_H2 [rows, round_up(k,16)] (returned as a float32-typed buffer of the same byte size)."""
+    _f32c(src, "src")
+    rows, k = src.numel() // src.shape[-1], src.shape[-1]
+    ld = -(-k // 16) * 16
+    dst = torch.empty(rows, ld, dtype=torch.float32, device=src.device)
+    check(lib().dm3d_split_h2(src.data_ptr(), rows, k, k, exp2, dst.data_ptr(), ld, _st()), "split_h2")
+    return dst
+
+
+def h2_to_f32(h2: torch.Tensor, k: int) -> torch.Tensor:
+    """Host-side decoder of DM3D_FMT_H2 (tests only): [rows, ld] float32-typed buffer -> float32 hi + lo values."""
+    rows, ld = h2.shape
+    rec = h2.contiguous().view(torch.float16).reshape(rows, ld // 16, 4, 8).float()
+    val = rec[:, :, 0:2, :] + rec[:, :, 2:4, :]
+    return val.reshape(rows, ld)[:, :k]
+
+
 def gemm_tn(a, b, *, m=None, n=None, k=None, lda=None, ldb=None, batch=1, stride_a=None, stride_b=None, alpha=1.0, bias=None,
-            bias_along_m=False, act=ACT_NONE, res=None, out=None) -> torch.Tensor:
+            bias_along_m=False, act=ACT_NONE, res=None, out=None, precision=_lib.PREC_F32, a_fmt=_lib.FMT_F32,
+            b_fmt=_lib.FMT_F32, out_fmt=_lib.FMT_F32) -> torch.Tensor:
     """out[b][m][n] = act(alpha * sum_k a[b][m][k] b[b][n][k] + bias) + res.  a: [batch?, m, k], b: [batch?, n, k]."""
     _f32c(a, "a"), _f32c(b, "b")
     m = a.shape[-2] if m is None else m
@@ -110,6 +129,7 @@ def gemm_tn(a, b, *, m=None, n=None, k=None, lda=None, ldb=None, batch=1, stride
     d.bias, d.bias_along_m, d.act = _p(bias), int(bool(bias_along_m)), act
     if res is not None:
         d.res, d.ldr, d.stride_r = res.data_ptr(), n, m * n
+    d.precision, d.a_fmt, d.b_fmt, d.out_fmt = precision, a_fmt, b_fmt, out_fmt
     check(lib().dm3d_gemm_tn(C.byref(d), _st()), "gemm_tn")
     return out
 
@@ -128,6 +148,28 @@ def layernorm3(x, params, eps=1e-3):
             args += [None, None, None]
     check(lib().dm3d_layernorm3(x.data_ptr(), rows, c, eps, *args, _st()), "layernorm3")
     return outs
+
+
+def layernorm3_h2(x, params, eps=1e-3):
+    _f32c(x, "x")
+    c = x.shape[-1]
+    rows = x.numel() // c
+    outs = [torch.empty_like(x) for _ in params]
+    args = []
+    for i in range(3):
+        if i < len(params):
+            args += [params[i][0].data_ptr(), params[i][1].data_ptr(), outs[i].data_ptr()]
+        else:
+            args += [None, None, None]
+    check(lib().dm3d_layernorm3_h2(x.data_ptr(), rows, c, eps, *args, _st()), "layernorm3_h2")
+    return outs
+
+
+def softmax_rows_h2_(s: torch.Tensor) -> torch.Tensor:
+    _f32c(s, "s")
+    cols = s.shape[-1]
+    check(lib().dm3d_softmax_rows_h2(s.data_ptr(), s.numel() // cols, cols, cols, _st()), "softmax_rows_h2")
+    return s
 
 
 def softmax_rows_(s: torch.Tensor) -> torch.Tensor:

@@ -48,6 +48,7 @@ class _Conv:
         self.wpk, self.bias, self.taps, self.cin, self.cout = wpk, bias, taps, cin, cout
         self.precision, self.w_exp = precision, w_exp
         self.cin_pad = -(-cin // _lib.CIN_PAD) * _lib.CIN_PAD
+        self.h2 = None              # DM3D_FMT_H2 copy of wpk ([cout_pad][cin_pad]) for the H3 GEMM
 
 
 class UNet:
@@ -127,6 +128,17 @@ class UNet:
               "pack_weights")
         return _Conv(wpk, self._dev(bias) if bias is not None else None, taps, cin, cout)
 
+    def _to_h2(self, t: torch.Tensor, rows: int, k: int) -> torch.Tensor:
+        """float32 [rows, k] device matrix (k % 16 == 0) -> DM3D_FMT_H2 buffer of the same byte size."""
+        out = torch.empty(rows, k, dtype=torch.float32, device=self.device)
+        check(lib().dm3d_split_h2(t.data_ptr(), rows, k, k, 0, out.data_ptr(), k, _stream()), "split_h2")
+        return out
+
+    def _with_h2(self, w: _Conv) -> _Conv:
+        if self.precision == "h3" and w.taps == 1:
+            w.h2 = self._to_h2(w.wpk, w.wpk.numel() // w.cin_pad, w.cin_pad)
+        return w
+
     def _fold_bn(self, name: str):
         """Inference BatchNormalization gamma*(x-mean)/sqrt(var+eps)+beta as x*scale+shift."""
         s = self.state
@@ -180,24 +192,28 @@ class UNet:
             self._gemm_now(a=shift, lda=u, b=plain.wpk, ldb=plain.cin_pad, out=bias2, ldo=u, m=1, n=u, k=u, bias=plain.bias)
             folded = self._pack(s[f"{n}.proj_in.kernel"], None, in_scale=scale)
             folded.bias = bias2
-            P[f"{n}.proj_in"] = folded
-            P[f"{n}.proj_out"] = self._pack(s[f"{n}.proj_out.kernel"], s[f"{n}.proj_out.bias"])
+            P[f"{n}.proj_in"] = self._with_h2(folded)
+            P[f"{n}.proj_out"] = self._with_h2(self._pack(s[f"{n}.proj_out.kernel"], s[f"{n}.proj_out.bias"]))
             for ln in ("ln1", "ln2", "ln3"):
                 P[f"{n}.{ln}"] = (self._dev(s[f"{n}.{ln}.gamma"]), self._dev(s[f"{n}.{ln}.beta"]))
-            P[f"{n}.mlp.0"] = self._pack(s[f"{n}.mlp.0.kernel"], s[f"{n}.mlp.0.bias"])
-            P[f"{n}.mlp.1"] = self._pack(s[f"{n}.mlp.1.kernel"], s[f"{n}.mlp.1.bias"])
+            P[f"{n}.mlp.0"] = self._with_h2(self._pack(s[f"{n}.mlp.0.kernel"], s[f"{n}.mlp.0.bias"]))
+            P[f"{n}.mlp.1"] = self._with_h2(self._pack(s[f"{n}.mlp.1.kernel"], s[f"{n}.mlp.1.bias"]))
             P[f"{n}.key"] = self._pack(s[f"{n}.key.kernel"], s[f"{n}.key.bias"])
         else:
             P[f"{n}.norm"] = self._fold_bn(f"{n}.norm")
-            P[f"{n}.proj"] = self._pack(s[f"{n}.proj.kernel"], s[f"{n}.proj.bias"])
+            P[f"{n}.proj"] = self._with_h2(self._pack(s[f"{n}.proj.kernel"], s[f"{n}.proj.bias"]))
         # query|key share one GEMM (rows 0..u-1 are the query weights and also serve the query-only call)
-        P[f"{n}.qk"] = self._pack(np.concatenate([s[f"{n}.query.kernel"], s[f"{n}.key.kernel"]], axis=1),
-                                  np.concatenate([s[f"{n}.query.bias"], s[f"{n}.key.bias"]]))
-        P[f"{n}.value"] = self._pack(s[f"{n}.value.kernel"], s[f"{n}.value.bias"])
+        P[f"{n}.qk"] = self._with_h2(self._pack(np.concatenate([s[f"{n}.query.kernel"], s[f"{n}.key.kernel"]], axis=1),
+                                                np.concatenate([s[f"{n}.query.bias"], s[f"{n}.key.bias"]])))
+        P[f"{n}.value"] = self._with_h2(self._pack(s[f"{n}.value.kernel"], s[f"{n}.value.bias"]))
 
     def _gemm_now(self, **kw):
         d = _gemm_desc(**kw)
         check(lib().dm3d_gemm_tn(C.byref(d), _stream()), "gemm")
+
+    def _attn_h2(self, u: int, L: int) -> bool:
+        """Attention blocks run on the H3 GEMM with DM3D_FMT_H2 intermediates when the 16-k record granularity fits."""
+        return self.precision == "h3" and u % 16 == 0 and L % 16 == 0
 
     def _prepare_context_tables(self):
         """ContextMLP + key/value projections for both context ids (conditional_dm3d.py:310-318, 168-169, 358):
@@ -221,6 +237,9 @@ class UNet:
             vctx_t = torch.empty(ids, u, L, dtype=torch.float32, device=self.device)
             self._gemm_now(a=val.wpk, lda=val.cin_pad, b=feat, ldb=u, stride_b=L * u, out=vctx_t, ldo=L, stride_o=u * L,
                            m=u, n=L, k=u, batch=ids, bias=val.bias, bias_along_m=1)
+            if self._attn_h2(u, L):
+                kctx = self._to_h2(kctx, ids * L, u).reshape(ids, L, u)
+                vctx_t = self._to_h2(vctx_t, ids * u, L).reshape(ids, u, L)
             self.ctx_tables[n] = (kctx, vctx_t)
             del w, feat
 
@@ -292,7 +311,8 @@ class UNet:
 
 
 def _gemm_desc(a, lda, b, ldb, out, ldo, m, n, k, batch=1, stride_a=0, stride_b=0, stride_o=0, alpha=1.0, bias=None,
-               bias_along_m=0, act=ACT_NONE, res=None, ldr=0, stride_r=0, a_off=0, b_off=0, out_off=0, res_off=0) -> GemmDesc:
+               bias_along_m=0, act=ACT_NONE, res=None, ldr=0, stride_r=0, a_off=0, b_off=0, out_off=0, res_off=0,
+               h3=False, a_h2=False, b_h2=False, out_h2=False) -> GemmDesc:
     d = GemmDesc()
     d.a, d.lda, d.stride_a = _ptr(a, a_off), lda, stride_a
     d.b, d.ldb, d.stride_b = _ptr(b, b_off), ldb, stride_b
@@ -301,6 +321,10 @@ def _gemm_desc(a, lda, b, ldb, out, ldo, m, n, k, batch=1, stride_a=0, stride_b=
     d.alpha = alpha
     d.bias, d.bias_along_m, d.act = _ptr(bias), bias_along_m, act
     d.res, d.ldr, d.stride_r = _ptr(res, res_off), ldr, stride_r
+    d.precision = _lib.PREC_H3 if h3 else _lib.PREC_F32
+    d.a_fmt = _lib.FMT_H2 if a_h2 else _lib.FMT_F32
+    d.b_fmt = _lib.FMT_H2 if b_h2 else _lib.FMT_F32
+    d.out_fmt = _lib.FMT_H2 if out_h2 else _lib.FMT_F32
     return d
 
 
@@ -359,8 +383,9 @@ class Plan:
     def _gemm(self, **kw):
         d = _gemm_desc(**kw)
         self._keep.append(d)
-        self.ops.append((lib().dm3d_gemm_tn, (C.byref(d),), "gemm",
-                         {"desc": f"gemm m={d.m} n={d.n} k={d.k} batch={d.batch}", "flops": 2.0 * d.m * d.n * d.k * d.batch}))
+        kind = "gemm_h3" if d.precision == _lib.PREC_H3 else "gemm"
+        self.ops.append((lib().dm3d_gemm_tn, (C.byref(d),), kind,
+                         {"desc": f"{kind} m={d.m} n={d.n} k={d.k} batch={d.batch}", "flops": 2.0 * d.m * d.n * d.k * d.batch}))
 
     # -- graph -----------------------------------------------------------------------------------------------------
     def _build(self):
@@ -408,56 +433,66 @@ class Plan:
         self._conv(P[f"{n}.conv2"], hmid, out, edge, pro=P[f"{n}.norm2"], res=res)
         return out
 
-    def _attn_core(self, q, q_ld, q_off, k, k_ld, k_off, k_stride, v_t, v_ld, v_off, v_stride, scores, res, out, L, u):
+    def _attn_core(self, q, q_ld, q_off, k, k_ld, k_off, k_stride, v_t, v_ld, v_off, v_stride, scores, res, out, L, u, h2):
         """softmax(q k^T * u^-0.5) v + res per sample (conditional_dm3d.py:171-180): two batched GEMMs around a
-        wavefront-shuffle row softmax."""
+        wavefront-shuffle row softmax.  h2: q, k, v_t arrive in DM3D_FMT_H2 and the probabilities are left in H2."""
         B = self.B
         self._gemm(a=q, a_off=q_off, lda=q_ld, stride_a=L * q_ld, b=k, b_off=k_off, ldb=k_ld, stride_b=k_stride,
-                   out=scores, ldo=L, stride_o=L * L, m=L, n=L, k=u, batch=B, alpha=float(u) ** -0.5)
-        self.ops.append((lib().dm3d_softmax_rows, (scores.data_ptr(), B * L, L, L), "softmax", {}))
+                   out=scores, ldo=L, stride_o=L * L, m=L, n=L, k=u, batch=B, alpha=float(u) ** -0.5, h3=h2, a_h2=h2, b_h2=h2)
+        fn = lib().dm3d_softmax_rows_h2 if h2 else lib().dm3d_softmax_rows
+        self.ops.append((fn, (scores.data_ptr(), B * L, L, L), "softmax", {}))
         self._gemm(a=scores, lda=L, stride_a=L * L, b=v_t, b_off=v_off, ldb=v_ld, stride_b=v_stride, out=out, ldo=u,
-                   stride_o=L * u, m=L, n=u, k=L, batch=B, res=res, ldr=u, stride_r=L * u)
+                   stride_o=L * u, m=L, n=u, k=L, batch=B, res=res, ldr=u, stride_r=L * u, h3=h2, a_h2=h2, b_h2=h2)
 
     def _cross_block(self, blk, x, edge):
-        """CrossAttentionBlock (conditional_dm3d.py:186-195)."""
+        """CrossAttentionBlock (conditional_dm3d.py:186-195).  With precision "h3" every intermediate that only feeds
+        Dense layers (LayerNorm outputs, q|k, v^T, probabilities, MLP hidden, a3) lives in DM3D_FMT_H2."""
         P, B, n, u = self.net.P, self.B, blk.name, blk.cout
         L = edge ** 3
         M = B * L
+        h2 = self.net._attn_h2(u, L)
+        W = (lambda w: w.h2) if h2 else (lambda w: w.wpk)
         pin, pout, qk, val = P[f"{n}.proj_in"], P[f"{n}.proj_out"], P[f"{n}.qk"], P[f"{n}.value"]
         m0, m1 = P[f"{n}.mlp.0"], P[f"{n}.mlp.1"]
-        y = self._buf(M, u)                                                   # relu(proj_in(BN(x)))
-        self._gemm(a=x, lda=u, b=pin.wpk, ldb=pin.cin_pad, out=y, ldo=u, m=M, n=u, k=u, bias=pin.bias, act=ACT_RELU)
+        y = self._buf(M, u)                                                   # relu(proj_in(BN(x))), float32
+        self._gemm(a=x, lda=u, b=W(pin), ldb=pin.cin_pad, out=y, ldo=u, m=M, n=u, k=u, bias=pin.bias, act=ACT_RELU,
+                   h3=h2, b_h2=h2)
         n1, n2, n3 = self._buf(M, u), self._buf(M, u), self._buf(M, u)
         (g1, b1), (g2, b2), (g3, b3) = P[f"{n}.ln1"], P[f"{n}.ln2"], P[f"{n}.ln3"]
         self._keep += [g1, b1, g2, b2, g3, b3]
-        self.ops.append((lib().dm3d_layernorm3, (y.data_ptr(), M, u, LN_EPS, g1.data_ptr(), b1.data_ptr(), n1.data_ptr(),
-                                                 g2.data_ptr(), b2.data_ptr(), n2.data_ptr(), g3.data_ptr(), b3.data_ptr(),
-                                                 n3.data_ptr()), "layernorm", {}))
+        ln = lib().dm3d_layernorm3_h2 if h2 else lib().dm3d_layernorm3
+        self.ops.append((ln, (y.data_ptr(), M, u, LN_EPS, g1.data_ptr(), b1.data_ptr(), n1.data_ptr(), g2.data_ptr(),
+                              b2.data_ptr(), n2.data_ptr(), g3.data_ptr(), b3.data_ptr(), n3.data_ptr()), "layernorm", {}))
         # self attention on norm1(y)
         qkb = self._buf(M, 2 * u)
-        self._gemm(a=n1, lda=u, b=qk.wpk, ldb=qk.cin_pad, out=qkb, ldo=2 * u, m=M, n=2 * u, k=u, bias=qk.bias)
+        self._gemm(a=n1, lda=u, b=W(qk), ldb=qk.cin_pad, out=qkb, ldo=2 * u, m=M, n=2 * u, k=u, bias=qk.bias,
+                   h3=h2, a_h2=h2, b_h2=h2, out_h2=h2)
         v_t = self._buf(u, M)                                                 # value projection, transposed
-        self._gemm(a=val.wpk, lda=val.cin_pad, b=n1, ldb=u, out=v_t, ldo=M, m=u, n=M, k=u, bias=val.bias, bias_along_m=1)
+        self._gemm(a=W(val), lda=val.cin_pad, b=n1, ldb=u, out=v_t, ldo=M, m=u, n=M, k=u, bias=val.bias, bias_along_m=1,
+                   h3=h2, a_h2=h2, b_h2=h2, out_h2=h2)
         scores = self._buf(B, L, L)
         a1 = self._buf(M, u)
-        self._attn_core(qkb, 2 * u, 0, qkb, 2 * u, u, L * 2 * u, v_t, M, 0, L, scores, y, a1, L, u)
+        self._attn_core(qkb, 2 * u, 0, qkb, 2 * u, u, L * 2 * u, v_t, M, 0, L, scores, y, a1, L, u, h2)
         # cross attention: queries from norm2(y), keys/values from the context (same key/value weights, :168-169)
         q2 = self._buf(M, u)
-        self._gemm(a=n2, lda=u, b=qk.wpk, ldb=qk.cin_pad, out=q2, ldo=u, m=M, n=u, k=u, bias=qk.bias)
+        self._gemm(a=n2, lda=u, b=W(qk), ldb=qk.cin_pad, out=q2, ldo=u, m=M, n=u, k=u, bias=qk.bias,
+                   h3=h2, a_h2=h2, b_h2=h2, out_h2=h2)
         rows = B if self.per_sample_context else 1
         kctx, vctx_t = self._buf(rows, L * u), self._buf(rows, u * L)
         self.ctx_bufs[n] = (kctx, vctx_t)
         a2 = self._buf(M, u)
         ks, vs = (L * u, u * L) if self.per_sample_context else (0, 0)
-        self._attn_core(q2, u, 0, kctx, u, 0, ks, vctx_t, L, 0, vs, scores, a1, a2, L, u)
+        self._attn_core(q2, u, 0, kctx, u, 0, ks, vctx_t, L, 0, vs, scores, a1, a2, L, u, h2)
         # MLP on norm3(y)
         hid = self._buf(M, 4 * u)
-        self._gemm(a=n3, lda=u, b=m0.wpk, ldb=m0.cin_pad, out=hid, ldo=4 * u, m=M, n=4 * u, k=u, bias=m0.bias, act=ACT_RELU)
+        self._gemm(a=n3, lda=u, b=W(m0), ldb=m0.cin_pad, out=hid, ldo=4 * u, m=M, n=4 * u, k=u, bias=m0.bias, act=ACT_RELU,
+                   h3=h2, a_h2=h2, b_h2=h2, out_h2=h2)
         a3 = self._buf(M, u)
-        self._gemm(a=hid, lda=4 * u, b=m1.wpk, ldb=m1.cin_pad, out=a3, ldo=u, m=M, n=u, k=4 * u, bias=m1.bias, res=a2, ldr=u)
+        self._gemm(a=hid, lda=4 * u, b=W(m1), ldb=m1.cin_pad, out=a3, ldo=u, m=M, n=u, k=4 * u, bias=m1.bias, res=a2, ldr=u,
+                   h3=h2, a_h2=h2, b_h2=h2, out_h2=h2)
         out = self._buf(B, edge, edge, edge, u)
-        self._gemm(a=a3, lda=u, b=pout.wpk, ldb=pout.cin_pad, out=out, ldo=u, m=M, n=u, k=u, bias=pout.bias, act=ACT_RELU,
-                   res=x, ldr=u)
+        self._gemm(a=a3, lda=u, b=W(pout), ldb=pout.cin_pad, out=out, ldo=u, m=M, n=u, k=u, bias=pout.bias, act=ACT_RELU,
+                   res=x, ldr=u, h3=h2, a_h2=h2, b_h2=h2)
         return out
 
     def _self_block(self, blk, x, edge):
@@ -465,20 +500,26 @@ class Plan:
         P, B, n, u = self.net.P, self.B, blk.name, blk.cout
         L = edge ** 3
         M = B * L
+        h2 = self.net._attn_h2(u, L)
+        W = (lambda w: w.h2) if h2 else (lambda w: w.wpk)
         qk, val, proj = P[f"{n}.qk"], P[f"{n}.value"], P[f"{n}.proj"]
         scale, shift = P[f"{n}.norm"]
         self._keep += [scale, shift]
-        xn = self._buf(M, u)
+        xn = self._buf(M, u)                                                  # float32: also the residual
         self.ops.append((lib().dm3d_affine_act, (x.data_ptr(), xn.data_ptr(), M, u, scale.data_ptr(), shift.data_ptr(),
                                                  ACT_NONE), "affine", {}))
         qkb = self._buf(M, 2 * u)
-        self._gemm(a=xn, lda=u, b=qk.wpk, ldb=qk.cin_pad, out=qkb, ldo=2 * u, m=M, n=2 * u, k=u, bias=qk.bias)
+        self._gemm(a=xn, lda=u, b=W(qk), ldb=qk.cin_pad, out=qkb, ldo=2 * u, m=M, n=2 * u, k=u, bias=qk.bias,
+                   h3=h2, b_h2=h2, out_h2=h2)
         v_t = self._buf(u, M)
-        self._gemm(a=val.wpk, lda=val.cin_pad, b=xn, ldb=u, out=v_t, ldo=M, m=u, n=M, k=u, bias=val.bias, bias_along_m=1)
+        self._gemm(a=W(val), lda=val.cin_pad, b=xn, ldb=u, out=v_t, ldo=M, m=u, n=M, k=u, bias=val.bias, bias_along_m=1,
+                   h3=h2, a_h2=h2, out_h2=h2)
         scores, o = self._buf(B, L, L), self._buf(M, u)
-        self._attn_core(qkb, 2 * u, 0, qkb, 2 * u, u, L * 2 * u, v_t, M, 0, L, scores, None, o, L, u)
+        self._attn_core(qkb, 2 * u, 0, qkb, 2 * u, u, L * 2 * u, v_t, M, 0, L, scores, None, o, L, u, h2)
         out = self._buf(B, edge, edge, edge, u)
-        self._gemm(a=o, lda=u, b=proj.wpk, ldb=proj.cin_pad, out=out, ldo=u, m=M, n=u, k=u, bias=proj.bias, res=xn, ldr=u)
+        # o is float32 here (the P.V GEMM writes float32); the projection splits it while staging
+        self._gemm(a=o, lda=u, b=W(proj), ldb=proj.cin_pad, out=out, ldo=u, m=M, n=u, k=u, bias=proj.bias, res=xn, ldr=u,
+                   h3=h2, b_h2=h2)
         return out
 
     # -- run ---------------------------------------------------------------------------------------------------------

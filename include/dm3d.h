@@ -42,6 +42,14 @@ extern "C" {
 #define DM3D_PREC_F32 0
 #define DM3D_PREC_H3  1
 
+/* storage formats of a [rows][k] matrix (same 4 bytes per element, leading dimensions always counted in elements):
+ *   F32: row-major float32.
+ *   H2 : the float16 hi/lo split of DM3D_PREC_H3 made once by the producer instead of by every consumer: each run of 16
+ *        consecutive k of a row is one 64-byte record [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15] — exactly the LDS record
+ *        of the H3 kernels, so their staging degenerates to 16-byte copies.  ld % 16 == 0. */
+#define DM3D_FMT_F32 0
+#define DM3D_FMT_H2  1
+
 /* padded extents of packed weights */
 #define DM3D_COUT_PAD 64
 #define DM3D_CIN_PAD  16
@@ -117,9 +125,17 @@ typedef struct dm3d_gemm_desc {
     int32_t bias_along_m;
     int32_t act;                /* DM3D_ACT_* applied after bias */
     const float* res; int64_t ldr; int64_t stride_r;   /* added after act, or NULL */
+    int32_t precision;          /* DM3D_PREC_F32 (all formats must be DM3D_FMT_F32) or DM3D_PREC_H3 */
+    int32_t a_fmt, b_fmt;       /* H3: DM3D_FMT_F32 (split while staging) or DM3D_FMT_H2 (pre-split); k % 16 == 0 */
+    int32_t out_fmt;            /* H3: DM3D_FMT_F32 or DM3D_FMT_H2 (n % 16 == 0, ldo % 16 == 0); res is always float32 */
 } dm3d_gemm_desc;
 
 int dm3d_gemm_tn(const dm3d_gemm_desc* d, void* stream);
+
+/* dst(H2) = split(src * 2^exp2): one-time conversion of static operands (weights, context keys/values). k % 16 == 0 is
+ * not required of src: columns k..round_up(k,16) of dst are zero filled; ld_dst % 16 == 0, ld_dst >= round_up(k,16). */
+int dm3d_split_h2(const float* src, int64_t rows, int32_t k, int64_t ld_src, int32_t exp2, void* dst, int64_t ld_dst,
+                  void* stream);
 
 /* ---- LayerNormalization (eps passed; Keras default 1e-3) ------------------------------------------------------
  * CrossAttentionBlock normalises the same tensor three times (norm1/2/3, :191-193): one pass computes the row
@@ -128,9 +144,16 @@ int dm3d_layernorm3(const float* x, int64_t rows, int32_t c, float eps,
                     const float* g1, const float* b1, float* o1,
                     const float* g2, const float* b2, float* o2,
                     const float* g3, const float* b3, float* o3, void* stream);
+/* same with the outputs written in DM3D_FMT_H2 (c % 16 == 0): they only feed Dense layers */
+int dm3d_layernorm3_h2(const float* x, int64_t rows, int32_t c, float eps,
+                       const float* g1, const float* b1, void* o1,
+                       const float* g2, const float* b2, void* o2,
+                       const float* g3, const float* b3, void* o3, void* stream);
 
 /* ---- tf.nn.softmax(scores, -1) in place, one wavefront per row (shuffle reductions) (:178; U:56) ------------ */
 int dm3d_softmax_rows(float* s, int64_t rows, int32_t cols, int64_t ld, void* stream);
+/* same, result left in place in DM3D_FMT_H2 (cols % 16 == 0, ld % 16 == 0, cols <= 1024): it only feeds the P.V contraction */
+int dm3d_softmax_rows_h2(float* s, int64_t rows, int32_t cols, int64_t ld, void* stream);
 
 /* ---- y = act(x*scale[c] + shift[c]) over the last axis (inference BatchNormalization of AttentionBlock, U:45;
  * swish of the time embedding, :250); scale/shift may be NULL (identity). */

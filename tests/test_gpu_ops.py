@@ -178,6 +178,87 @@ def test_gemm_tn(dev, case):
     assert err < 2e-5, f"{name}: rel err {err:.3e}"
 
 
+H3_GEMM_CASES = [
+    ("h2h2_plain", dict(m=256, n=64, k=32)),
+    ("h2h2_guards_ktail", dict(m=300, n=80, k=48, bias=True, act=1, res=True)),
+    ("f32h2", dict(m=130, n=96, k=64, a_f32=True, bias=True)),
+    ("h2f32_bias_m", dict(m=96, n=144, k=256, b_f32=True, bias=True, bias_m=True)),
+    ("f32f32_long_k", dict(m=64, n=64, k=1024, a_f32=True, b_f32=True)),
+    ("batched_alpha", dict(m=512, n=512, k=256, batch=3, alpha=0.0625)),
+    ("batched_bcast_res", dict(m=64, n=48, k=64, batch=4, bcast_b=True, res=True)),
+    ("out_h2", dict(m=300, n=96, k=64, out_h2=True, bias=True, act=1)),
+    ("out_h2_res_silu", dict(m=256, n=64, k=128, out_h2=True, res=True, act=2, a_f32=True)),
+]
+
+
+@pytest.mark.parametrize("case", H3_GEMM_CASES, ids=[c[0] for c in H3_GEMM_CASES])
+def test_gemm_tn_h3(dev, case):
+    """Split-float16 GEMM with every operand/output format combination, against float64."""
+    from dm3d_amd import ops, _lib
+    name, kw = case
+    m, n, k, batch = kw["m"], kw["n"], kw["k"], kw.get("batch", 1)
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    a = torch.randn(batch, m, k, generator=g)
+    b = torch.randn(1 if kw.get("bcast_b") else batch, n, k, generator=g)
+    bias = torch.randn(m if kw.get("bias_m") else n, generator=g) if kw.get("bias") else None
+    res = torch.randn(batch, m, n, generator=g) if kw.get("res") else None
+    alpha = kw.get("alpha", 1.0)
+    ref = torch.einsum("bmk,bnk->bmn", a.double(), b.double().expand(batch, n, k)) * alpha
+    if bias is not None:
+        ref = ref + (bias.double()[None, :, None] if kw.get("bias_m") else bias.double())
+    act = kw.get("act", 0)
+    ref = torch.relu(ref) if act == 1 else (ref * torch.sigmoid(ref) if act == 2 else ref)
+    if res is not None:
+        ref = ref + res.double()
+    c = lambda t: None if t is None else t.to(dev).contiguous()
+    ad, bd = c(a), c(b)
+    a_fmt = b_fmt = _lib.FMT_H2
+    if kw.get("a_f32"):
+        a_fmt = _lib.FMT_F32
+    else:
+        ad = ops.split_h2(ad.reshape(-1, k)).reshape(batch, m, k)
+    if kw.get("b_f32"):
+        b_fmt = _lib.FMT_F32
+    else:
+        bd = ops.split_h2(bd.reshape(-1, k)).reshape(bd.shape[0], n, k)
+    out = ops.gemm_tn(ad, bd, m=m, n=n, k=k, batch=batch, stride_a=m * k, stride_b=0 if kw.get("bcast_b") else n * k,
+                      alpha=alpha, bias=c(bias), bias_along_m=bool(kw.get("bias_m")), act=act, res=c(res),
+                      out=torch.empty(batch, m, n, device=dev), precision=_lib.PREC_H3, a_fmt=a_fmt, b_fmt=b_fmt,
+                      out_fmt=_lib.FMT_H2 if kw.get("out_h2") else _lib.FMT_F32)
+    torch.cuda.synchronize()
+    if kw.get("out_h2"):
+        out = ops.h2_to_f32(out.reshape(batch * m, n), n).reshape(batch, m, n)
+    err = _rel(out, ref)
+    print(f"gemm_h3 {name}: rel err {err:.2e}")
+    assert err < 2e-5, f"{name}: rel err {err:.3e}"
+
+
+def test_h2_format_roundtrip_and_norm_kernels(dev):
+    from dm3d_amd import ops
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(37, 40, generator=g) * 3
+    h2 = ops.split_h2(x.to(dev))
+    assert tuple(h2.shape) == (37, 48)
+    assert _rel(ops.h2_to_f32(h2, 40), x) < 1e-6
+    assert float(ops.h2_to_f32(h2, 48)[:, 40:].abs().max()) == 0.0           # zero padded to the record
+    assert _rel(ops.h2_to_f32(ops.split_h2(x.to(dev), exp2=5), 40), x * 32) < 1e-6
+    # LayerNorm with H2 outputs == float32 LayerNorm
+    for rows, c in ((33, 256), (5, 48), (3, 1024)):
+        y = torch.randn(rows, c, generator=g) * 2 + 0.3
+        params = [(torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)) for _ in range(3)]
+        pd = [(a.to(dev), b.to(dev)) for a, b in params]
+        outs = ops.layernorm3_h2(y.to(dev), pd, eps=1e-3)
+        for (ga, be), o in zip(params, outs):
+            ref = torch.nn.functional.layer_norm(y.double(), (c,), ga.double(), be.double(), 1e-3)
+            assert _rel(ops.h2_to_f32(o, c), ref) < 3e-6
+    # softmax left in place in H2
+    for rows, cols in ((9, 512), (130, 64), (2, 1024), (5, 16)):
+        sc = torch.randn(rows, cols, generator=g) * 4
+        out = ops.softmax_rows_h2_(sc.to(dev).clone())
+        torch.cuda.synchronize()
+        assert float((ops.h2_to_f32(out, cols).double().cpu() - torch.softmax(sc.double(), -1)).abs().max()) < 2e-6
+
+
 def test_gemm_strided_views(dev):
     """q|k packed in one [M, 2u] buffer, scores = q k^T per sample (the layout the attention blocks use)."""
     from dm3d_amd import ops
