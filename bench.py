@@ -75,19 +75,27 @@ def main():
     if world != args.gpus:
         if args.gpus != 1 and world == 1:
             raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} processes (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # DM3D_BENCH_REHEARSAL=1: several ranks share GPU 0 and talk over gloo — only to rehearse the multi-process logic
+    # on a one-GPU box (RCCL refuses two ranks on one device); the driver's real runs use one GPU per rank over RCCL.
+    rehearsal = os.environ.get("DM3D_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     _lib.require_device()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    comm_dev = torch.device("cpu") if rehearsal else dev
 
     B, S, Cc = args.batch, args.size, args.channels
     log(f"rank {rank}/{world}: building weights and model (B={B}, {S}^3x{Cc})")
     cfg = dm3d_amd.UNetConfig(img_size=S, img_channels=Cc)
     spec = dm3d_amd.param_spec(cfg)
     W = dm3d_amd.synthetic_weights(cfg, seed=0) if rank == 0 else None
-    W = parallel.broadcast_state(W, spec, src=0, device=dev)              # RCCL broadcast over xGMI (no-op at N=1)
+    W = parallel.broadcast_state(W, spec, src=0, device=comm_dev)              # RCCL broadcast over xGMI (no-op at N=1)
     margs = SimpleNamespace(timesteps=T_FULL, num_gpus=world, kernel_resize=False, bs=B * world)
     model = cdm.DiffusionModel(S, 1024, Cc, None, margs, device=dev, weights=W, precision=args.precision)
     smp = model.sampler((B, S, S, S, Cc), context_value=1, seed=parallel.rank_seed(1234, rank),
@@ -112,7 +120,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, comm_dev)
     s_per_step = elapsed / K
     log(f"timed {K} steps: {s_per_step * 1e3:.2f} ms/step")
     value = world * B / (T_FULL * s_per_step)
@@ -154,6 +162,20 @@ def main():
                     "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
                     "algorithmic_mb_per_launch": round(by / n / 1e6, 2)}
 
+    # HBM traffic of the dominant kernel: PMC counters need their own rocprofv3 passes (MI355X_MICROARCH.md), so the figure
+    # comes from the committed summary of those passes over this same command (profiles/summarize_pmc.py), not from this run
+    if roofline is not None:
+        try:
+            import csv
+            path = os.path.join(ROOT, "profiles", "r01_h3_pmc_hbm.csv" if args.precision == "h3" else "r01_fp32_pmc_hbm.csv")
+            want = "conv3d_igemm_h3<4, 8, 8, 1, 3, 4, 1, 2>" if args.precision == "h3" else "conv3d_igemm_f32<4, 8, 8, 1, 3, 4, 1>"
+            for row in csv.reader(l for l in open(path) if not l.startswith("#")):
+                if row and row[0] == want:
+                    roofline["traffic"] = float(row[4]) * 1e6
+                    roofline["traffic_unit"] = "bytes/launch (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc, " + os.path.basename(path) + ")"
+        except Exception:
+            pass
+
     # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only) ----------------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -192,7 +214,7 @@ def main():
                                    f"(U-Net eps + posterior update + Philox noise, HIP-graph replay); "
                                    f"value = n_gpus*B/(T*s_per_step)",
                        "batch_per_gpu": B, "global_batch": B * world, "timesteps": T_FULL,
-                       "weights": "seeded synthetic (seed 0), rank-0 broadcast", "parallelism": f"batch-shard x{world}"},
+                       "weights": "seeded synthetic (seed 0), rank-0 broadcast", "parallelism": f"batch-shard x{world}" + (" (REHEARSAL: ranks share one GPU, gloo)" if rehearsal else "")},
             "roofline": roofline, "cpu_baseline": cpu, "per_kernel_kind": per_kind,
             "conv_mfma_util_pct": None if roofline is None else round(100 * roofline["executed_mfma_frac_of_peak"], 2),
             "precision": args.precision,
