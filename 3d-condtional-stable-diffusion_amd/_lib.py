@@ -62,6 +62,10 @@ SIGNATURES = {
     "dm3d_pack_weights": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, _f32p, _f32p, C.c_void_p]),
     "dm3d_packed_weight_h3_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "dm3d_pack_weights_h3": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p, C.c_void_p, C.c_void_p]),
+    "dm3d_packed_weight_up_elems": (C.c_int64, [C.c_int32, C.c_int32]),
+    "dm3d_pack_weights_up": (C.c_int, [_f32p, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
+    "dm3d_packed_weight_up_h3_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
+    "dm3d_pack_weights_up_h3": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "dm3d_conv3d_ndhwc": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "dm3d_gemm_tn": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "dm3d_split_h2": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -73,3 +73,23 @@ __device__ __forceinline__ void dm3d_mma_step(f32x16 (&acc)[MR][NR], const float
 
 // C/D layout of the 32x32 MFMA: register r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
 __device__ __forceinline__ int dm3d_acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// Weight of tap2 = (td,th,tw) in {0,1}^3 of the 2x2x2 conv that reproduces, for output parity par = (a,b,c), a 3x3x3 conv on
+// the nearest-2x upsampled tensor (reference UpSample, conditional_dm3d.py:288-296): along each axis the three taps of the
+// k3 kernel read source voxels {i-1, i, i} (parity 0) or {i, i, i+1} (parity 1), so the taps sharing a source are summed.
+__device__ __forceinline__ float dm3d_up_weight(const float* __restrict__ w, int cin, int cout, int par, int tap2, int ci, int co) {
+    float acc = 0.f;
+    const int pa[3] = {par >> 2, (par >> 1) & 1, par & 1};
+    const int tt[3] = {tap2 >> 2, (tap2 >> 1) & 1, tap2 & 1};
+    int lo[3], hi[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        if (pa[ax] == 0) { lo[ax] = tt[ax] == 0 ? 0 : 1; hi[ax] = tt[ax] == 0 ? 0 : 2; }
+        else             { lo[ax] = tt[ax] == 0 ? 0 : 2; hi[ax] = tt[ax] == 0 ? 1 : 2; }
+    }
+    for (int kd = lo[0]; kd <= hi[0]; ++kd)
+        for (int kh = lo[1]; kh <= hi[1]; ++kh)
+            for (int kw = lo[2]; kw <= hi[2]; ++kw)
+                acc += w[((long)((kd * 3 + kh) * 3 + kw) * cin + ci) * cout + co];
+    return acc;
+}

@@ -49,6 +49,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_f32(const ConvArgs p) {
     const int oy0 = ((brick / p.bw) % p.bh) * TH;
     const int ox0 = (brick % p.bw) * TW;
     const int n0 = blockIdx.y * NT;
+    int padz = p.padz, pady = p.pady, padx = p.padx, ooz = p.ooz, ooy = p.ooy, oox = p.oox;
+    const float* wbase = static_cast<const float*>(p.wpk);
+    if (p.parity) {                             // uniform: one output parity of upsample(2) + conv k3 per grid.z slice
+        const int par = blockIdx.z;
+        ooz = par >> 2; ooy = (par >> 1) & 1; oox = par & 1;
+        padz = 1 - ooz; pady = 1 - ooy; padx = 1 - oox;
+        wbase += (size_t)par * p.w_parity_stride;
+    }
 
     // staging slots: this thread copies float4 piece `piece` of halo voxels hv0 + j*64
     const int piece = tid & 3;
@@ -59,11 +67,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_f32(const ConvArgs p) {
         int g = -1;
         if (hv < HVOX) {
             const int hz = hv / (HH * HW), hy = (hv / HW) % HH, hx = hv % HW;
-            const int iz = oz0 * S - p.pad + hz, iy = oy0 * S - p.pad + hy, ix = ox0 * S - p.pad + hx;
-            if (iz >= 0 && iz < p.lgd && iy >= 0 && iy < p.lgh && ix >= 0 && ix < p.lgw) {
-                const int pz = p.ups ? (iz >> 1) : iz, py = p.ups ? (iy >> 1) : iy, px = p.ups ? (ix >> 1) : ix;
-                g = ((b * p.ind + pz) * p.inh + py) * p.inw + px;
-            }
+            const int iz = oz0 * S - padz + hz, iy = oy0 * S - pady + hy, ix = ox0 * S - padx + hx;
+            if (iz >= 0 && iz < p.ind && iy >= 0 && iy < p.inh && ix >= 0 && ix < p.inw)
+                g = ((b * p.ind + iz) * p.inh + iy) * p.inw + ix;
         }
         gvox[j] = g;
     }
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_f32(const ConvArgs p) {
             for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.0f;
 
     // weight slice (tap, chunk): row n = tid>>2 of 64, float4 piece tid&3 of the 16 input channels
-    const float* w_thread = static_cast<const float*>(p.wpk) + (size_t)(n0 + (tid >> 2)) * p.cinpad + piece * 4;
+    const float* w_thread = wbase + (size_t)(n0 + (tid >> 2)) * p.cinpad + piece * 4;
     const size_t w_tap_stride = (size_t)p.coutpad * p.cinpad;
     const int w_lds_off = (tid >> 2) * LDV + piece * 4;
     f32x4 wreg = *reinterpret_cast<const f32x4*>(w_thread);      // (tap 0, chunk 0)
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_f32(const ConvArgs p) {
                 const int row = wm * (TM / WM) + mr * 32 + dm3d_acc_row(r, half);
                 const int oz = oz0 + row / (TH * TW), oy = oy0 + (row / TW) % TH, ox = ox0 + row % TW;
                 ok[r] = n_ok && oz < p.od && oy < p.oh && ox < p.ow;
-                o[r] = ok[r] ? ((((size_t)b * p.od + oz) * p.oh + oy) * p.ow + ox) * p.cout + n : 0;
+                o[r] = ok[r] ? ((((size_t)b * p.fd + oz * p.os + ooz) * p.fh + oy * p.os + ooy) * p.fw + ox * p.os + oox) * p.cout + n : 0;
             }
             if (p.res) {
 #pragma unroll
@@ -211,7 +217,7 @@ int launch_conv(ConvArgs& a, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64));
+    dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64), a.parity ? 8u : 1u);
     hipLaunchKernelGGL((conv3d_igemm_f32<TD, TH, TW, S, KS, WM, WN>), grid, dim3(256), lds, st, a);
     return dm3d_launch_check("conv3d_igemm_f32");
 }
@@ -233,24 +239,26 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
     DM3D_REQUIRE(!d->vec || d->vec_ld >= d->cout, "conv: vec_ld %d < cout %d", d->vec_ld, d->cout);
     const void* ptrs[] = {d->x1, d->x2, d->wpk, d->pro_scale, d->pro_shift, d->out, d->res};
     for (const void* q : ptrs) DM3D_REQUIRE(dm3d_aligned16(q), "conv: pointer %p is not 16-byte aligned", q);
-    const int64_t vox = (int64_t)d->batch * d->in_d * d->in_h * d->in_w * (d->upsample ? 8 : 1);
+    const int64_t vox = (int64_t)d->batch * d->in_d * d->in_h * d->in_w;
     DM3D_REQUIRE(vox < (1ll << 31) / 4, "conv: %lld voxels overflow the 32-bit voxel index", (long long)vox);
 
     ConvArgs a{};
     a.x1 = d->x1; a.x2 = d->x2; a.c1 = d->c1; a.c2 = d->c2;
     a.ind = d->in_d; a.inh = d->in_h; a.inw = d->in_w;
-    const int up = d->upsample ? 2 : 1;
-    a.lgd = d->in_d * up; a.lgh = d->in_h * up; a.lgw = d->in_w * up;
-    a.od = (a.lgd + d->stride - 1) / d->stride;
-    a.oh = (a.lgh + d->stride - 1) / d->stride;
-    a.ow = (a.lgw + d->stride - 1) / d->stride;
-    a.ups = d->upsample ? 1 : 0;
-    // TF SAME: total = max((out-1)*stride + k - in, 0), zeros in front = total/2.  For k=3: stride 1 -> 1; stride 2 -> 0 on
-    // even sizes and 1 on odd sizes.  The kernel uses one pad for all three axes, so mixed parity is rejected.
+    // Logical output domain the bricks tile.  upsample: the k3 conv on the nearest-2x upsampled tensor is evaluated as 8
+    // 2x2x2 convs (one per output parity) on the low-resolution input, so the domain is the input extent and results are
+    // scattered with stride 2 into the full output.
+    a.lgd = d->in_d; a.lgh = d->in_h; a.lgw = d->in_w;
+    a.od = (d->in_d + d->stride - 1) / d->stride;
+    a.oh = (d->in_h + d->stride - 1) / d->stride;
+    a.ow = (d->in_w + d->stride - 1) / d->stride;
+    a.parity = d->upsample ? 1 : 0;
+    a.os = d->upsample ? 2 : 1;
+    a.fd = a.od * a.os; a.fh = a.oh * a.os; a.fw = a.ow * a.os;
+    // TF SAME: total = max((out-1)*stride + k - in, 0), zeros in front = total/2 (k=3: stride 1 -> 1; stride 2 -> 0 on even
+    // sizes, 1 on odd sizes).  In parity mode the kernel derives the pads from the parity bits.
     auto pad_front = [&](int in, int out) { int t = (out - 1) * d->stride + d->ksize - in; return t > 0 ? t / 2 : 0; };
-    a.pad = pad_front(a.lgd, a.od);
-    DM3D_REQUIRE(pad_front(a.lgh, a.oh) == a.pad && pad_front(a.lgw, a.ow) == a.pad,
-                 "conv: stride-2 SAME padding differs between axes (mixed odd/even extents)");
+    a.padz = pad_front(a.lgd, a.od); a.pady = pad_front(a.lgh, a.oh); a.padx = pad_front(a.lgw, a.ow);
     const int cin = d->c1 + d->c2;
     a.cinpad = (int)dm3d_round_up(cin, DM3D_CIN_PAD);
     a.coutpad = (int)dm3d_round_up(d->cout, DM3D_COUT_PAD);
@@ -263,11 +271,14 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
     DM3D_REQUIRE(d->w_exp >= -100 && d->w_exp <= 100, "conv: w_exp %d out of range", d->w_exp);
     a.out_scale = d->precision == DM3D_PREC_H3 ? ldexpf(1.0f, -d->w_exp) : 1.0f;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int which = d->ksize == 1 ? DM3D_CONV_K1 : (d->stride == 2 ? DM3D_CONV_K3S2 : DM3D_CONV_K3S1);
+    const int which = d->upsample ? DM3D_CONV_UP : (d->ksize == 1 ? DM3D_CONV_K1 : (d->stride == 2 ? DM3D_CONV_K3S2 : DM3D_CONV_K3S1));
+    if (d->upsample) a.w_parity_stride = d->precision == DM3D_PREC_H3
+        ? dm3d_packed_weight_h3_bytes(8, cin, d->cout) / 2 : dm3d_packed_weight_elems(8, cin, d->cout);
     return d->precision == DM3D_PREC_H3 ? dm3d_conv_launch_h3(a, which, st) : dm3d_conv_launch_f32(a, which, st);
 }
 
 int dm3d_conv_launch_f32(ConvArgs& a, int which, hipStream_t st) {
+    if (which == DM3D_CONV_UP) return launch_conv<4, 8, 8, 1, 2, 4, 1>(a, st);
     if (which == DM3D_CONV_K1) return launch_conv<4, 8, 8, 1, 1, 4, 1>(a, st);
     if (which == DM3D_CONV_K3S2) return launch_conv<2, 4, 8, 2, 3, 2, 2>(a, st);
     return launch_conv<4, 8, 8, 1, 3, 4, 1>(a, st);

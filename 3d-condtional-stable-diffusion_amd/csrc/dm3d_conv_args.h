@@ -7,7 +7,13 @@ struct ConvArgs {
     int ind, inh, inw;        // physical input extent
     int lgd, lgh, lgw;        // logical extent seen by the conv (2x when upsampling)
     int od, oh, ow;
-    int ups, pad;             // pad = zero voxels in front of index 0 (TF SAME)
+    int padz, pady, padx;     // zero voxels in front of index 0 per axis (TF SAME; parity mode: 1 - parity bit)
+    int os;                   // output stride in the full output tensor (2 in parity mode, else 1)
+    int ooz, ooy, oox;        // output offset in the full output tensor (the parity bits)
+    int fd, fh, fw;           // extent of the full output tensor (od*os ...)
+    int parity;               // 1: blockIdx.z enumerates the 8 output parities of a nearest-2x upsample + k3 conv, each a
+                              //    2x2x2 conv on the low-resolution input with pre-summed weights
+    long w_parity_stride;     // elements (fp32) / halfs (h3) between the packed weight images of two parities
     const void* wpk; int cinpad, coutpad;
     const float* bias; const float* pscale; const float* pshift;
     const float* vec; const int* vec_idx; int vec_ld;
@@ -19,7 +25,7 @@ struct ConvArgs {
 };
 
 // which tile configuration a (ksize, stride) pair uses
-enum { DM3D_CONV_K3S1 = 0, DM3D_CONV_K3S2 = 1, DM3D_CONV_K1 = 2 };
+enum { DM3D_CONV_K3S1 = 0, DM3D_CONV_K3S2 = 1, DM3D_CONV_K1 = 2, DM3D_CONV_UP = 3 };
 
 int dm3d_conv_launch_f32(ConvArgs& a, int which, hipStream_t st);
 int dm3d_conv_launch_h3(ConvArgs& a, int which, hipStream_t st);

@@ -47,8 +47,8 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
     constexpr int HD = (TD - 1) * S + KS, HH = (TH - 1) * S + KS, HW = (TW - 1) * S + KS;
     constexpr int HVOX = HD * HH * HW;                      // real halo voxels (staged)
     constexpr bool CF = (S == 1 && TH % 4 == 0 && TW == 8); // conflict-free layout available
-    constexpr int HWP = (CF && KS == 3) ? 12 : HW;          // padded row stride of the LDS image
-    constexpr int PAIR = CF ? (KS == 3 ? 2 : 1) : 0;
+    constexpr int HWP = (CF && KS >= 2) ? 12 : HW;          // padded row stride of the LDS image
+    constexpr int PAIR = CF ? (KS >= 2 ? 2 : 1) : 0;
     constexpr int HREC = HD * HH * HWP;                     // records in the LDS image
     constexpr int MRSTEP = 4 * S * HWP;                     // records between consecutive 32-row tiles of a wave (4 y rows)
     static_assert(TM / WM <= 32 || MRSTEP % 16 == 0, "row tiles of a wave must share the swizzle term");
@@ -83,6 +83,14 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
     const int oy0 = ((brick / p.bw) % p.bh) * TH;
     const int ox0 = (brick % p.bw) * TW;
     const int ntile = blockIdx.y;
+    int padz = p.padz, pady = p.pady, padx = p.padx, ooz = p.ooz, ooy = p.ooy, oox = p.oox;
+    const _Float16* wbase = static_cast<const _Float16*>(p.wpk);
+    if (p.parity) {                             // uniform: one output parity of upsample(2) + conv k3 per grid.z slice
+        const int par = blockIdx.z;
+        ooz = par >> 2; ooy = (par >> 1) & 1; oox = par & 1;
+        padz = 1 - ooz; pady = 1 - ooy; padx = 1 - oox;
+        wbase += (size_t)par * p.w_parity_stride;
+    }
 
     // staging slots: this thread converts channels [8*piece, 8*piece+8) of halo voxels (tid>>1) + j*128
     const int piece = tid & 1;
@@ -93,11 +101,9 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
         int g = -1;
         if (hv < HVOX) {
             const int hz = hv / (HH * HW), hy = (hv / HW) % HH, hx = hv % HW;
-            const int iz = oz0 * S - p.pad + hz, iy = oy0 * S - p.pad + hy, ix = ox0 * S - p.pad + hx;
-            if (iz >= 0 && iz < p.lgd && iy >= 0 && iy < p.lgh && ix >= 0 && ix < p.lgw) {
-                const int pz = p.ups ? (iz >> 1) : iz, py = p.ups ? (iy >> 1) : iy, px = p.ups ? (ix >> 1) : ix;
-                g = ((b * p.ind + pz) * p.inh + py) * p.inw + px;
-            }
+            const int iz = oz0 * S - padz + hz, iy = oy0 * S - pady + hy, ix = ox0 * S - padx + hx;
+            if (iz >= 0 && iz < p.ind && iy >= 0 && iy < p.inh && ix >= 0 && ix < p.inw)
+                g = ((b * p.ind + iz) * p.inh + iy) * p.inw + ix;
         }
         gvox[j] = g;
     }
@@ -140,8 +146,7 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
             for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.0f;
 
     // weight image: [ntile][chunk][group][G][NT][REC] halfs; a group is a dense run of WPIECES 16-byte pieces
-    const f32x4* w_img = reinterpret_cast<const f32x4*>(static_cast<const _Float16*>(p.wpk) +
-                                                        (size_t)ntile * p.nchunks * NG * WGRP);
+    const f32x4* w_img = reinterpret_cast<const f32x4*>(wbase + (size_t)ntile * p.nchunks * NG * WGRP);
     f32x4 wreg[WSLOT];
     auto fetch_w = [&](int group_index) {
         const f32x4* src = w_img + (size_t)group_index * WPIECES;
@@ -273,12 +278,13 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
     const int vrow = p.vec ? (p.vec_idx ? p.vec_idx[b] : b) : 0;
     const int n0 = ntile * NT;
     const bool full = oz0 + TD <= p.od && oy0 + TH <= p.oh && ox0 + TW <= p.ow && n0 + NT <= p.cout;
+    const int cstep = p.os * p.cout;                            // distance between x-neighbours of the brick in the output
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
         const int r0 = wm * (TM / WM) + mr * 32;
         const int oz = oz0 + r0 / (TH * TW), oyb = oy0 + (r0 / TW) % TH;
         const bool z_ok = oz < p.od;
-        const size_t zbase = (((size_t)b * p.od + (z_ok ? oz : 0)) * p.oh) * p.ow * p.cout;
+        const size_t zbase = (((size_t)b * p.fd + (z_ok ? oz * p.os + ooz : 0)) * p.fh) * p.fw * p.cout;
         float* outz = p.out + zbase;
         const float* resz = p.res ? p.res + zbase : nullptr;
         int rowoff[4], oyq[4], oxq[4];
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
             row_to_yx<PAIR>(8 * q + 4 * half, dy, dx);
             oyq[q] = oyb + dy;
             oxq[q] = ox0 + dx;
-            rowoff[q] = (oyq[q] * p.ow + oxq[q]) * p.cout;
+            rowoff[q] = ((oyq[q] * p.os + ooy) * p.fw + oxq[q] * p.os + oox) * p.cout;
         }
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) {
@@ -301,21 +307,21 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
                 float rv[16];
                 if (resz) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) rv[r] = resz[rowoff[r >> 2] + (r & 3) * p.cout + n];
+                    for (int r = 0; r < 16; ++r) rv[r] = resz[rowoff[r >> 2] + (r & 3) * cstep + n];
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = fmaf(acc[mr][nr][r], p.out_scale, add);
                     if (p.relu) v = fmaxf(v, 0.0f);
                     if (resz) v += rv[r];
-                    outz[rowoff[r >> 2] + (r & 3) * p.cout + n] = v;
+                    outz[rowoff[r >> 2] + (r & 3) * cstep + n] = v;
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int q = r >> 2, c = r & 3;
                     const bool ok = n_ok && z_ok && oyq[q] < p.oh && oxq[q] + c < p.ow;
-                    const int o = ok ? rowoff[q] + c * p.cout + n : 0;
+                    const int o = ok ? rowoff[q] + c * cstep + n : 0;
                     float v = fmaf(acc[mr][nr][r], p.out_scale, add);
                     if (p.relu) v = fmaxf(v, 0.0f);
                     if (resz) v += resz[o];
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
 template <int TD, int TH, int TW, int S, int KS, int WM, int WN, int MINW>
 int launch_h3(ConvArgs& a, hipStream_t st) {
     constexpr int HW = (TW - 1) * S + KS;
-    constexpr int HWP = (S == 1 && TH % 4 == 0 && TW == 8 && KS == 3) ? 12 : HW;
+    constexpr int HWP = (S == 1 && TH % 4 == 0 && TW == 8 && KS >= 2) ? 12 : HW;
     constexpr int HREC = ((TD - 1) * S + KS) * ((TH - 1) * S + KS) * HWP;
     constexpr size_t lds = (size_t)(HREC * REC + 2 * KS * 64 * REC) * sizeof(_Float16);
     static_assert(lds <= 160 * 1024, "LDS budget");
@@ -342,7 +348,7 @@ int launch_h3(ConvArgs& a, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64));
+    dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64), a.parity ? 8u : 1u);
     hipLaunchKernelGGL((conv3d_igemm_h3<TD, TH, TW, S, KS, WM, WN, MINW>), grid, dim3(256), lds, st, a);
     return dm3d_launch_check("conv3d_igemm_h3");
 }
@@ -351,9 +357,12 @@ int launch_h3(ConvArgs& a, hipStream_t st) {
 // group, i.e. slots (hi c0-7, hi c8-15, lo c0-7, lo c8-15) of output channel n stored at physical slot s ^ swz(n)
 __global__ __launch_bounds__(256) void pack_weights_h3_kernel(const float* __restrict__ w, int taps, int cin, int cout,
                                                               int nchunks, int ntiles, float scale, const float* in_scale,
-                                                              _Float16* __restrict__ out) {
+                                                              _Float16* __restrict__ out, int up) {
+    // up: w is the 3x3x3 kernel of an UpSample conv, taps == 8, and 8 parity images follow each other (dm3d_up_weight)
     const long nrec = (long)ntiles * nchunks * taps * 64;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nrec * 16; i += (long)gridDim.x * 256) {
+    for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < nrec * 16 * (up ? 8 : 1); i0 += (long)gridDim.x * 256) {
+        const int par = (int)(i0 / (nrec * 16));
+        const long i = i0 % (nrec * 16);
         const int k = (int)(i & 15);
         long rec = i >> 4;
         const int nn = (int)(rec % 64);
@@ -363,13 +372,13 @@ __global__ __launch_bounds__(256) void pack_weights_h3_kernel(const float* __res
         const int ci = chunk * 16 + k, co = nt * 64 + nn;
         float v = 0.f;
         if (ci < cin && co < cout) {
-            v = w[((long)tap * cin + ci) * cout + co];
+            v = up ? dm3d_up_weight(w, cin, cout, par, tap, ci, co) : w[((long)tap * cin + ci) * cout + co];
             if (in_scale) v *= in_scale[ci];
             v *= scale;
         }
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)hi);
-        _Float16* r = out + rec * REC;
+        _Float16* r = out + ((long)par * nrec + rec) * REC;
         const int sw = (nn >> 2) & 3;
         r[(((k >> 3) ^ sw) << 3) + (k & 7)] = hi;
         r[(((2 + (k >> 3)) ^ sw) << 3) + (k & 7)] = lo;
@@ -379,6 +388,7 @@ __global__ __launch_bounds__(256) void pack_weights_h3_kernel(const float* __res
 }  // namespace
 
 int dm3d_conv_launch_h3(ConvArgs& a, int which, hipStream_t st) {
+    if (which == DM3D_CONV_UP) return launch_h3<4, 8, 8, 1, 2, 4, 1, 2>(a, st);
     if (which == DM3D_CONV_K1) return launch_h3<4, 8, 8, 1, 1, 4, 1, 2>(a, st);
     if (which == DM3D_CONV_K3S2) return launch_h3<2, 4, 8, 2, 3, 2, 2, 2>(a, st);
     return launch_h3<4, 8, 8, 1, 3, 4, 1, 2>(a, st);
@@ -399,6 +409,18 @@ extern "C" int dm3d_pack_weights_h3(const float* keras_kernel, int32_t taps, int
     long g = (n + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(pack_weights_h3_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream), keras_kernel,
-                       taps, cin, cout, nchunks, ntiles, ldexpf(1.0f, w_exp), in_scale, static_cast<_Float16*>(packed));
+                       taps, cin, cout, nchunks, ntiles, ldexpf(1.0f, w_exp), in_scale, static_cast<_Float16*>(packed), 0);
     return dm3d_launch_check("pack_weights_h3_kernel");
+}
+
+extern "C" int64_t dm3d_packed_weight_up_h3_bytes(int32_t cin, int32_t cout) { return 8 * dm3d_packed_weight_h3_bytes(8, cin, cout); }
+
+extern "C" int dm3d_pack_weights_up_h3(const float* keras_kernel, int32_t cin, int32_t cout, int32_t w_exp, void* packed,
+                                       void* stream) {
+    DM3D_REQUIRE(keras_kernel && packed && cin > 0 && cout > 0, "pack_weights_up_h3: bad arguments");
+    DM3D_REQUIRE(w_exp >= -100 && w_exp <= 100 && dm3d_aligned16(packed), "pack_weights_up_h3: w_exp out of range or packed unaligned");
+    const int nchunks = (int)(dm3d_round_up(cin, 16) / 16), ntiles = (int)(dm3d_round_up(cout, 64) / 64);
+    hipLaunchKernelGGL(pack_weights_h3_kernel, dim3(4096), dim3(256), 0, static_cast<hipStream_t>(stream), keras_kernel, 8, cin,
+                       cout, nchunks, ntiles, ldexpf(1.0f, w_exp), nullptr, static_cast<_Float16*>(packed), 1);
+    return dm3d_launch_check("pack_weights_h3_kernel(up)");
 }

@@ -345,6 +345,20 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     }
 }
 
+// upsample variant: 8 parity images of a taps=8 conv (see dm3d_up_weight)
+__global__ __launch_bounds__(256) void pack_weights_up_kernel(const float* __restrict__ w, int cin, int cout, int cinpad,
+                                                              int coutpad, float* __restrict__ out) {
+    const long per = (long)8 * coutpad * cinpad;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < 8 * per; i += (long)gridDim.x * 256) {
+        const int par = (int)(i / per);
+        const long j = i % per;
+        const int ci = (int)(j % cinpad);
+        const int co = (int)((j / cinpad) % coutpad);
+        const int tap = (int)(j / ((long)cinpad * coutpad));
+        out[i] = (ci < cin && co < cout) ? dm3d_up_weight(w, cin, cout, par, tap, ci, co) : 0.f;
+    }
+}
+
 inline unsigned grid_for(long n, int cap = 256 * 8) {
     long g = (n + 255) / 256;
     return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -473,4 +487,14 @@ extern "C" int dm3d_softmax_rows_h2(float* s, int64_t rows, int32_t cols, int64_
     hipLaunchKernelGGL(softmax_rows_h2_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        s, (long)rows, cols, (long)ld);
     return dm3d_launch_check("softmax_rows_h2_kernel");
+}
+
+extern "C" int64_t dm3d_packed_weight_up_elems(int32_t cin, int32_t cout) { return 8 * dm3d_packed_weight_elems(8, cin, cout); }
+
+extern "C" int dm3d_pack_weights_up(const float* keras_kernel, int32_t cin, int32_t cout, float* packed, void* stream) {
+    DM3D_REQUIRE(keras_kernel && packed && cin > 0 && cout > 0, "pack_weights_up: bad arguments");
+    const int cinpad = (int)dm3d_round_up(cin, DM3D_CIN_PAD), coutpad = (int)dm3d_round_up(cout, DM3D_COUT_PAD);
+    hipLaunchKernelGGL(pack_weights_up_kernel, dim3(grid_for((long)64 * cinpad * coutpad)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), keras_kernel, cin, cout, cinpad, coutpad, packed);
+    return dm3d_launch_check("pack_weights_up_kernel");
 }

@@ -57,6 +57,26 @@ def pack_weights_h3(kernel: torch.Tensor, in_scale: Optional[torch.Tensor] = Non
     return out, w_exp
 
 
+def pack_weights_up(kernel: torch.Tensor, h3: bool = False):
+    """[3,3,3,Cin,Cout] kernel of an UpSample conv -> the 8 parity images dm3d_conv3d_ndhwc(upsample=1) expects.
+    Returns wpk (fp32) or (wpk, w_exp) (h3)."""
+    _f32c(kernel, "kernel")
+    if kernel.dim() != 5 or tuple(kernel.shape[:3]) != (3, 3, 3):
+        raise ValueError("kernel must be [3,3,3,cin,cout]")
+    cin, cout = kernel.shape[-2], kernel.shape[-1]
+    if not h3:
+        out = torch.empty(lib().dm3d_packed_weight_up_elems(cin, cout), dtype=torch.float32, device=kernel.device)
+        check(lib().dm3d_pack_weights_up(kernel.data_ptr(), cin, cout, out.data_ptr(), _st()), "pack_weights_up")
+        return out
+    import math
+    from .weights import upsample_parity_kernels
+    wmax = float(abs(upsample_parity_kernels(kernel.cpu().numpy())).max())
+    w_exp = 0 if wmax == 0.0 or not math.isfinite(wmax) else int(13 - math.floor(math.log2(wmax)))
+    out = torch.empty(lib().dm3d_packed_weight_up_h3_bytes(cin, cout) // 2, dtype=torch.float16, device=kernel.device)
+    check(lib().dm3d_pack_weights_up_h3(kernel.data_ptr(), cin, cout, w_exp, out.data_ptr(), _st()), "pack_weights_up_h3")
+    return out, w_exp
+
+
 def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False, pro_scale=None, pro_shift=None,
            vec=None, vec_idx=None, relu=False, res=None, precision=_lib.PREC_F32, w_exp=0) -> torch.Tensor:
     """Conv3D(padding="same") on NDHWC with the fused prologue / concat / upsample / epilogue of dm3d_conv3d_ndhwc."""

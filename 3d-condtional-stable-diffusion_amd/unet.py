@@ -25,7 +25,7 @@ import torch
 from . import _lib
 from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, ConvDesc, GemmDesc, check, lib
 from .betas import time_embedding_table
-from .weights import UNetConfig, keras_init_weights, walk
+from .weights import UNetConfig, keras_init_weights, upsample_parity_kernels, walk
 
 BN_EPS = 1e-3     # keras.layers.BatchNormalization default
 LN_EPS = 1e-3     # keras.layers.LayerNormalization default
@@ -106,12 +106,24 @@ class UNet:
         return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(self.device)
 
     def _pack(self, kernel: np.ndarray, bias: Optional[np.ndarray], in_scale: Optional[torch.Tensor] = None,
-              conv: bool = False) -> _Conv:
-        """``conv=True``: weights of a dm3d_conv3d_ndhwc launch (packed for self.precision); otherwise GEMM operand."""
+              conv: bool = False, up: bool = False) -> _Conv:
+        """``conv=True``: weights of a dm3d_conv3d_ndhwc launch (packed for self.precision); otherwise GEMM operand.
+        ``up=True``: UpSample conv — packed as the 8 parity 2x2x2 kernels the upsample launch expects."""
         shape = kernel.shape
         taps = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
         cin, cout = int(shape[-2]), int(shape[-1])
         raw = self._dev(kernel)
+        dbias = self._dev(bias) if bias is not None else None
+        if up:
+            if self.precision == "h3":
+                wmax = float(np.abs(upsample_parity_kernels(kernel)).max())
+                w_exp = 0 if wmax == 0.0 or not np.isfinite(wmax) else max(-100, min(100, int(13 - np.floor(np.log2(wmax)))))
+                wpk = torch.empty(lib().dm3d_packed_weight_up_h3_bytes(cin, cout) // 2, dtype=torch.float16, device=self.device)
+                check(lib().dm3d_pack_weights_up_h3(raw.data_ptr(), cin, cout, w_exp, wpk.data_ptr(), _stream()), "pack_weights_up_h3")
+                return _Conv(wpk, dbias, taps, cin, cout, _lib.PREC_H3, w_exp)
+            wpk = torch.empty(lib().dm3d_packed_weight_up_elems(cin, cout), dtype=torch.float32, device=self.device)
+            check(lib().dm3d_pack_weights_up(raw.data_ptr(), cin, cout, wpk.data_ptr(), _stream()), "pack_weights_up")
+            return _Conv(wpk, dbias, taps, cin, cout)
         if conv and self.precision == "h3":
             # power-of-two pre-scale so that max|w| lands in [2^13, 2^14): hi stays finite, lo stays a normal float16
             wmax = float(np.abs(kernel).max())
@@ -170,7 +182,7 @@ class UNet:
                 self.temb_off[n] = off
                 off += blk.cout
             elif blk.kind in ("down", "up"):
-                P[n] = self._pack(s[f"{n}.kernel"], s[f"{n}.bias"], conv=True)
+                P[n] = self._pack(s[f"{n}.kernel"], s[f"{n}.bias"], conv=True, up=blk.kind == "up")
             elif blk.kind == "attn":
                 self._prepare_attn(P, blk)
         self.temb_ld = off
@@ -377,7 +389,10 @@ class Plan:
         kind = "conv_k1" if w.taps == 1 else ("conv_k3s2" if stride == 2 else "conv_k3s1")
         self.ops.append((lib().dm3d_conv3d_ndhwc, (C.byref(d),), kind,
                          {"desc": f"{kind} {edge_in}^3{'x2up' if upsample else ''} cin={w.cin} cout={w.cout}",
-                          "flops": 2.0 * w.taps * w.cin * w.cout * self.B * eo ** 3,
+                          "flops": 2.0 * w.taps * w.cin * w.cout * self.B * eo ** 3,      # algorithmic
+                          # MFMA work actually issued: the upsample conv runs as 8 parity convs of 8 taps on the low-res grid
+                          "exec_flops": 2.0 * (8 if upsample else w.taps) * w.cin * w.cout * self.B * eo ** 3
+                                        * (3 if w.precision == _lib.PREC_H3 else 1),
                           "bytes": 4.0 * self.B * (edge_in ** 3 * w.cin + eo ** 3 * w.cout)}))
 
     def _gemm(self, **kw):

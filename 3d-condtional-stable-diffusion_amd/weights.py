@@ -220,3 +220,20 @@ def synthetic_weights(cfg: UNetConfig, seed: int = 0) -> Dict[str, np.ndarray]:
         else:
             raise KeyError(name)
     return out
+
+
+def upsample_parity_kernels(kernel: np.ndarray) -> np.ndarray:
+    """[3,3,3,Cin,Cout] kernel of an UpSample conv (conditional_dm3d.py:288-296) -> [8,2,2,2,Cin,Cout]: for output parity
+    p = 4a+2b+c the 2x2x2 kernel acting on the low-resolution tensor (taps of the k3 kernel that read the same source voxel
+    of the nearest-2x upsampled tensor are summed).  Host mirror of the device packing, used to size the H3 weight scale."""
+    groups = {0: ([0], [1, 2]), 1: ([0, 1], [2])}           # parity -> k3 taps feeding k2 tap 0 / 1
+    k = np.asarray(kernel, dtype=np.float64)
+    out = np.zeros((8, 2, 2, 2) + k.shape[3:], dtype=np.float64)
+    for p in range(8):
+        a, b, c = p >> 2, (p >> 1) & 1, p & 1
+        for td in range(2):
+            for th in range(2):
+                for tw in range(2):
+                    sel = k[np.ix_(groups[a][td], groups[b][th], groups[c][tw])]
+                    out[p, td, th, tw] = sel.sum(axis=(0, 1, 2))
+    return out

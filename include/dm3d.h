@@ -76,6 +76,15 @@ int64_t dm3d_packed_weight_h3_bytes(int32_t taps, int32_t cin, int32_t cout);
 int     dm3d_pack_weights_h3(const float* keras_kernel, int32_t taps, int32_t cin, int32_t cout, int32_t w_exp,
                              const float* in_scale, void* packed, void* stream);
 
+/* UpSample (UpSampling3D(2) + Conv3D k3, conditional_dm3d.py:288-296): a 3x3x3 conv on a nearest-2x upsampled tensor equals,
+ * per output parity (a,b,c), a 2x2x2 conv on the low-resolution tensor whose taps are sums of the k3 taps that read the same
+ * source voxel — 8 taps instead of 27.  These pack the [3,3,3,Cin,Cout] kernel into the 8 parity images that
+ * dm3d_conv3d_ndhwc expects in wpk when upsample == 1 (for H3, choose w_exp from the summed taps: up to 8x the largest tap). */
+int64_t dm3d_packed_weight_up_elems(int32_t cin, int32_t cout);
+int     dm3d_pack_weights_up(const float* keras_kernel, int32_t cin, int32_t cout, float* packed, void* stream);
+int64_t dm3d_packed_weight_up_h3_bytes(int32_t cin, int32_t cout);
+int     dm3d_pack_weights_up_h3(const float* keras_kernel, int32_t cin, int32_t cout, int32_t w_exp, void* packed, void* stream);
+
 /* ---- Conv3D(padding="same") as implicit GEMM on MFMA ---------------------------------------------------------
  * Replaces layers.Conv3D for k=3/s=1 (:257-259, :348-353, :412-414), k=3/s=2 (DownSample :274-285, TF SAME pad 0
  * before / 1 after on even sizes), k=1 (ResidualBlock skip :245-248) and UpSampling3D(2)+Conv3D (UpSample :288-296,
@@ -94,7 +103,7 @@ typedef struct dm3d_conv_desc {
     int32_t upsample;           /* 1: convolve the nearest-2x upsampled tensor (stride must be 1) */
     int32_t ksize;              /* 1 or 3 */
     int32_t stride;             /* 1 or 2 */
-    const float* wpk;           /* dm3d_pack_weights output for (ksize^3, c1+c2, cout) */
+    const float* wpk;           /* dm3d_pack_weights[_h3] output for (ksize^3, c1+c2, cout); upsample: dm3d_pack_weights_up[_h3] */
     const float* bias;          /* [cout] or NULL */
     const float* pro_scale;     /* [c1+c2] or NULL (both or neither) */
     const float* pro_shift;

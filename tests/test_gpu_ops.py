@@ -64,6 +64,9 @@ CONV_CASES = [
     ("k3s2_4to2", 1, (4, 4, 4), 16, 0, 64, 3, 2, False, "bias"),
     ("k3_upsample_4to8", 2, (4, 4, 4), 32, 0, 32, 3, 1, True, "bias"),
     ("k3_upsample_8to16", 1, (8, 8, 8), 16, 0, 64, 3, 1, True, "bias"),
+    ("k3_upsample_noncubic_res", 2, (4, 8, 8), 32, 0, 40, 3, 1, True, "bias res"),
+    ("k3_upsample_2to4", 1, (2, 2, 2), 16, 0, 64, 3, 1, True, ""),
+    ("k3s2_odd_mixed", 1, (5, 6, 8), 16, 0, 32, 3, 2, False, "bias"),
     ("k1_dual", 2, (8, 8, 8), 32, 16, 64, 1, 1, False, "bias"),
     ("k1_relu_res", 1, (4, 4, 4), 64, 0, 64, 1, 1, False, "bias relu res"),
 ]
@@ -91,10 +94,10 @@ def test_conv3d(dev, case, prec):
                     relu="relu" in extras, res=res)
     c = lambda t: None if t is None else t.to(dev).contiguous()
     if prec == "h3":
-        wpk, w_exp = ops.pack_weights_h3(c(kern))
+        wpk, w_exp = ops.pack_weights_up(c(kern), h3=True) if ups else ops.pack_weights_h3(c(kern))
         pk = dict(precision=_lib.PREC_H3, w_exp=w_exp)
     else:
-        wpk, pk = ops.pack_weights(c(kern)), {}
+        wpk, pk = (ops.pack_weights_up(c(kern)) if ups else ops.pack_weights(c(kern))), {}
     out = ops.conv3d(c(x1), wpk, cout, ks, x2=c(x2), bias=c(bias), stride=stride, upsample=ups,
                      pro_scale=c(pro[0]) if pro else None, pro_shift=c(pro[1]) if pro else None,
                      vec=c(vec), vec_idx=c(vec_idx), relu="relu" in extras, res=c(res), **pk)

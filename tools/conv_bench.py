@@ -14,6 +14,7 @@ CASES = [  # name, edge, c1, c2, cout, ks, stride, ups, pro, res, vec
     ("32^3 64->64 pro+vec", 32, 64, 0, 64, 3, 1, 0, 1, 0, 1),
     ("32^3 128+64->64 pro", 32, 128, 64, 64, 3, 1, 0, 1, 0, 1),
     ("16^3x2 128->128 up", 16, 128, 0, 128, 3, 1, 1, 0, 0, 0),
+    ("8^3x2 256->256 up", 8, 256, 0, 256, 3, 1, 1, 0, 0, 0),
     ("16^3 128->128 pro+res", 16, 128, 0, 128, 3, 1, 0, 1, 1, 0),
     ("8^3 256->256 pro+res", 8, 256, 0, 256, 3, 1, 0, 1, 1, 0),
     ("32^3 64->8 pro (out)", 32, 64, 0, 8, 3, 1, 0, 1, 0, 0),
@@ -26,10 +27,10 @@ for name, e, c1, c2, cout, ks, stride, ups, pro, res, vec in CASES:
     x2 = torch.randn(B, e, e, e, c2, device=dev) if c2 else None
     k = torch.randn(ks, ks, ks, c1 + c2, cout, device=dev) * 0.05
     if prec == "h3":
-        wpk, w_exp = ops.pack_weights_h3(k)
+        wpk, w_exp = ops.pack_weights_up(k, h3=True) if ups else ops.pack_weights_h3(k)
         kw = dict(precision=_lib.PREC_H3, w_exp=w_exp)
     else:
-        wpk, kw = ops.pack_weights(k), {}
+        wpk, kw = (ops.pack_weights_up(k) if ups else ops.pack_weights(k)), {}
     eo = e * (2 if ups else 1) // stride
     args = dict(x2=x2, bias=torch.randn(cout, device=dev), stride=stride, upsample=bool(ups), **kw)
     if pro:
