@@ -40,6 +40,7 @@ class GemmDesc(C.Structure):
         ("alpha", C.c_float), ("bias", _f32p), ("bias_along_m", C.c_int32), ("act", C.c_int32),
         ("res", _f32p), ("ldr", C.c_int64), ("stride_r", C.c_int64),
         ("precision", C.c_int32), ("a_fmt", C.c_int32), ("b_fmt", C.c_int32), ("out_fmt", C.c_int32),
+        ("res2", _f32p),
     ]
 
 
@@ -68,6 +69,7 @@ SIGNATURES = {
     "dm3d_pack_weights_up_h3": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "dm3d_conv3d_ndhwc": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "dm3d_gemm_tn": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "dm3d_gemm_tn_group": (C.c_int, [C.POINTER(GemmDesc), C.c_int32, C.c_void_p]),
     "dm3d_split_h2": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "dm3d_layernorm3_h2": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_float] + [_f32p] * 9 + [C.c_void_p]),
     "dm3d_softmax_rows_h2": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]),

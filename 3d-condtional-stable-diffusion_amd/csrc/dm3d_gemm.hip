@@ -17,6 +17,7 @@ struct GemmArgs {
     float alpha;
     const float* bias; int bias_m; int act;
     const float* res; long ldr, sr;
+    const float* res2;
 };
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_f32(const GemmArgs p) {
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32(const GemmArgs p) {
 
     float* O = p.out + (size_t)bz * p.so;
     const float* R = p.res ? p.res + (size_t)bz * p.sr : nullptr;
+    const float* R2 = p.res2 ? p.res2 + (size_t)bz * p.sr : nullptr;
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         const int n = n0 + nr * 32 + l32;
@@ -95,6 +97,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32(const GemmArgs p) {
                     if (p.bias && p.bias_m) v += p.bias[m];
                     v = dm3d_act(v, p.act);
                     if (R) v += R[(size_t)m * p.ldr + n];
+                    if (R2) v += R2[(size_t)m * p.ldr + n];
                     O[(size_t)m * p.ldo + n] = v;
                 }
             }
@@ -116,6 +119,7 @@ extern "C" int dm3d_gemm_tn(const dm3d_gemm_desc* d, void* stream) {
     DM3D_REQUIRE(d->stride_a % 4 == 0 && d->stride_b % 4 == 0, "gemm: batch strides of a/b must be multiples of 4");
     DM3D_REQUIRE(d->lda >= d->k && d->ldb >= d->k && d->ldo >= d->n, "gemm: leading dimension smaller than the row");
     DM3D_REQUIRE(!d->res || d->ldr >= d->n, "gemm: ldr smaller than n");
+    DM3D_REQUIRE(!d->res2 || d->res, "gemm: res2 needs res");
     DM3D_REQUIRE(dm3d_aligned16(d->a) && dm3d_aligned16(d->b), "gemm: a/b must be 16-byte aligned");
     DM3D_REQUIRE(d->act >= DM3D_ACT_NONE && d->act <= DM3D_ACT_SILU, "gemm: unknown act %d", d->act);
     DM3D_REQUIRE(d->batch <= 65535, "gemm: batch %d exceeds grid.z", d->batch);
@@ -129,7 +133,7 @@ extern "C" int dm3d_gemm_tn(const dm3d_gemm_desc* d, void* stream) {
     a.out = d->out; a.ldo = d->ldo; a.so = d->stride_o;
     a.m = d->m; a.n = d->n; a.k = d->k; a.alpha = d->alpha;
     a.bias = d->bias; a.bias_m = d->bias_along_m; a.act = d->act;
-    a.res = d->res; a.ldr = d->ldr; a.sr = d->stride_r;
+    a.res = d->res; a.ldr = d->ldr; a.sr = d->stride_r; a.res2 = d->res2;
     dim3 grid((unsigned)((d->m + 255) / 256), (unsigned)((d->n + 63) / 64), (unsigned)d->batch);
     hipLaunchKernelGGL(gemm_tn_f32, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return dm3d_launch_check("gemm_tn_f32");

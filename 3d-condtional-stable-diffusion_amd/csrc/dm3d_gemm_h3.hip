@@ -9,8 +9,11 @@
 // the XOR-swizzled LDS records; a float32 operand is still accepted (split on the fly) for the tensors that enter a block
 // from a convolution.
 //
-// Workgroup = 256 threads, tile 256 (m) x 64 (n), K in chunks of 32 (two 16-k records per row), LDS double-buffered
-// (2 x 40 KB -> two workgroups per CU), next chunk prefetched into registers during the MFMAs, one barrier per chunk.
+// Workgroup = 256 threads = 2 x 2 waves of 64 x 64, tile 128 (m) x 128 (n), K in chunks of 32 (two 16-k records per row), LDS
+// double-buffered (2 x 32 KB -> two workgroups per CU), next chunk prefetched into registers during the MFMAs, one barrier
+// per chunk.  The square tile matters: this kernel re-stages both operands every chunk and is bound by LDS write bandwidth
+// (ds_write_b128 ~ 70 B/clk/CU); 128 x 128 stages 341 B per MFMA against 427 B for a 256 x 64 tile, and the model's GEMMs
+// (m = B*L = 16384, n = 256...1024) still yield >= 256 workgroups.
 #include "dm3d_h3.h"
 
 namespace {
@@ -23,33 +26,54 @@ struct GemmH3Args {
     float alpha;
     const float* bias; int bias_m; int act;
     const float* res; long ldr, sr;
+    const float* res2;                  // optional second float32 residual with res's layout
     int out_h2;
+    int batch;
+};
+
+constexpr int MAX_GROUP = 4;
+struct GemmGroup {                      // independent problems served by one launch: blockIdx.x is a flat tile index
+    GemmH3Args prob[MAX_GROUP];
+    int tstart[MAX_GROUP + 1];          // prefix sums of tiles_m * tiles_n * batch
+    int tiles_m[MAX_GROUP];
+    int count;
 };
 
 constexpr int REC = DM3D_REC;
-constexpr int KC = 32, TM = 256, NT = 64;
+constexpr int KC = 32, TM = 128, NT = 128;        // 2 x 2 waves of 64 x 64: A and B staging balanced, 256 B staged per MFMA
 constexpr int A_BUF = 2 * TM * REC, B_BUF = 2 * NT * REC;      // halfs per buffer (two records per row)
 
 template <bool A_F32, bool B_F32>
-__global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmH3Args p) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
+    // problem selection (uniform): flat tile index -> (problem, batch, tile_m, tile_n); m tiles vary fastest so that
+    // consecutive workgroups share the B tile (the weight operand) through L2
+    int which = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_GROUP; ++i) which += (i < grp.count && (int)blockIdx.x >= grp.tstart[i]) ? 1 : 0;
+    const GemmH3Args& p = grp.prob[which];
+    const int tm = grp.tiles_m[which], tn = (p.n + NT - 1) / NT;
+    int local = blockIdx.x - grp.tstart[which];
+    const int bz = local / (tm * tn);
+    local -= bz * tm * tn;
+    const int tile_n = local / tm, tile_m = local - tile_n * tm;
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_g[];
     _Float16* lds_a = smem_g;                   // [2][2][TM][REC]
     _Float16* lds_b = smem_g + 2 * A_BUF;       // [2][2][NT][REC]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l32 = lane & 31;
-    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * NT, bz = blockIdx.z;
+    const int m0 = tile_m * TM, n0 = tile_n * NT;
     const char* A = static_cast<const char*>(p.a) + (size_t)bz * p.sa * 4;
     const char* B = static_cast<const char*>(p.b) + (size_t)bz * p.sb * 4;
 
     // ---- staging maps (all loads unconditional on clamped rows; rows beyond m / n only feed outputs that are never stored)
     // H2 source: a row's chunk is 128 contiguous bytes = 8 pieces (record kk = w >> 2, slot w & 3)
     // F32 source: item = (row, 8-k group g): two float4 -> hi slot g & 1, lo slot 2 + (g & 1) of record g >> 1
-    constexpr int A_ITEMS = A_F32 ? 4 : 8, B_ITEMS = A_F32 ? 1 : 2;
-    constexpr int BI = B_F32 ? 1 : 2;
-    f32x4 ra[8], rb[2];
-    size_t a_src[A_F32 ? 4 : 8];
-    int a_dst[A_F32 ? 4 : 8];
+    constexpr int A_ITEMS = A_F32 ? 2 : 4;
+    constexpr int BI = B_F32 ? 2 : 4;
+    f32x4 ra[4], rb[4];
+    size_t a_src[A_ITEMS];
+    int a_dst[A_ITEMS];
 #pragma unroll
     for (int i = 0; i < A_ITEMS; ++i) {
         const int q = tid + i * 256;
@@ -65,8 +89,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmH3Args p) {
             a_dst[i] = ((w >> 2) * TM + row) * REC + (((w & 3) ^ swz(row)) << 3);
         }
     }
-    size_t b_src[2];
-    int b_dst[2];
+    size_t b_src[BI];
+    int b_dst[BI];
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
         const int q = tid + i * 256;
@@ -82,7 +106,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmH3Args p) {
             b_dst[i] = ((w >> 2) * NT + row) * REC + (((w & 3) ^ swz(row)) << 3);
         }
     }
-    (void)B_ITEMS;
 
     auto fetch = [&](int k0) {                  // k0 is clamped by the caller to the last chunk
         // when k % 32 == 16 the last chunk has no second record: its loads re-read the first one (64 bytes earlier)
@@ -104,8 +127,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmH3Args p) {
             const bool second = B_F32 ? (((tid + i * 256) & 3) >= 2) : (((tid + i * 256) & 7) >= 4);
             const size_t koff = (size_t)k0 * 4 - ((!sec && second) ? 64 : 0);
             if (B_F32) {
-                rb[0] = *reinterpret_cast<const f32x4*>(B + b_src[i] + koff);
-                rb[1] = *reinterpret_cast<const f32x4*>(B + b_src[i] + koff + 16);
+                rb[2 * i] = *reinterpret_cast<const f32x4*>(B + b_src[i] + koff);
+                rb[2 * i + 1] = *reinterpret_cast<const f32x4*>(B + b_src[i] + koff + 16);
             } else {
                 rb[i] = *reinterpret_cast<const f32x4*>(B + b_src[i] + koff);
             }
@@ -134,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmH3Args p) {
             if (B_F32) {
                 const bool ok = second_rec || ((tid + i * 256) & 3) < 2;
                 h8 hi, lo;
-                split8(rb[0], rb[1], ok ? 65504.0f : 0.0f, ok ? 65504.0f : 0.0f, hi, lo);
+                split8(rb[2 * i], rb[2 * i + 1], ok ? 65504.0f : 0.0f, ok ? 65504.0f : 0.0f, hi, lo);
                 *reinterpret_cast<h8*>(db + b_dst[i]) = hi;
                 *reinterpret_cast<h8*>(db + (b_dst[i] ^ 16)) = lo;
             } else {
@@ -145,11 +168,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmH3Args p) {
     };
 
     // fragment addresses: record = row, hi slot = half ^ swz(row), lo slot = that ^ 2; 32-row tiles are 32 records apart
+    const int wm = wave >> 1, wn = wave & 1;
     int a_hi, b_hi;
     {
-        const int row = wave * 64 + l32;
+        const int row = wm * 64 + l32, col = wn * 64 + l32;
         a_hi = row * REC + ((half ^ swz(row)) << 3);
-        b_hi = l32 * REC + ((half ^ swz(l32)) << 3);
+        b_hi = col * REC + ((half ^ swz(col)) << 3);
     }
 
     f32x16 acc[2][2];
@@ -201,11 +225,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmH3Args p) {
     const bool full = m0 + TM <= p.m && n0 + NT <= p.n;
     char* O = static_cast<char*>(p.out) + ((size_t)bz * p.so + (size_t)m0 * p.ldo) * 4;
     const float* R = p.res ? p.res + (size_t)bz * p.sr + (size_t)m0 * p.ldr : nullptr;
-    const int lrow = wave * 64 + 4 * half;                     // + mr*32 + (r&3) + 8*(r>>2)
+    const float* R2 = p.res2 ? p.res2 + (size_t)bz * p.sr + (size_t)m0 * p.ldr : nullptr;
+    const int lrow = wm * 64 + 4 * half;                       // + mr*32 + (r&3) + 8*(r>>2)
     const int ldo = (int)p.ldo, ldr = (int)p.ldr;
 #pragma unroll
     for (int nr = 0; nr < 2; ++nr) {
-        const int n = n0 + nr * 32 + l32;
+        const int n = n0 + wn * 64 + nr * 32 + l32;
         const bool n_ok = n < p.n;
         const int nc = n_ok ? n : p.n - 1;
         const float bn = (p.bias && !p.bias_m) ? p.bias[nc] : 0.0f;
@@ -221,6 +246,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmH3Args p) {
                 const int row = lrow + mr * 32 + (r & 3) + 8 * (r >> 2);
                 const int rc = full ? row : (m0 + row < p.m ? row : p.m - 1 - m0);
                 rv[r] = R ? R[rc * ldr + nc] : 0.0f;
+                if (R2) rv[r] += R2[rc * ldr + nc];
                 bm[r] = (p.bias && p.bias_m) ? p.bias[m0 + rc] : 0.0f;
             }
 #pragma unroll
@@ -266,24 +292,35 @@ __global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__
 
 }  // namespace
 
-int dm3d_gemm_h3_launch(const dm3d_gemm_desc* d, hipStream_t st) {
+static int fill_args(const dm3d_gemm_desc* d, GemmH3Args& a) {
+    DM3D_REQUIRE(d->a && d->b && d->out, "gemm(h3): a/b/out must be non-null");
+    DM3D_REQUIRE(d->m > 0 && d->n > 0 && d->k > 0 && d->batch > 0, "gemm(h3): non-positive extent");
     DM3D_REQUIRE(d->k % 16 == 0 && d->lda % 4 == 0 && d->ldb % 4 == 0, "gemm(h3): k=%d must be a multiple of 16", d->k);
+    DM3D_REQUIRE(d->lda >= d->k && d->ldb >= d->k && d->ldo >= d->n, "gemm(h3): leading dimension smaller than the row");
     DM3D_REQUIRE(d->a_fmt == DM3D_FMT_F32 || d->a_fmt == DM3D_FMT_H2, "gemm(h3): bad a_fmt");
     DM3D_REQUIRE(d->b_fmt == DM3D_FMT_F32 || d->b_fmt == DM3D_FMT_H2, "gemm(h3): bad b_fmt");
     DM3D_REQUIRE(d->a_fmt == DM3D_FMT_F32 || (d->lda % 16 == 0 && d->stride_a % 16 == 0), "gemm(h3): H2 operand a needs lda, stride %% 16 == 0");
     DM3D_REQUIRE(d->b_fmt == DM3D_FMT_F32 || (d->ldb % 16 == 0 && d->stride_b % 16 == 0), "gemm(h3): H2 operand b needs ldb, stride %% 16 == 0");
     DM3D_REQUIRE(d->out_fmt == DM3D_FMT_F32 || (d->out_fmt == DM3D_FMT_H2 && d->n % 16 == 0 && d->ldo % 16 == 0 && d->stride_o % 16 == 0),
                  "gemm(h3): H2 output needs n, ldo, stride_o %% 16 == 0");
+    DM3D_REQUIRE(dm3d_aligned16(d->a) && dm3d_aligned16(d->b), "gemm(h3): a/b must be 16-byte aligned");
     DM3D_REQUIRE(dm3d_aligned16(d->out) || d->out_fmt == DM3D_FMT_F32, "gemm(h3): H2 output must be 16-byte aligned");
-    GemmH3Args a{};
+    DM3D_REQUIRE(!d->res || d->ldr >= d->n, "gemm(h3): ldr smaller than n");
+    DM3D_REQUIRE(!d->res2 || d->res, "gemm(h3): res2 needs res");
+    DM3D_REQUIRE(d->act >= DM3D_ACT_NONE && d->act <= DM3D_ACT_SILU, "gemm(h3): unknown act %d", d->act);
     a.a = d->a; a.lda = d->lda; a.sa = d->stride_a;
     a.b = d->b; a.ldb = d->ldb; a.sb = d->stride_b;
     a.out = d->out; a.ldo = d->ldo; a.so = d->stride_o;
     a.m = d->m; a.n = d->n; a.k = d->k; a.alpha = d->alpha;
     a.bias = d->bias; a.bias_m = d->bias_along_m; a.act = d->act;
-    a.res = d->res; a.ldr = d->ldr; a.sr = d->stride_r;
+    a.res = d->res; a.ldr = d->ldr; a.sr = d->stride_r; a.res2 = d->res2;
     a.out_h2 = d->out_fmt == DM3D_FMT_H2;
-    constexpr size_t lds = (size_t)(2 * A_BUF + 2 * B_BUF) * sizeof(_Float16);     // 81920
+    a.batch = d->batch;
+    return DM3D_OK;
+}
+
+static int launch_group(GemmGroup& g, bool af, bool bf, hipStream_t st) {
+    constexpr size_t lds = (size_t)(2 * A_BUF + 2 * B_BUF) * sizeof(_Float16);     // 65536
     static bool attr_set = false;
     if (!attr_set) {
         const void* fns[] = {reinterpret_cast<const void*>(&gemm_tn_h3<false, false>), reinterpret_cast<const void*>(&gemm_tn_h3<true, false>),
@@ -291,13 +328,42 @@ int dm3d_gemm_h3_launch(const dm3d_gemm_desc* d, hipStream_t st) {
         for (const void* f : fns) DM3D_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    dim3 grid((unsigned)((d->m + TM - 1) / TM), (unsigned)((d->n + NT - 1) / NT), (unsigned)d->batch);
-    const bool af = d->a_fmt == DM3D_FMT_F32, bf = d->b_fmt == DM3D_FMT_F32;
-    if (af && bf) hipLaunchKernelGGL((gemm_tn_h3<true, true>), grid, dim3(256), lds, st, a);
-    else if (af) hipLaunchKernelGGL((gemm_tn_h3<true, false>), grid, dim3(256), lds, st, a);
-    else if (bf) hipLaunchKernelGGL((gemm_tn_h3<false, true>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((gemm_tn_h3<false, false>), grid, dim3(256), lds, st, a);
+    long t = 0;
+    for (int i = 0; i < g.count; ++i) {
+        g.tstart[i] = (int)t;
+        g.tiles_m[i] = (g.prob[i].m + TM - 1) / TM;
+        t += (long)g.tiles_m[i] * ((g.prob[i].n + NT - 1) / NT) * g.prob[i].batch;
+    }
+    for (int i = g.count; i <= MAX_GROUP; ++i) g.tstart[i] = (int)t;
+    DM3D_REQUIRE(t > 0 && t < (1l << 31), "gemm(h3): %ld tiles do not fit the grid", t);
+    dim3 grid((unsigned)t);
+    if (af && bf) hipLaunchKernelGGL((gemm_tn_h3<true, true>), grid, dim3(256), lds, st, g);
+    else if (af) hipLaunchKernelGGL((gemm_tn_h3<true, false>), grid, dim3(256), lds, st, g);
+    else if (bf) hipLaunchKernelGGL((gemm_tn_h3<false, true>), grid, dim3(256), lds, st, g);
+    else hipLaunchKernelGGL((gemm_tn_h3<false, false>), grid, dim3(256), lds, st, g);
     return dm3d_launch_check("gemm_tn_h3");
+}
+
+int dm3d_gemm_h3_launch(const dm3d_gemm_desc* d, hipStream_t st) {
+    GemmGroup g{};
+    g.count = 1;
+    const int rc = fill_args(d, g.prob[0]);
+    if (rc != DM3D_OK) return rc;
+    return launch_group(g, d->a_fmt == DM3D_FMT_F32, d->b_fmt == DM3D_FMT_F32, st);
+}
+
+extern "C" int dm3d_gemm_tn_group(const dm3d_gemm_desc* descs, int32_t count, void* stream) {
+    DM3D_REQUIRE(descs != nullptr && count >= 1 && count <= MAX_GROUP, "gemm_group: count %d not in [1,%d]", count, MAX_GROUP);
+    GemmGroup g{};
+    g.count = count;
+    for (int i = 0; i < count; ++i) {
+        DM3D_REQUIRE(descs[i].precision == DM3D_PREC_H3, "gemm_group: only DM3D_PREC_H3 problems can be grouped");
+        DM3D_REQUIRE(descs[i].a_fmt == descs[0].a_fmt && descs[i].b_fmt == descs[0].b_fmt,
+                     "gemm_group: all problems must share the operand formats");
+        const int rc = fill_args(&descs[i], g.prob[i]);
+        if (rc != DM3D_OK) return rc;
+    }
+    return launch_group(g, descs[0].a_fmt == DM3D_FMT_F32, descs[0].b_fmt == DM3D_FMT_F32, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int dm3d_split_h2(const float* src, int64_t rows, int32_t k, int64_t ld_src, int32_t exp2, void* dst, int64_t ld_dst,

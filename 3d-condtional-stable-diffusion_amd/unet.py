@@ -324,7 +324,7 @@ class UNet:
 
 def _gemm_desc(a, lda, b, ldb, out, ldo, m, n, k, batch=1, stride_a=0, stride_b=0, stride_o=0, alpha=1.0, bias=None,
                bias_along_m=0, act=ACT_NONE, res=None, ldr=0, stride_r=0, a_off=0, b_off=0, out_off=0, res_off=0,
-               h3=False, a_h2=False, b_h2=False, out_h2=False) -> GemmDesc:
+               h3=False, a_h2=False, b_h2=False, out_h2=False, res2=None) -> GemmDesc:
     d = GemmDesc()
     d.a, d.lda, d.stride_a = _ptr(a, a_off), lda, stride_a
     d.b, d.ldb, d.stride_b = _ptr(b, b_off), ldb, stride_b
@@ -333,6 +333,7 @@ def _gemm_desc(a, lda, b, ldb, out, ldo, m, n, k, batch=1, stride_a=0, stride_b=
     d.alpha = alpha
     d.bias, d.bias_along_m, d.act = _ptr(bias), bias_along_m, act
     d.res, d.ldr, d.stride_r = _ptr(res, res_off), ldr, stride_r
+    d.res2 = _ptr(res2)
     d.precision = _lib.PREC_H3 if h3 else _lib.PREC_F32
     d.a_fmt = _lib.FMT_H2 if a_h2 else _lib.FMT_F32
     d.b_fmt = _lib.FMT_H2 if b_h2 else _lib.FMT_F32
@@ -402,6 +403,14 @@ class Plan:
         self.ops.append((lib().dm3d_gemm_tn, (C.byref(d),), kind,
                          {"desc": f"{kind} m={d.m} n={d.n} k={d.k} batch={d.batch}", "flops": 2.0 * d.m * d.n * d.k * d.batch}))
 
+    def _gemm_group(self, problems):
+        """Independent H3 GEMMs with identical operand formats as one launch (dm3d_gemm_tn_group)."""
+        arr = (GemmDesc * len(problems))(*[_gemm_desc(**kw) for kw in problems])
+        self._keep.append(arr)
+        fl = sum(2.0 * d.m * d.n * d.k * d.batch for d in arr)
+        desc = "gemm_h3 group[" + " | ".join(f"m={d.m} n={d.n} k={d.k} b={d.batch}" for d in arr) + "]"
+        self.ops.append((lib().dm3d_gemm_tn_group, (arr, len(problems)), "gemm_h3", {"desc": desc, "flops": fl}))
+
     # -- graph -----------------------------------------------------------------------------------------------------
     def _build(self):
         net, cfg, B = self.net, self.net.cfg, self.B
@@ -466,6 +475,8 @@ class Plan:
         L = edge ** 3
         M = B * L
         h2 = self.net._attn_h2(u, L)
+        if h2:
+            return self._cross_block_h2(blk, x, edge)
         W = (lambda w: w.h2) if h2 else (lambda w: w.wpk)
         pin, pout, qk, val = P[f"{n}.proj_in"], P[f"{n}.proj_out"], P[f"{n}.qk"], P[f"{n}.value"]
         m0, m1 = P[f"{n}.mlp.0"], P[f"{n}.mlp.1"]
@@ -508,6 +519,63 @@ class Plan:
         out = self._buf(B, edge, edge, edge, u)
         self._gemm(a=a3, lda=u, b=W(pout), ldb=pout.cin_pad, out=out, ldo=u, m=M, n=u, k=u, bias=pout.bias, act=ACT_RELU,
                    res=x, ldr=u, h3=h2, a_h2=h2, b_h2=h2)
+        return out
+
+    def _cross_block_h2(self, blk, x, edge):
+        """CrossAttentionBlock on the H3 GEMM with DM3D_FMT_H2 intermediates, 8 launches: the GEMMs that depend only on the
+        LayerNorm outputs (q|k, v^T, q2, MLP hidden) go out as one grouped launch, likewise the two score products and the
+        two P.V products; a3 = MLP + (attn_self + y) + attn_cross is formed in the MLP GEMM's epilogue (two residuals)."""
+        P, B, n, u = self.net.P, self.B, blk.name, blk.cout
+        L = edge ** 3
+        M = B * L
+        pin, pout, qk, val = P[f"{n}.proj_in"], P[f"{n}.proj_out"], P[f"{n}.qk"], P[f"{n}.value"]
+        m0, m1 = P[f"{n}.mlp.0"], P[f"{n}.mlp.1"]
+        hh = dict(h3=True, a_h2=True, b_h2=True)
+        y = self._buf(M, u)                                                   # relu(proj_in(BN(x))), float32
+        self._gemm(a=x, lda=u, b=pin.h2, ldb=pin.cin_pad, out=y, ldo=u, m=M, n=u, k=u, bias=pin.bias, act=ACT_RELU,
+                   h3=True, b_h2=True)
+        n1, n2, n3 = self._buf(M, u), self._buf(M, u), self._buf(M, u)
+        (g1, b1), (g2, b2), (g3, b3) = P[f"{n}.ln1"], P[f"{n}.ln2"], P[f"{n}.ln3"]
+        self._keep += [g1, b1, g2, b2, g3, b3]
+        self.ops.append((lib().dm3d_layernorm3_h2, (y.data_ptr(), M, u, LN_EPS, g1.data_ptr(), b1.data_ptr(), n1.data_ptr(),
+                                                    g2.data_ptr(), b2.data_ptr(), n2.data_ptr(), g3.data_ptr(), b3.data_ptr(),
+                                                    n3.data_ptr()), "layernorm", {}))
+        qkb, v_t, q2, hid = self._buf(M, 2 * u), self._buf(u, M), self._buf(M, u), self._buf(M, 4 * u)
+        self._gemm_group([
+            dict(a=n1, lda=u, b=qk.h2, ldb=qk.cin_pad, out=qkb, ldo=2 * u, m=M, n=2 * u, k=u, bias=qk.bias, out_h2=True, **hh),
+            dict(a=val.h2, lda=val.cin_pad, b=n1, ldb=u, out=v_t, ldo=M, m=u, n=M, k=u, bias=val.bias, bias_along_m=1,
+                 out_h2=True, **hh),
+            dict(a=n2, lda=u, b=qk.h2, ldb=qk.cin_pad, out=q2, ldo=u, m=M, n=u, k=u, bias=qk.bias, out_h2=True, **hh),
+            dict(a=n3, lda=u, b=m0.h2, ldb=m0.cin_pad, out=hid, ldo=4 * u, m=M, n=4 * u, k=u, bias=m0.bias, act=ACT_RELU,
+                 out_h2=True, **hh),
+        ])
+        rows = B if self.per_sample_context else 1
+        kctx, vctx_t = self._buf(rows, L * u), self._buf(rows, u * L)
+        self.ctx_bufs[n] = (kctx, vctx_t)
+        ks, vs = (L * u, u * L) if self.per_sample_context else (0, 0)
+        scores = self._buf(2, B, L, L)
+        s2 = B * L * L                                                        # element offset of the cross-attention scores
+        scale = float(u) ** -0.5
+        self._gemm_group([
+            dict(a=qkb, lda=2 * u, stride_a=L * 2 * u, b=qkb, b_off=u, ldb=2 * u, stride_b=L * 2 * u, out=scores, ldo=L,
+                 stride_o=L * L, m=L, n=L, k=u, batch=B, alpha=scale, **hh),
+            dict(a=q2, lda=u, stride_a=L * u, b=kctx, ldb=u, stride_b=ks, out=scores, out_off=s2, ldo=L, stride_o=L * L,
+                 m=L, n=L, k=u, batch=B, alpha=scale, **hh),
+        ])
+        self.ops.append((lib().dm3d_softmax_rows_h2, (scores.data_ptr(), 2 * B * L, L, L), "softmax", {}))
+        a1, a2 = self._buf(M, u), self._buf(M, u)
+        self._gemm_group([
+            dict(a=scores, lda=L, stride_a=L * L, b=v_t, ldb=M, stride_b=L, out=a1, ldo=u, stride_o=L * u, m=L, n=u, k=L,
+                 batch=B, res=y, ldr=u, stride_r=L * u, **hh),
+            dict(a=scores, a_off=s2, lda=L, stride_a=L * L, b=vctx_t, ldb=L, stride_b=vs, out=a2, ldo=u, stride_o=L * u,
+                 m=L, n=u, k=L, batch=B, **hh),
+        ])
+        a3 = self._buf(M, u)
+        self._gemm(a=hid, lda=4 * u, b=m1.h2, ldb=m1.cin_pad, out=a3, ldo=u, m=M, n=u, k=4 * u, bias=m1.bias, res=a1, res2=a2,
+                   ldr=u, out_h2=True, **hh)
+        out = self._buf(B, edge, edge, edge, u)
+        self._gemm(a=a3, lda=u, b=pout.h2, ldb=pout.cin_pad, out=out, ldo=u, m=M, n=u, k=u, bias=pout.bias, act=ACT_RELU,
+                   res=x, ldr=u, **hh)
         return out
 
     def _self_block(self, blk, x, edge):

@@ -137,9 +137,14 @@ typedef struct dm3d_gemm_desc {
     int32_t precision;          /* DM3D_PREC_F32 (all formats must be DM3D_FMT_F32) or DM3D_PREC_H3 */
     int32_t a_fmt, b_fmt;       /* H3: DM3D_FMT_F32 (split while staging) or DM3D_FMT_H2 (pre-split); k % 16 == 0 */
     int32_t out_fmt;            /* H3: DM3D_FMT_F32 or DM3D_FMT_H2 (n % 16 == 0, ldo % 16 == 0); res is always float32 */
+    const float* res2;          /* optional second float32 residual, same ldr / stride_r as res (needs res) */
 } dm3d_gemm_desc;
 
 int dm3d_gemm_tn(const dm3d_gemm_desc* d, void* stream);
+/* Up to 4 independent DM3D_PREC_H3 contractions with identical operand formats in ONE launch (grid.z enumerates the problems'
+ * batches).  The attention blocks' GEMMs are small (m = B*L rows, one workgroup per CU each); issuing the independent ones
+ * together (q|k, v^T, q2 and the MLP hidden layer; the two score products; the two P.V products) fills the chip. */
+int dm3d_gemm_tn_group(const dm3d_gemm_desc* descs, int32_t count, void* stream);
 
 /* dst(H2) = split(src * 2^exp2): one-time conversion of static operands (weights, context keys/values). k % 16 == 0 is
  * not required of src: columns k..round_up(k,16) of dst are zero filled; ld_dst % 16 == 0, ld_dst >= round_up(k,16). */
