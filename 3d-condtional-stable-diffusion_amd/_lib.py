@@ -28,6 +28,7 @@ class ConvDesc(C.Structure):
         ("pro_scale", _f32p), ("pro_shift", _f32p), ("vec", _f32p), ("vec_idx", _i32p), ("vec_ld", C.c_int32),
         ("relu", C.c_int32), ("res", _f32p), ("out", _f32p), ("cout", C.c_int32),
         ("precision", C.c_int32), ("w_exp", C.c_int32),
+        ("prelu_alpha", _f32p), ("relu_out", C.c_int32), ("transpose", C.c_int32),
     ]
 
 
@@ -67,6 +68,8 @@ SIGNATURES = {
     "dm3d_pack_weights_up": (C.c_int, [_f32p, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
     "dm3d_packed_weight_up_h3_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
     "dm3d_pack_weights_up_h3": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "dm3d_pack_weights_convt": (C.c_int, [_f32p, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
+    "dm3d_pack_weights_convt_h3": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "dm3d_conv3d_ndhwc": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "dm3d_gemm_tn": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "dm3d_gemm_tn_group": (C.c_int, [C.POINTER(GemmDesc), C.c_int32, C.c_void_p]),
@@ -80,6 +83,7 @@ SIGNATURES = {
     "dm3d_add_i32": (C.c_int, [_i32p, C.c_int32, C.c_int32, C.c_void_p]),
     "dm3d_randn": (C.c_int, [_f32p, C.c_int64, C.c_uint64, C.c_uint32, C.c_void_p]),
     "dm3d_gather_rows": (C.c_int, [_f32p, C.c_int32, _i32p, _f32p, C.c_int32, C.c_int32, C.c_void_p]),
+    "dm3d_vq_assign": (C.c_int, [_f32p, C.c_int64, C.c_int32, _f32p, C.c_int32, _f32p, _i32p, C.c_void_p]),
     "dm3d_graph_begin": (C.c_int, [C.c_void_p]),
     "dm3d_graph_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "dm3d_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),

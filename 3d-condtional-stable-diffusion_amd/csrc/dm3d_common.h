@@ -93,3 +93,15 @@ __device__ __forceinline__ float dm3d_up_weight(const float* __restrict__ w, int
                 acc += w[((long)((kd * 3 + kh) * 3 + kw) * cin + ci) * cout + co];
     return acc;
 }
+
+// Weight of tap2 of the 2x2x2 conv that reproduces, for output parity par, Conv3DTranspose(k=4, strides=2, padding="same")
+// (reference vqvae3d_monai.py:373-377).  Forward conv y[i] = sum_k x[2i+k-1] w[k]; its transpose out[j] = sum_{2i+k-1=j} y[i] w[k]:
+// j = 2m reads y[m-1] w[3] + y[m] w[1]; j = 2m+1 reads y[m] w[2] + y[m+1] w[0].  Keras layout [kd,kh,kw,Cout,Cin].
+__device__ __forceinline__ float dm3d_convt_weight(const float* __restrict__ w, int cin, int cout, int par, int tap2, int ci, int co) {
+    const int pa[3] = {par >> 2, (par >> 1) & 1, par & 1};
+    const int tt[3] = {tap2 >> 2, (tap2 >> 1) & 1, tap2 & 1};
+    int k[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) k[ax] = pa[ax] == 0 ? (tt[ax] == 0 ? 3 : 1) : (tt[ax] == 0 ? 2 : 0);
+    return w[((long)((k[0] * 4 + k[1]) * 4 + k[2]) * cout + co) * cin + ci];
+}

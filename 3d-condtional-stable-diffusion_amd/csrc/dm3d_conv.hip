@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_f32(const ConvArgs p) {
     // epilogue: + bias + vec[row(b)] -> relu -> + res -> store.  Lanes 0..31 cover 32 consecutive output channels.
     // Loads are unconditional on clamped indices; only the stores are predicated.
     const int vrow = p.vec ? (p.vec_idx ? p.vec_idx[b] : b) : 0;
+    const size_t sample_elems = (size_t)p.fd * p.fh * p.fw * p.cout;
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         const int n = n0 + wn * (NT / WN) + nr * 32 + l32;
@@ -196,7 +197,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_f32(const ConvArgs p) {
             for (int r = 0; r < 16; ++r) {
                 float v = acc[mr][nr][r] + add;
                 if (p.relu) v = fmaxf(v, 0.0f);
+                if (p.prelu) { const float al = p.prelu[o[r] % sample_elems]; v = v > 0.0f ? v : al * v; }
                 if (p.res) v += rv[r];
+                if (p.relu_out) v = fmaxf(v, 0.0f);
                 if (ok[r]) p.out[o[r]] = v;
             }
         }
@@ -227,8 +230,9 @@ int launch_conv(ConvArgs& a, hipStream_t st) {
 extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
     DM3D_REQUIRE(d != nullptr, "conv: null descriptor");
     DM3D_REQUIRE(d->x1 && d->wpk && d->out, "conv: x1/wpk/out must be non-null");
-    DM3D_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv: ksize %d not in {1,3}", d->ksize);
+    DM3D_REQUIRE(d->ksize == 1 || d->ksize == 3 || (d->ksize == 4 && d->stride == 2), "conv: ksize %d not in {1,3} (4 needs stride 2)", d->ksize);
     DM3D_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride %d not in {1,2}", d->stride);
+    DM3D_REQUIRE(!d->transpose || (d->ksize == 4 && d->stride == 2 && !d->upsample), "conv: transpose needs ksize 4, stride 2, no upsample");
     DM3D_REQUIRE(!(d->upsample && d->stride != 1), "conv: upsample requires stride 1");
     DM3D_REQUIRE(!(d->ksize == 1 && (d->stride != 1 || d->upsample)), "conv: ksize 1 supports stride 1 without upsample only");
     DM3D_REQUIRE(d->batch > 0 && d->in_d > 0 && d->in_h > 0 && d->in_w > 0 && d->cout > 0, "conv: non-positive extent");
@@ -248,16 +252,18 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
     // Logical output domain the bricks tile.  upsample: the k3 conv on the nearest-2x upsampled tensor is evaluated as 8
     // 2x2x2 convs (one per output parity) on the low-resolution input, so the domain is the input extent and results are
     // scattered with stride 2 into the full output.
+    const bool par_mode = d->upsample || d->transpose;      // both run as 8 parity 2x2x2 convs on the input grid
+    const int cstride = par_mode ? 1 : d->stride;
     a.lgd = d->in_d; a.lgh = d->in_h; a.lgw = d->in_w;
-    a.od = (d->in_d + d->stride - 1) / d->stride;
-    a.oh = (d->in_h + d->stride - 1) / d->stride;
-    a.ow = (d->in_w + d->stride - 1) / d->stride;
-    a.parity = d->upsample ? 1 : 0;
-    a.os = d->upsample ? 2 : 1;
+    a.od = (d->in_d + cstride - 1) / cstride;
+    a.oh = (d->in_h + cstride - 1) / cstride;
+    a.ow = (d->in_w + cstride - 1) / cstride;
+    a.parity = par_mode ? 1 : 0;
+    a.os = par_mode ? 2 : 1;
     a.fd = a.od * a.os; a.fh = a.oh * a.os; a.fw = a.ow * a.os;
     // TF SAME: total = max((out-1)*stride + k - in, 0), zeros in front = total/2 (k=3: stride 1 -> 1; stride 2 -> 0 on even
     // sizes, 1 on odd sizes).  In parity mode the kernel derives the pads from the parity bits.
-    auto pad_front = [&](int in, int out) { int t = (out - 1) * d->stride + d->ksize - in; return t > 0 ? t / 2 : 0; };
+    auto pad_front = [&](int in, int out) { int t = (out - 1) * cstride + d->ksize - in; return t > 0 ? t / 2 : 0; };
     a.padz = pad_front(a.lgd, a.od); a.pady = pad_front(a.lgh, a.oh); a.padx = pad_front(a.lgw, a.ow);
     const int cin = d->c1 + d->c2;
     a.cinpad = (int)dm3d_round_up(cin, DM3D_CIN_PAD);
@@ -266,13 +272,15 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
     a.wpk = d->wpk; a.bias = d->bias; a.pscale = d->pro_scale; a.pshift = d->pro_shift;
     a.vec = d->vec; a.vec_idx = d->vec_idx; a.vec_ld = d->vec_ld;
     a.relu = d->relu; a.res = d->res; a.out = d->out; a.cout = d->cout;
+    a.prelu = d->prelu_alpha; a.relu_out = d->relu_out;
     a.batch = d->batch;
     DM3D_REQUIRE(d->precision == DM3D_PREC_F32 || d->precision == DM3D_PREC_H3, "conv: unknown precision %d", d->precision);
     DM3D_REQUIRE(d->w_exp >= -100 && d->w_exp <= 100, "conv: w_exp %d out of range", d->w_exp);
     a.out_scale = d->precision == DM3D_PREC_H3 ? ldexpf(1.0f, -d->w_exp) : 1.0f;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int which = d->upsample ? DM3D_CONV_UP : (d->ksize == 1 ? DM3D_CONV_K1 : (d->stride == 2 ? DM3D_CONV_K3S2 : DM3D_CONV_K3S1));
-    if (d->upsample) a.w_parity_stride = d->precision == DM3D_PREC_H3
+    const int which = par_mode ? DM3D_CONV_UP
+                               : (d->ksize == 1 ? DM3D_CONV_K1 : (d->ksize == 4 ? DM3D_CONV_K4S2 : (d->stride == 2 ? DM3D_CONV_K3S2 : DM3D_CONV_K3S1)));
+    if (par_mode) a.w_parity_stride = d->precision == DM3D_PREC_H3
         ? dm3d_packed_weight_h3_bytes(8, cin, d->cout) / 2 : dm3d_packed_weight_elems(8, cin, d->cout);
     return d->precision == DM3D_PREC_H3 ? dm3d_conv_launch_h3(a, which, st) : dm3d_conv_launch_f32(a, which, st);
 }
@@ -281,5 +289,6 @@ int dm3d_conv_launch_f32(ConvArgs& a, int which, hipStream_t st) {
     if (which == DM3D_CONV_UP) return launch_conv<4, 8, 8, 1, 2, 4, 1>(a, st);
     if (which == DM3D_CONV_K1) return launch_conv<4, 8, 8, 1, 1, 4, 1>(a, st);
     if (which == DM3D_CONV_K3S2) return launch_conv<2, 4, 8, 2, 3, 2, 2>(a, st);
+    if (which == DM3D_CONV_K4S2) return launch_conv<2, 4, 8, 2, 4, 2, 2>(a, st);
     return launch_conv<4, 8, 8, 1, 3, 4, 1>(a, st);
 }

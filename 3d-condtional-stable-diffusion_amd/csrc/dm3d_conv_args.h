@@ -18,6 +18,7 @@ struct ConvArgs {
     const float* bias; const float* pscale; const float* pshift;
     const float* vec; const int* vec_idx; int vec_ld;
     int relu; const float* res; float* out; int cout;
+    const float* prelu; int relu_out;      // PReLU slope [od*os, oh*os, ow*os, cout] before res; ReLU after res
     int bd, bh, bw;           // bricks per volume along d, h, w
     int nchunks;
     int batch;
@@ -25,7 +26,7 @@ struct ConvArgs {
 };
 
 // which tile configuration a (ksize, stride) pair uses
-enum { DM3D_CONV_K3S1 = 0, DM3D_CONV_K3S2 = 1, DM3D_CONV_K1 = 2, DM3D_CONV_UP = 3 };
+enum { DM3D_CONV_K3S1 = 0, DM3D_CONV_K3S2 = 1, DM3D_CONV_K1 = 2, DM3D_CONV_UP = 3, DM3D_CONV_K4S2 = 4 };
 
 int dm3d_conv_launch_f32(ConvArgs& a, int which, hipStream_t st);
 int dm3d_conv_launch_h3(ConvArgs& a, int which, hipStream_t st);

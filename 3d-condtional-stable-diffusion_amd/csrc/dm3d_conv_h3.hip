@@ -40,7 +40,7 @@ __device__ __forceinline__ void row_to_yx(int i, int& dy, int& dx) {
     else dy = g1 ? 2 + sel : sel;
 }
 
-template <int TD, int TH, int TW, int S, int KS, int WM, int WN, int MINW>
+template <int TD, int TH, int TW, int S, int KS, int WM, int WN, int MINW, int NRA = 0>
 __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
     constexpr int CK = 16, NT = 64;
     constexpr int TM = TD * TH * TW;
@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
     constexpr int TAPS = KS * KS * KS;
     constexpr int G = KS;                       // taps per weight group (one kw row), TAPS / G groups per chunk
     constexpr int NG = TAPS / G;
-    constexpr int MR = TM / WM / 32, NR = NT / WN / 32;
+    // NRA > 0: Cout <= 32*NRA, only the first NRA column tiles are computed (conv_in / conv_out); the weight image keeps 64 rows
+    constexpr int MR = TM / WM / 32, NR = NRA > 0 ? NRA : NT / WN / 32;
     constexpr int NSLOT = (HVOX * 2 + 255) / 256;          // (voxel, 8-channel piece) slots per thread
     constexpr int WGRP = G * NT * REC;                      // halfs per weight group
     constexpr int WPIECES = WGRP * 2 / 16;                  // 16-byte pieces per group
@@ -287,6 +288,8 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
         const size_t zbase = (((size_t)b * p.fd + (z_ok ? oz * p.os + ooz : 0)) * p.fh) * p.fw * p.cout;
         float* outz = p.out + zbase;
         const float* resz = p.res ? p.res + zbase : nullptr;
+        // PReLU slope tensor is [fd, fh, fw, cout] without a batch axis: same z-slice offset minus the sample base
+        const float* prz = p.prelu ? p.prelu + (zbase - (size_t)b * p.fd * p.fh * p.fw * p.cout) : nullptr;
         int rowoff[4], oyq[4], oxq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -311,10 +314,13 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+                    const int o = rowoff[r >> 2] + (r & 3) * cstep + n;
                     float v = fmaf(acc[mr][nr][r], p.out_scale, add);
                     if (p.relu) v = fmaxf(v, 0.0f);
+                    if (prz) { const float al = prz[o]; v = v > 0.0f ? v : al * v; }
                     if (resz) v += rv[r];
-                    outz[rowoff[r >> 2] + (r & 3) * cstep + n] = v;
+                    if (p.relu_out) v = fmaxf(v, 0.0f);
+                    outz[o] = v;
                 }
             } else {
 #pragma unroll
@@ -324,7 +330,9 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
                     const int o = ok ? rowoff[q] + c * cstep + n : 0;
                     float v = fmaf(acc[mr][nr][r], p.out_scale, add);
                     if (p.relu) v = fmaxf(v, 0.0f);
+                    if (prz) { const float al = prz[o]; v = v > 0.0f ? v : al * v; }
                     if (resz) v += resz[o];
+                    if (p.relu_out) v = fmaxf(v, 0.0f);
                     if (ok) outz[o] = v;
                 }
             }
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
     }
 }
 
-template <int TD, int TH, int TW, int S, int KS, int WM, int WN, int MINW>
+template <int TD, int TH, int TW, int S, int KS, int WM, int WN, int MINW, int NRA = 0>
 int launch_h3(ConvArgs& a, hipStream_t st) {
     constexpr int HW = (TW - 1) * S + KS;
     constexpr int HWP = (S == 1 && TH % 4 == 0 && TW == 8 && KS >= 2) ? 12 : HW;
@@ -344,12 +352,12 @@ int launch_h3(ConvArgs& a, hipStream_t st) {
     a.bw = (a.ow + TW - 1) / TW;
     static bool attr_set = false;
     if (!attr_set) {
-        DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3<TD, TH, TW, S, KS, WM, WN, MINW>),
+        DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3<TD, TH, TW, S, KS, WM, WN, MINW, NRA>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64), a.parity ? 8u : 1u);
-    hipLaunchKernelGGL((conv3d_igemm_h3<TD, TH, TW, S, KS, WM, WN, MINW>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3d_igemm_h3<TD, TH, TW, S, KS, WM, WN, MINW, NRA>), grid, dim3(256), lds, st, a);
     return dm3d_launch_check("conv3d_igemm_h3");
 }
 
@@ -358,7 +366,8 @@ int launch_h3(ConvArgs& a, hipStream_t st) {
 __global__ __launch_bounds__(256) void pack_weights_h3_kernel(const float* __restrict__ w, int taps, int cin, int cout,
                                                               int nchunks, int ntiles, float scale, const float* in_scale,
                                                               _Float16* __restrict__ out, int up) {
-    // up: w is the 3x3x3 kernel of an UpSample conv, taps == 8, and 8 parity images follow each other (dm3d_up_weight)
+    // up == 1: w is the 3x3x3 kernel of an UpSample conv; up == 2: the [4,4,4,Cout,Cin] kernel of a Conv3DTranspose(k4,s2).
+    // In both cases taps == 8 and 8 parity images follow each other (dm3d_up_weight / dm3d_convt_weight)
     const long nrec = (long)ntiles * nchunks * taps * 64;
     for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < nrec * 16 * (up ? 8 : 1); i0 += (long)gridDim.x * 256) {
         const int par = (int)(i0 / (nrec * 16));
@@ -372,7 +381,8 @@ __global__ __launch_bounds__(256) void pack_weights_h3_kernel(const float* __res
         const int ci = chunk * 16 + k, co = nt * 64 + nn;
         float v = 0.f;
         if (ci < cin && co < cout) {
-            v = up ? dm3d_up_weight(w, cin, cout, par, tap, ci, co) : w[((long)tap * cin + ci) * cout + co];
+            v = up == 1 ? dm3d_up_weight(w, cin, cout, par, tap, ci, co)
+              : up == 2 ? dm3d_convt_weight(w, cin, cout, par, tap, ci, co) : w[((long)tap * cin + ci) * cout + co];
             if (in_scale) v *= in_scale[ci];
             v *= scale;
         }
@@ -391,6 +401,8 @@ int dm3d_conv_launch_h3(ConvArgs& a, int which, hipStream_t st) {
     if (which == DM3D_CONV_UP) return launch_h3<4, 8, 8, 1, 2, 4, 1, 2>(a, st);
     if (which == DM3D_CONV_K1) return launch_h3<4, 8, 8, 1, 1, 4, 1, 2>(a, st);
     if (which == DM3D_CONV_K3S2) return launch_h3<2, 4, 8, 2, 3, 2, 2, 2>(a, st);
+    if (which == DM3D_CONV_K4S2) return launch_h3<2, 4, 8, 2, 4, 2, 2, 1>(a, st);
+    if (a.cout <= 32) return launch_h3<4, 8, 8, 1, 3, 4, 1, 2, 1>(a, st);     // conv_in / conv_out: half the MFMAs
     return launch_h3<4, 8, 8, 1, 3, 4, 1, 2>(a, st);
 }
 
@@ -423,4 +435,14 @@ extern "C" int dm3d_pack_weights_up_h3(const float* keras_kernel, int32_t cin, i
     hipLaunchKernelGGL(pack_weights_h3_kernel, dim3(4096), dim3(256), 0, static_cast<hipStream_t>(stream), keras_kernel, 8, cin,
                        cout, nchunks, ntiles, ldexpf(1.0f, w_exp), nullptr, static_cast<_Float16*>(packed), 1);
     return dm3d_launch_check("pack_weights_h3_kernel(up)");
+}
+
+extern "C" int dm3d_pack_weights_convt_h3(const float* keras_kernel, int32_t cin, int32_t cout, int32_t w_exp, void* packed,
+                                          void* stream) {
+    DM3D_REQUIRE(keras_kernel && packed && cin > 0 && cout > 0, "pack_weights_convt_h3: bad arguments");
+    DM3D_REQUIRE(w_exp >= -100 && w_exp <= 100 && dm3d_aligned16(packed), "pack_weights_convt_h3: w_exp out of range or packed unaligned");
+    const int nchunks = (int)(dm3d_round_up(cin, 16) / 16), ntiles = (int)(dm3d_round_up(cout, 64) / 64);
+    hipLaunchKernelGGL(pack_weights_h3_kernel, dim3(4096), dim3(256), 0, static_cast<hipStream_t>(stream), keras_kernel, 8, cin,
+                       cout, nchunks, ntiles, ldexpf(1.0f, w_exp), nullptr, static_cast<_Float16*>(packed), 2);
+    return dm3d_launch_check("pack_weights_h3_kernel(convt)");
 }

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 
 // upsample variant: 8 parity images of a taps=8 conv (see dm3d_up_weight)
 __global__ __launch_bounds__(256) void pack_weights_up_kernel(const float* __restrict__ w, int cin, int cout, int cinpad,
-                                                              int coutpad, float* __restrict__ out) {
+                                                              int coutpad, float* __restrict__ out, int convt) {
     const long per = (long)8 * coutpad * cinpad;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < 8 * per; i += (long)gridDim.x * 256) {
         const int par = (int)(i / per);
@@ -355,8 +355,35 @@ __global__ __launch_bounds__(256) void pack_weights_up_kernel(const float* __res
         const int ci = (int)(j % cinpad);
         const int co = (int)((j / cinpad) % coutpad);
         const int tap = (int)(j / ((long)cinpad * coutpad));
-        out[i] = (ci < cin && co < cout) ? dm3d_up_weight(w, cin, cout, par, tap, ci, co) : 0.f;
+        out[i] = (ci < cin && co < cout) ? (convt ? dm3d_convt_weight(w, cin, cout, par, tap, ci, co)
+                                                  : dm3d_up_weight(w, cin, cout, par, tap, ci, co)) : 0.f;
     }
+}
+
+// ---- VectorQuantizer.get_code_indices (reference networks/vqvae3d_monai.py:164-177): distances = |z|^2 + |e_k|^2 - 2 z.e_k in
+// float32 in that order, argmin with the lowest index on ties.  sim = z.E comes from the GEMM; one wavefront per row. ----
+__global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict__ z, long rows, int d, const float* __restrict__ sim,
+                                                        int k, const float* __restrict__ esq, int* __restrict__ idx) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float zs = 0.f;
+    for (int i = lane; i < d; i += 64) { const float v = z[row * d + i]; zs += v * v; }
+    zs = wave_sum(zs);
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    const float* srow = sim + row * k;
+    for (int j = lane; j < k; j += 64) {
+        const float dist = __fsub_rn(__fadd_rn(zs, esq[j]), __fmul_rn(2.0f, srow[j]));
+        if (dist < best) { best = dist; bi = j; }           // ascending j per lane: first minimum kept
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) idx[row] = bi;
 }
 
 inline unsigned grid_for(long n, int cap = 256 * 8) {
@@ -495,6 +522,22 @@ extern "C" int dm3d_pack_weights_up(const float* keras_kernel, int32_t cin, int3
     DM3D_REQUIRE(keras_kernel && packed && cin > 0 && cout > 0, "pack_weights_up: bad arguments");
     const int cinpad = (int)dm3d_round_up(cin, DM3D_CIN_PAD), coutpad = (int)dm3d_round_up(cout, DM3D_COUT_PAD);
     hipLaunchKernelGGL(pack_weights_up_kernel, dim3(grid_for((long)64 * cinpad * coutpad)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), keras_kernel, cin, cout, cinpad, coutpad, packed);
+                       static_cast<hipStream_t>(stream), keras_kernel, cin, cout, cinpad, coutpad, packed, 0);
     return dm3d_launch_check("pack_weights_up_kernel");
+}
+
+extern "C" int dm3d_pack_weights_convt(const float* keras_kernel, int32_t cin, int32_t cout, float* packed, void* stream) {
+    DM3D_REQUIRE(keras_kernel && packed && cin > 0 && cout > 0, "pack_weights_convt: bad arguments");
+    const int cinpad = (int)dm3d_round_up(cin, DM3D_CIN_PAD), coutpad = (int)dm3d_round_up(cout, DM3D_COUT_PAD);
+    hipLaunchKernelGGL(pack_weights_up_kernel, dim3(grid_for((long)64 * cinpad * coutpad)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), keras_kernel, cin, cout, cinpad, coutpad, packed, 1);
+    return dm3d_launch_check("pack_weights_up_kernel(convt)");
+}
+
+extern "C" int dm3d_vq_assign(const float* z, int64_t rows, int32_t d, const float* sim, int32_t k, const float* esq,
+                              int32_t* idx, void* stream) {
+    DM3D_REQUIRE(z && sim && esq && idx && rows > 0 && d > 0 && k > 0, "vq_assign: bad arguments");
+    hipLaunchKernelGGL(vq_assign_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), z,
+                       (long)rows, d, sim, k, esq, idx);
+    return dm3d_launch_check("vq_assign_kernel");
 }

@@ -49,12 +49,13 @@ class DiffusionModel:
         self.timesteps = int(args.timesteps)
         self.b = Betas(self.timesteps)
         self.lc = latent_channels
-        # The VQ-VAE bracket (networks/vqvae3d_monai.py) is outside this path: the attributes
-        # exist, nothing is constructed.
+        # The VQ-VAE bracket (networks/vqvae3d_monai.py; conditional_dm3d.py:425-460) is built lazily on first use of
+        # .vqvae_trainer / .encoder / .quantizer / .decoder — Keras, too, creates its weights only on the first call.
         self.num_embed = num_embed
         self.vqvae_load_ckpt = vqvae_load_ckpt
-        self.vqvae_trainer = None
-        self.encoder = self.quantizer = self.decoder = None
+        self._vqvae = None
+        self._kernel_resize = getattr(args, "kernel_resize", False)
+        self._precision = precision
         self.network = UNet(
             UNetConfig(img_size=latent_size, img_channels=latent_channels, widths=[64, 128, 256],
                        has_attention=[False, False, True, True], conditional=self.conditional),
@@ -65,6 +66,41 @@ class DiffusionModel:
         self.device = self.network.device
         self._graphs = {}
         self._stream = None
+
+    # -- the autoencoder bracket --------------------------------------------------------------------------------------
+    @property
+    def vqvae_trainer(self):
+        """VQVAE(in=1, out=1, channels (32,64,128,256), 5 residual layers, 4 x (stride 2, k4), num_embeddings=num_embed,
+        embedding_dim=latent_channels) as in conditional_dm3d.py:425-449; input edge = 16 x latent_size (128 for the
+        reference's latent_size 8)."""
+        if self._vqvae is None:
+            from .networks.vqvae3d_monai import VQVAE
+            self._vqvae = VQVAE(
+                in_channels=1, out_channels=1, num_channels=(32, 64, 128, 256), num_res_channels=(32, 64, 128, 256),
+                num_res_layers=5, downsample_parameters=((2, 4, 1, "same"),) * 4,
+                upsample_parameters=((2, 4, 1, "same", 0),) * 4, num_embeddings=self.num_embed, embedding_dim=self.lc,
+                dropout=None, num_gpus=self.num_gpus, kernel_resize=self._kernel_resize,
+                input_size=16 * self.network.cfg.img_size, device=self.device, precision=self._precision)
+            if self.vqvae_load_ckpt is not None:
+                print("Loading VQVAE weights")
+                self._vqvae.load_weights(self.vqvae_load_ckpt)
+        return self._vqvae
+
+    @vqvae_trainer.setter
+    def vqvae_trainer(self, v):
+        self._vqvae = v
+
+    @property
+    def encoder(self):
+        return self.vqvae_trainer.encoder
+
+    @property
+    def quantizer(self):
+        return self.vqvae_trainer.quantizer
+
+    @property
+    def decoder(self):
+        return self.vqvae_trainer.decoder
 
     # -- Keras-model conveniences the reference's drivers touch ----------------------------------------------------
     @property
@@ -90,10 +126,16 @@ class DiffusionModel:
             pass
 
     def train_step(self, inputs):
-        """conditional_dm3d.py:471-510.  Needs the frozen VQ encoder (next-1) and the backward kernels (next-2)."""
+        """conditional_dm3d.py:471-510.  The forward half that precedes the network call exists (``q_sample`` below, on the
+        frozen encoder + quantizer); the network in training mode and the weight update need batch-statistics
+        BatchNormalization and the backward kernels."""
         raise NotImplementedError(
-            "train_step is not built in this round: it needs batch-statistics BatchNormalization, the backward kernels "
-            "and the VQ-VAE encoder (SURVEY.md §8(f) next-1/next-2). There is deliberately no PyTorch-autograd fallback.")
+            "train_step is not built in this round: it needs batch-statistics BatchNormalization and the backward kernels "
+            "(SURVEY.md §8(f) next-2). There is deliberately no PyTorch-autograd fallback.")
+
+    def encode_latents(self, images):
+        """train_step's first half (conditional_dm3d.py:478): latents, _ = quantizer(encoder(images))."""
+        return self.quantizer(self.encoder(images))[0]
 
     # -- a13: sample ------------------------------------------------------------------------------------------------
     def _ddpm_desc(self, x, eps, t_idx, mode, noise=None, seed=0, mean_out=None, var_out=None) -> DdpmDesc:
@@ -184,8 +226,19 @@ class DiffusionModel:
         return self._graphs[key]
 
     def test(self, test_prefix, context=None):
-        """conditional_dm3d.py:577-594 decodes through the VQ-VAE, which is outside this path."""
-        raise NotImplementedError("test() needs the VQ-VAE decoder (SURVEY.md §8(f) next-1); use generate()")
+        """conditional_dm3d.py:577-594: generate 10 latents, decode them, np.save the images.  The reference hard-codes the
+        latent shape (10,16,16,16,64); here it is (10, latent_size^3, latent_channels), identical for its test setting."""
+        import os
+        for i in [self.timesteps]:
+            print(f"Generating for {i} rsteps")
+            if self.vqvae_load_ckpt is not None:
+                self.vqvae_trainer.load_weights(self.vqvae_load_ckpt)
+            e = self.network.cfg.img_size
+            img_latents = self.generate((10, e, e, e, self.lc), last_step=self.timesteps - i, context_value=context)
+            images = self.vqvae_trainer.decoder(img_latents)
+            os.makedirs("./generated_images_dm3d", exist_ok=True)
+            np.save(f"./generated_images_dm3d/{test_prefix}-{i}rsteps.npy", images.cpu().numpy())
+        return images
 
 
 class UnconditionalDiffusionModel(DiffusionModel):
@@ -201,7 +254,7 @@ class UnconditionalDiffusionModel(DiffusionModel):
         return super().generate(shape, last_step, None, **kw)
 
     def test(self, test_prefix):
-        raise NotImplementedError("test() needs the VQ-VAE decoder (SURVEY.md §8(f) next-1); use generate()")
+        return super().test(test_prefix, None)
 
 
 class Sampler:

@@ -77,8 +77,28 @@ def pack_weights_up(kernel: torch.Tensor, h3: bool = False):
     return out, w_exp
 
 
+def pack_weights_convt(kernel: torch.Tensor, h3: bool = False):
+    """[4,4,4,Cout,Cin] kernel of Conv3DTranspose(k=4, strides=2, padding="same") -> the 8 parity images that
+    dm3d_conv3d_ndhwc(transpose=1) expects.  Returns wpk (fp32) or (wpk, w_exp) (h3)."""
+    _f32c(kernel, "kernel")
+    if kernel.dim() != 5 or tuple(kernel.shape[:3]) != (4, 4, 4):
+        raise ValueError("kernel must be [4,4,4,cout,cin]")
+    cout, cin = kernel.shape[-2], kernel.shape[-1]
+    if not h3:
+        out = torch.empty(lib().dm3d_packed_weight_up_elems(cin, cout), dtype=torch.float32, device=kernel.device)
+        check(lib().dm3d_pack_weights_convt(kernel.data_ptr(), cin, cout, out.data_ptr(), _st()), "pack_weights_convt")
+        return out
+    import math
+    wmax = float(kernel.abs().max())
+    w_exp = 0 if wmax == 0.0 or not math.isfinite(wmax) else int(13 - math.floor(math.log2(wmax)))
+    out = torch.empty(lib().dm3d_packed_weight_up_h3_bytes(cin, cout) // 2, dtype=torch.float16, device=kernel.device)
+    check(lib().dm3d_pack_weights_convt_h3(kernel.data_ptr(), cin, cout, w_exp, out.data_ptr(), _st()), "pack_weights_convt_h3")
+    return out, w_exp
+
+
 def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False, pro_scale=None, pro_shift=None,
-           vec=None, vec_idx=None, relu=False, res=None, precision=_lib.PREC_F32, w_exp=0) -> torch.Tensor:
+           vec=None, vec_idx=None, relu=False, res=None, precision=_lib.PREC_F32, w_exp=0, prelu_alpha=None,
+           relu_out=False, transpose=False) -> torch.Tensor:
     """Conv3D(padding="same") on NDHWC with the fused prologue / concat / upsample / epilogue of dm3d_conv3d_ndhwc."""
     _f32c(x1, "x1")
     if x1.dim() != 5:
@@ -92,6 +112,8 @@ def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False
         c2 = x2.shape[4]
     up = 2 if upsample else 1
     od, oh, ow = (-(-D * up // stride), -(-H * up // stride), -(-W * up // stride))
+    if transpose:
+        od, oh, ow = 2 * D, 2 * H, 2 * W
     out = torch.empty(B, od, oh, ow, cout, dtype=torch.float32, device=x1.device)
     d = ConvDesc()
     d.x1, d.x2, d.c1, d.c2, d.batch = x1.data_ptr(), _p(x2), c1, c2, B
@@ -103,6 +125,9 @@ def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False
         raise ValueError("res must have the output's shape")
     d.relu, d.res, d.out, d.cout = int(bool(relu)), _p(res), out.data_ptr(), cout
     d.precision, d.w_exp = precision, w_exp
+    if prelu_alpha is not None and tuple(prelu_alpha.shape) != (od, oh, ow, cout):
+        raise ValueError("prelu_alpha must be [out_d, out_h, out_w, cout]")
+    d.prelu_alpha, d.relu_out, d.transpose = _p(prelu_alpha), int(bool(relu_out)), int(bool(transpose))
     check(lib().dm3d_conv3d_ndhwc(C.byref(d), _st()), "conv3d")
     return out
 
@@ -211,3 +236,22 @@ def randn(shape, seed: int, stream_id: int = 0, device="cuda") -> torch.Tensor:
     x = torch.empty(shape, dtype=torch.float32, device=device)
     check(lib().dm3d_randn(x.data_ptr(), x.numel(), seed, stream_id, _st()), "randn")
     return x
+
+
+def vq_assign(z: torch.Tensor, codebook_t: torch.Tensor, esq: torch.Tensor) -> torch.Tensor:
+    """Nearest-code indices (reference VectorQuantizer.get_code_indices): z [rows, D], codebook_t = E^T [K, D], esq [K]."""
+    _f32c(z, "z"), _f32c(codebook_t, "codebook_t")
+    rows, dd = z.shape
+    k = codebook_t.shape[0]
+    sim = gemm_tn(z, codebook_t)                         # exact float32 MFMA: z.E
+    idx = torch.empty(rows, dtype=torch.int32, device=z.device)
+    check(lib().dm3d_vq_assign(z.data_ptr(), rows, dd, sim.data_ptr(), k, esq.data_ptr(), idx.data_ptr(), _st()), "vq_assign")
+    return idx
+
+
+def gather_rows(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    _f32c(table, "table")
+    out = torch.empty(idx.numel(), table.shape[1], dtype=torch.float32, device=table.device)
+    check(lib().dm3d_gather_rows(table.data_ptr(), table.shape[0], idx.data_ptr(), out.data_ptr(), idx.numel(), table.shape[1],
+                                 _st()), "gather_rows")
+    return out

@@ -85,12 +85,20 @@ int     dm3d_pack_weights_up(const float* keras_kernel, int32_t cin, int32_t cou
 int64_t dm3d_packed_weight_up_h3_bytes(int32_t cin, int32_t cout);
 int     dm3d_pack_weights_up_h3(const float* keras_kernel, int32_t cin, int32_t cout, int32_t w_exp, void* packed, void* stream);
 
+/* Conv3DTranspose(k=4, strides=2, padding="same") kernels are [4,4,4,Cout,Cin] in Keras; packed as 8 parity images of a
+ * taps=8 conv like the UpSample case (same buffer sizes: dm3d_packed_weight_up_elems / _up_h3_bytes with cin, cout). */
+int     dm3d_pack_weights_convt(const float* keras_kernel, int32_t cin, int32_t cout, float* packed, void* stream);
+int     dm3d_pack_weights_convt_h3(const float* keras_kernel, int32_t cin, int32_t cout, int32_t w_exp, void* packed, void* stream);
+
 /* ---- Conv3D(padding="same") as implicit GEMM on MFMA ---------------------------------------------------------
  * Replaces layers.Conv3D for k=3/s=1 (:257-259, :348-353, :412-414), k=3/s=2 (DownSample :274-285, TF SAME pad 0
  * before / 1 after on even sizes), k=1 (ResidualBlock skip :245-248) and UpSampling3D(2)+Conv3D (UpSample :288-296,
  * upsample=1 reads the low-resolution tensor at index>>1).  Fused around it:
  *   prologue  x -> silu(x*pro_scale[c] + pro_shift[c])   (inference BatchNormalization + swish, :255-256, 262-263,
  *             410-411), applied before zero padding;
+ *   also      k=4/s=2 (VQ-VAE Encoder downsampling, vqvae3d_monai.py:266-273; SAME pad 1/1) and its transpose
+ *             (Decoder, :373-377): Conv3DTranspose k4 s2 is evaluated per output parity as a 2x2x2 conv on the input
+ *             (parity 0 reads sources {i-1,i} with taps w[3],w[1]; parity 1 reads {i,i+1} with w[2],w[0]);
  *   concat    channels of x1 then x2 (layers.Concatenate(axis=-1)([x, skip]), :396) without materialising it;
  *   epilogue  + bias[co] + vec[row(b)][co] (the time-embedding Dense broadcast-add, :250-253, 260) then optional
  *             ReLU, then + res (layers.Add with the residual, :268). */
@@ -101,7 +109,7 @@ typedef struct dm3d_conv_desc {
     int32_t batch;
     int32_t in_d, in_h, in_w;   /* physical extent of x1/x2 */
     int32_t upsample;           /* 1: convolve the nearest-2x upsampled tensor (stride must be 1) */
-    int32_t ksize;              /* 1 or 3 */
+    int32_t ksize;              /* 1 or 3; 4 with stride 2 (and with transpose) */
     int32_t stride;             /* 1 or 2 */
     const float* wpk;           /* dm3d_pack_weights[_h3] output for (ksize^3, c1+c2, cout); upsample: dm3d_pack_weights_up[_h3] */
     const float* bias;          /* [cout] or NULL */
@@ -116,6 +124,12 @@ typedef struct dm3d_conv_desc {
     int32_t cout;
     int32_t precision;          /* DM3D_PREC_F32: wpk from dm3d_pack_weights; DM3D_PREC_H3: wpk from dm3d_pack_weights_h3 */
     int32_t w_exp;              /* H3 only: the power-of-two exponent the weights were packed with */
+    /* autoencoder bracket (networks/vqvae3d_monai.py): */
+    const float* prelu_alpha;   /* keras PReLU() with its default full-shape slope [out_d,out_h,out_w,cout] (shared by the batch),
+                                   applied after bias/vec/relu and before res: v = v > 0 ? v : alpha*v; or NULL */
+    int32_t relu_out;           /* 1: ReLU after the residual add (VQVAEResidualUnit: ReLU(x + PReLU(BN(conv)))) */
+    int32_t transpose;          /* 1: Conv3DTranspose(k=4, strides=2, padding="same"): out = 2*in; wpk from
+                                   dm3d_pack_weights_convt[_h3]; ksize must be 4, stride 2, no upsample */
 } dm3d_conv_desc;
 
 int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream);
@@ -202,6 +216,12 @@ int dm3d_randn(float* x, int64_t n, uint64_t seed, uint32_t stream_id, void* str
 /* out[r][:] = table[idx[r]][:] (tf.gather / Embedding lookup, :358, 518-538). c % 4 == 0. */
 int dm3d_gather_rows(const float* table, int32_t table_rows, const int32_t* idx, float* out, int32_t rows,
                      int32_t c, void* stream);
+
+/* ---- VectorQuantizer.get_code_indices (vqvae3d_monai.py:164-177): idx[r] = argmin_k (|z_r|^2 + esq[k] - 2*sim[r][k]), float32 in
+ * that order, lowest index on ties.  sim = z.E [rows, k] comes from dm3d_gemm_tn; esq[k] = |e_k|^2.  The quantised vectors are
+ * then dm3d_gather_rows(E^T, idx). */
+int dm3d_vq_assign(const float* z, int64_t rows, int32_t d, const float* sim, int32_t k, const float* esq, int32_t* idx,
+                   void* stream);
 
 /* ---- HIP graph capture of one denoising step (replaces the eager per-op Python loop of generate, :559-573) -- */
 int dm3d_graph_begin(void* stream);

@@ -186,3 +186,31 @@ def ddpm_step(tab, x, eps, i, z):
     c2 = (1 - tab["alpha_bar_prev"][i]) * tab["sqrt_alpha"][i] / (1 - tab["alpha_bar"][i])
     var = (1 - tab["alpha_bar_prev"][i]) * tab["beta"][i] / (1 - tab["alpha_bar"][i])
     return np.clip(c1 * x0 + c2 * x, -1, 1) + math.sqrt(max(var, 1e-20)) * z
+
+
+# ---- next-1 pieces, re-derived from their definitions (reference networks/vqvae3d_monai.py) ---------------------------------
+def conv3d_transpose_k4s2(x, kernel, bias):
+    """Conv3DTranspose(k=4, strides=2, padding='same') as the literal transpose of the k4/s2 'same' convolution
+    y[i] = sum_k x[2i + k - 1] w[k]: every input voxel scatters into out[2i + k - 1].  kernel [kd,kh,kw,Cout,Cin]."""
+    B, D, H, Wd, _ = x.shape
+    out = np.zeros((B, 2 * D + 2, 2 * H + 2, 2 * Wd + 2, kernel.shape[3]))       # index + 1 so that k - 1 = -1 fits
+    for a in range(4):
+        for b in range(4):
+            for c in range(4):
+                out[:, a:a + 2 * D:2, b:b + 2 * H:2, c:c + 2 * Wd:2] += x @ kernel[a, b, c].T
+    return out[:, 1:2 * D + 1, 1:2 * H + 1, 1:2 * Wd + 1] + bias
+
+
+def prelu(x, alpha):
+    return np.where(x > 0, x, alpha * x)
+
+
+def vq_residual_unit(W, n, x):
+    h = np.maximum(conv3d_same(x, W[n + ".conv1.kernel"], W[n + ".conv1.bias"]), 0)
+    h = prelu(bn(conv3d_same(h, W[n + ".conv2.kernel"], W[n + ".conv2.bias"]), W, n + ".bn"), W[n + ".prelu.alpha"])
+    return np.maximum(x + h, 0)
+
+
+def vq_code_indices(E, z_flat):
+    d = (z_flat ** 2).sum(1, keepdims=True) + (E ** 2).sum(0) - 2 * (z_flat @ E)
+    return d.argmin(1)

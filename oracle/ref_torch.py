@@ -466,3 +466,159 @@ def train_loss(noise, pred_noise, global_bs: int, lc: int):
     mean over the channel axis, SUM over b*d*h*w, divided by global_bs*lc^4."""
     mse_sum = ((noise - pred_noise) ** 2).mean(-1).sum()
     return mse_sum / (global_bs * lc * lc * lc * lc * 1.0)
+
+
+# ==============================================================================================================
+# next-1 (SURVEY.md §8(f)): the VQ-VAE bracket around the sampler — reference networks/vqvae3d_monai.py (abbreviated V:)
+# Encoder V:237-306, VectorQuantizer V:112-177, VQVAEResidualUnit V:218-234, Decoder V:309-391, as wired by
+# DiffusionModel (C:425-460): latents = quantizer(encoder(images))[0] in training, decoder(latents) after sampling.
+# Keras semantics: Conv3D(k=4, strides=2, padding="same") pads 1/1; Conv3DTranspose(k=4, strides=2, padding="same") has
+# out = 2*in and kernel [kd,kh,kw,Cout,Cin]; PReLU() has a full-shape slope [D,H,W,C]; BatchNormalization eps 1e-3.
+# ==============================================================================================================
+@dataclass
+class VQVAEConfig:
+    in_channels: int = 1
+    out_channels: int = 1
+    num_channels: Sequence[int] = (32, 64, 128, 256)
+    num_res_layers: int = 5
+    num_res_channels: Sequence[int] = (32, 64, 128, 256)
+    num_embeddings: int = 1024
+    embedding_dim: int = 256
+    input_size: int = 128              # PReLU slopes are full-shape, so the model is tied to its input size
+    output_act: bool = False
+
+    @property
+    def latent_size(self) -> int:
+        return self.input_size >> len(self.num_channels)
+
+
+def _res_unit_spec(spec, name, ch, rc, edge):
+    spec[f"{name}.conv1.kernel"] = (3, 3, 3, ch, rc)
+    spec[f"{name}.conv1.bias"] = (rc,)
+    spec[f"{name}.conv2.kernel"] = (3, 3, 3, rc, ch)
+    spec[f"{name}.conv2.bias"] = (ch,)
+    _bn(spec, f"{name}.bn", ch)
+    spec[f"{name}.prelu.alpha"] = (edge, edge, edge, ch)
+
+
+def vqvae_param_spec(cfg: VQVAEConfig) -> Dict[str, Tuple[int, ...]]:
+    spec: Dict[str, Tuple[int, ...]] = {}
+    ch_in, edge = cfg.in_channels, cfg.input_size
+    for i, ch in enumerate(cfg.num_channels):                          # Encoder V:266-291
+        edge //= 2
+        spec[f"enc.down{i}.kernel"] = (4, 4, 4, ch_in, ch)
+        spec[f"enc.down{i}.bias"] = (ch,)
+        for j in range(cfg.num_res_layers):
+            _res_unit_spec(spec, f"enc.l{i}.res{j}", ch, cfg.num_res_channels[i], edge)
+        ch_in = ch
+    spec["enc.out.kernel"] = (3, 3, 3, ch_in, cfg.embedding_dim)       # V:296-301
+    spec["enc.out.bias"] = (cfg.embedding_dim,)
+    spec["enc.out_prelu.alpha"] = (edge, edge, edge, cfg.embedding_dim)
+    spec["vq.embeddings"] = (cfg.embedding_dim, cfg.num_embeddings)    # V:125-131
+    rev, rrev = list(reversed(cfg.num_channels)), list(reversed(cfg.num_res_channels))
+    spec["dec.in.kernel"] = (3, 3, 3, cfg.embedding_dim, rev[0])       # V:346-350
+    spec["dec.in.bias"] = (rev[0],)
+    spec["dec.in_prelu.alpha"] = (edge, edge, edge, rev[0])
+    for i, ch in enumerate(rev):                                       # V:353-381
+        for j in range(cfg.num_res_layers):
+            _res_unit_spec(spec, f"dec.l{i}.res{j}", ch, rrev[i], edge)
+        out = cfg.out_channels if i == len(rev) - 1 else rev[i + 1]
+        spec[f"dec.up{i}.kernel"] = (4, 4, 4, out, ch)                 # Conv3DTranspose: [k,k,k,Cout,Cin]
+        spec[f"dec.up{i}.bias"] = (out,)
+        edge *= 2
+    return spec
+
+
+def vqvae_synthetic_weights(cfg: VQVAEConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded non-degenerate weights: glorot-uniform kernels, small biases, random BN statistics, PReLU slopes U(0.05, 0.45)
+    (Keras initialises them to 0 = ReLU, which would hide the slope path), codebook N(0,1)."""
+    g = np.random.default_rng(seed)
+    out = {}
+    for name, shape in vqvae_param_spec(cfg).items():
+        if name.endswith(".kernel"):
+            rf = int(np.prod(shape[:3]))
+            lim = math.sqrt(6.0 / (shape[3] * rf + shape[4] * rf))
+            arr = g.uniform(-lim, lim, size=shape)
+        elif name.endswith(".alpha"):
+            arr = g.uniform(0.05, 0.45, size=shape)
+        elif name.endswith(".embeddings"):
+            arr = g.normal(0.0, 1.0, size=shape)
+        elif name.endswith(".gamma"):
+            arr = g.uniform(0.8, 1.2, size=shape)
+        elif name.endswith(".var"):
+            arr = g.uniform(0.5, 1.5, size=shape)
+        elif name.endswith((".beta", ".mean")):
+            arr = g.normal(0.0, 0.1, size=shape)
+        elif name.endswith(".bias"):
+            arr = g.normal(0.0, 0.05, size=shape)
+        else:
+            raise KeyError(name)
+        out[name] = torch.from_numpy(arr.astype(np.float32))
+    return out
+
+
+def _conv3d_k4s2(x, kernel, bias):
+    """Conv3D(k=4, strides=2, padding='same') on even sizes: total pad 2 -> 1 before, 1 after (V:269-273)."""
+    y = F.conv3d(x.permute(0, 4, 1, 2, 3), kernel.permute(4, 3, 0, 1, 2), bias, stride=2, padding=1)
+    return y.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _conv3d_transpose_k4s2(x, kernel, bias):
+    """Conv3DTranspose(k=4, strides=2, padding='same'): out = 2*in; Keras kernel [kd,kh,kw,Cout,Cin] (V:373-377).
+    It is the transpose of the k4/s2 'same' convolution above, i.e. conv_transpose3d(stride 2, padding 1)."""
+    w = kernel.permute(4, 3, 0, 1, 2)                   # torch conv_transpose3d weight: [Cin, Cout, kd, kh, kw]
+    y = F.conv_transpose3d(x.permute(0, 4, 1, 2, 3), w, bias, stride=2, padding=1)
+    return y.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _prelu(x, alpha):
+    return torch.where(x > 0, x, alpha * x)
+
+
+def vq_residual_unit(W, name, x):
+    """V:225-234: ReLU(x + PReLU(BN(Conv3(relu(Conv3(x))))))."""
+    h = torch.relu(_conv3d(x, W[f"{name}.conv1.kernel"], W[f"{name}.conv1.bias"]))
+    h = _conv3d(h, W[f"{name}.conv2.kernel"], W[f"{name}.conv2.bias"])
+    h = _prelu(_bn_infer(h, W, f"{name}.bn"), W[f"{name}.prelu.alpha"])
+    return torch.relu(x + h)
+
+
+def vq_encoder(W, cfg: VQVAEConfig, x):
+    h = x
+    for i in range(len(cfg.num_channels)):
+        h = torch.relu(_conv3d_k4s2(h, W[f"enc.down{i}.kernel"], W[f"enc.down{i}.bias"]))
+        for j in range(cfg.num_res_layers):
+            h = vq_residual_unit(W, f"enc.l{i}.res{j}", h)
+    h = _conv3d(h, W["enc.out.kernel"], W["enc.out.bias"])
+    return _prelu(h, W["enc.out_prelu.alpha"])
+
+
+def vq_code_indices(W, z_flat):
+    """V:164-177: argmin_k(|z|^2 + |e_k|^2 - 2 z.e_k)."""
+    E = W["vq.embeddings"]
+    sim = z_flat @ E
+    dist = (z_flat ** 2).sum(1, keepdim=True) + (E ** 2).sum(0) - 2 * sim
+    return torch.argmin(dist, dim=1)
+
+
+def vq_quantize(W, z):
+    """V:133-162 forward value: (quantised latents, perplexity)."""
+    E = W["vq.embeddings"]
+    flat = z.reshape(-1, E.shape[0])
+    idx = vq_code_indices(W, flat)
+    q = E.t()[idx].reshape(z.shape)
+    probs = torch.bincount(idx, minlength=E.shape[1]).to(z.dtype) / idx.numel()
+    perplexity = torch.exp(-(probs * torch.log(probs + 1e-10)).sum())
+    return q, perplexity, idx
+
+
+def vq_decoder(W, cfg: VQVAEConfig, z):
+    h = _prelu(_conv3d(z, W["dec.in.kernel"], W["dec.in.bias"]), W["dec.in_prelu.alpha"])
+    n = len(cfg.num_channels)
+    for i in range(n):
+        for j in range(cfg.num_res_layers):
+            h = vq_residual_unit(W, f"dec.l{i}.res{j}", h)
+        h = _conv3d_transpose_k4s2(h, W[f"dec.up{i}.kernel"], W[f"dec.up{i}.bias"])
+        if i != n - 1:
+            h = torch.relu(h)
+    return torch.relu(h) if cfg.output_act else h

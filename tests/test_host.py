@@ -126,7 +126,7 @@ def test_drop_in_signatures():
     m = conditional_dm3d.DiffusionModel(8, 1024, 4, None, type("A", (), dict(timesteps=7, num_gpus=1, kernel_resize=False, bs=3))(),
                                         device="cpu")
     assert m.timesteps == 7 and m.lc == 4 and m.global_bs == 3 and m.b.beta.shape == (7,) and m.metrics[0].name == "loss"
-    assert m.network.cfg.widths == (64, 128, 256) and m.encoder is None
+    assert m.network.cfg.widths == (64, 128, 256) and m._vqvae is None      # the VQ-VAE bracket is built lazily
     with pytest.raises(NotImplementedError):
         m.train_step((None, None, None))
 

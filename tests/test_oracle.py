@@ -142,3 +142,51 @@ def test_train_loss_definition():
     n, p = torch.randn(2, 2, 2, 2, 4), torch.randn(2, 2, 2, 2, 4)
     lo = rt.train_loss(n, p, global_bs=8, lc=4)
     assert abs(float(lo) - float(((n - p) ** 2).sum() / 4 / (8 * 256))) < 1e-7
+
+
+def test_vqvae_bracket_restatements_agree():
+    """next-1 oracle pieces (reference networks/vqvae3d_monai.py): PyTorch vs the independent NumPy definitions."""
+    cfg = rt.VQVAEConfig(in_channels=1, out_channels=1, num_channels=(4, 8), num_res_layers=2, num_res_channels=(4, 8),
+                         num_embeddings=32, embedding_dim=4, input_size=16)
+    spec = rt.vqvae_param_spec(cfg)
+    assert spec["enc.l0.res0.prelu.alpha"] == (8, 8, 8, 4) and spec["dec.up1.kernel"] == (4, 4, 4, 1, 4)
+    assert spec["vq.embeddings"] == (4, 32) and cfg.latent_size == 4
+    full = rt.vqvae_param_spec(rt.VQVAEConfig())                        # the model DiffusionModel wires (C:425-449)
+    assert abs(sum(int(np.prod(s)) for s in full.values()) / 1e6 - 75.9) < 1.0     # reference log: 75.6 M (3-level variant)
+    W = {k: v.double() for k, v in rt.vqvae_synthetic_weights(cfg, 0).items()}
+    Wn = rn.to_f64({k: v.numpy() for k, v in W.items()})
+    x = torch.randn(2, 16, 16, 16, 1, dtype=torch.float64)
+    a = rt._conv3d_k4s2(x, W["enc.down0.kernel"], W["enc.down0.bias"]).numpy()
+    assert np.abs(a - rn.conv3d_same(x.numpy(), Wn["enc.down0.kernel"], Wn["enc.down0.bias"], stride=2)).max() < 1e-12
+    t = torch.randn(2, 4, 4, 4, 8, dtype=torch.float64)
+    a = rt._conv3d_transpose_k4s2(t, W["dec.up0.kernel"], W["dec.up0.bias"]).numpy()
+    assert a.shape == (2, 8, 8, 8, 4)
+    assert np.abs(a - rn.conv3d_transpose_k4s2(t.numpy(), Wn["dec.up0.kernel"], Wn["dec.up0.bias"])).max() < 1e-12
+    r = torch.randn(2, 8, 8, 8, 4, dtype=torch.float64)
+    assert np.abs(rt.vq_residual_unit(W, "enc.l0.res0", r).numpy() - rn.vq_residual_unit(Wn, "enc.l0.res0", r.numpy())).max() < 1e-12
+    z = rt.vq_encoder(W, cfg, x)
+    q, perp, idx = rt.vq_quantize(W, z)
+    assert (idx.numpy() != rn.vq_code_indices(Wn["vq.embeddings"], z.reshape(-1, 4).numpy())).sum() == 0
+    assert 1.0 <= float(perp) <= 32.0 and torch.equal(q.reshape(-1, 4), W["vq.embeddings"].t()[idx])
+    y = rt.vq_decoder(W, cfg, q)
+    assert y.shape == (2, 16, 16, 16, 1)
+
+
+def test_upsample_conv_equals_eight_parity_convs():
+    """The identity behind the UpSample kernel path: conv3(nearest2x(x)) == interleave of 8 2x2x2 convs with summed taps."""
+    import dm3d_amd
+    from dm3d_amd.weights import upsample_parity_kernels
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, 5, 6, 3, generator=g, dtype=torch.float64)
+    k = torch.randn(3, 3, 3, 3, 2, generator=g, dtype=torch.float64)
+    ref = rt._conv3d(rt._upsample2(x), k, torch.zeros(2, dtype=torch.float64)).numpy()
+    pk = upsample_parity_kernels(k.numpy())
+    out = np.zeros(ref.shape)
+    xp = np.pad(x.numpy(), ((0, 0), (1, 1), (1, 1), (1, 1), (0, 0)))
+    for p in range(8):
+        a, b, c = p >> 2, (p >> 1) & 1, p & 1
+        for td in range(2):
+            for th in range(2):
+                for tw in range(2):
+                    out[:, a::2, b::2, c::2] += xp[:, td + a:td + a + 4, th + b:th + b + 5, tw + c:tw + c + 6] @ pk[p, td, th, tw]
+    assert np.abs(out - ref).max() < 1e-12
