@@ -151,8 +151,13 @@ def test_vqvae_bracket_restatements_agree():
     spec = rt.vqvae_param_spec(cfg)
     assert spec["enc.l0.res0.prelu.alpha"] == (8, 8, 8, 4) and spec["dec.up1.kernel"] == (4, 4, 4, 1, 4)
     assert spec["vq.embeddings"] == (4, 32) and cfg.latent_size == 4
-    full = rt.vqvae_param_spec(rt.VQVAEConfig())                        # the model DiffusionModel wires (C:425-449)
-    assert abs(sum(int(np.prod(s)) for s in full.values()) / 1e6 - 75.9) < 1.0     # reference log: 75.6 M (3-level variant)
+    # Reference-derived known answer: the Keras summary of the (32,64,128) x 3-residual-layer, 64-dim, 256-code VQVAE
+    # (main.py:190-209 era settings) logged in experiments/vqvae/vqvae3d-scaled-monai-B8-all.output:33-38 reports
+    # 75,593,473 trainable parameters and 2,694 non-trainable (2,688 BatchNorm moving statistics + 6 metric counters).
+    logged = rt.vqvae_param_spec(rt.VQVAEConfig(num_channels=(32, 64, 128), num_res_channels=(32, 64, 128), num_res_layers=3,
+                                               embedding_dim=64, num_embeddings=256))
+    stats = sum(int(np.prod(v)) for k, v in logged.items() if k.endswith((".mean", ".var")))
+    assert stats == 2688 and sum(int(np.prod(v)) for v in logged.values()) - stats == 75593473
     W = {k: v.double() for k, v in rt.vqvae_synthetic_weights(cfg, 0).items()}
     Wn = rn.to_f64({k: v.numpy() for k, v in W.items()})
     x = torch.randn(2, 16, 16, 16, 1, dtype=torch.float64)
