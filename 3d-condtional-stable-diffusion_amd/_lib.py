@@ -29,6 +29,7 @@ class ConvDesc(C.Structure):
         ("relu", C.c_int32), ("res", _f32p), ("out", _f32p), ("cout", C.c_int32),
         ("precision", C.c_int32), ("w_exp", C.c_int32),
         ("prelu_alpha", _f32p), ("relu_out", C.c_int32), ("transpose", C.c_int32),
+        ("pro_batch_stride", C.c_int64),
     ]
 
 
@@ -77,6 +78,10 @@ SIGNATURES = {
     "dm3d_layernorm3_h2": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_float] + [_f32p] * 9 + [C.c_void_p]),
     "dm3d_softmax_rows_h2": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]),
     "dm3d_layernorm3": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_float] + [_f32p] * 9 + [C.c_void_p]),
+    "dm3d_groupnorm_stats": (C.c_int, [_f32p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "dm3d_groupnorm_finalize": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_float, _f32p, _f32p, _f32p,
+                                           _f32p, C.c_void_p]),
+    "dm3d_affine_act_batched": (C.c_int, [_f32p, _f32p, C.c_int32, C.c_int64, C.c_int32, _f32p, _f32p, C.c_int32, C.c_void_p]),
     "dm3d_softmax_rows": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]),
     "dm3d_affine_act": (C.c_int, [_f32p, _f32p, C.c_int64, C.c_int32, _f32p, _f32p, C.c_int32, C.c_void_p]),
     "dm3d_ddpm_update": (C.c_int, [C.POINTER(DdpmDesc), C.c_void_p]),

@@ -109,8 +109,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_f32(const ConvArgs p) {
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
         const bool pro = p.pscale != nullptr;
         if (pro && chan_ok) {
-            sc = *reinterpret_cast<const f32x4*>(p.pscale + c0 + piece * 4);
-            sh = *reinterpret_cast<const f32x4*>(p.pshift + c0 + piece * 4);
+            sc = *reinterpret_cast<const f32x4*>(p.pscale + (size_t)b * p.pro_bstride + c0 + piece * 4);
+            sh = *reinterpret_cast<const f32x4*>(p.pshift + (size_t)b * p.pro_bstride + c0 + piece * 4);
         }
         // unconditional loads on clamped addresses, masked afterwards: a load inside a divergent branch costs one
         // serialized memory round trip each (hipcc waits vmcnt(0) per branch)
@@ -269,7 +269,9 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
     a.cinpad = (int)dm3d_round_up(cin, DM3D_CIN_PAD);
     a.coutpad = (int)dm3d_round_up(d->cout, DM3D_COUT_PAD);
     a.nchunks = a.cinpad / 16;
-    a.wpk = d->wpk; a.bias = d->bias; a.pscale = d->pro_scale; a.pshift = d->pro_shift;
+    a.wpk = d->wpk; a.bias = d->bias; a.pscale = d->pro_scale; a.pshift = d->pro_shift; a.pro_bstride = d->pro_batch_stride;
+    DM3D_REQUIRE(d->pro_batch_stride == 0 || (d->pro_batch_stride >= d->c1 + d->c2 && d->pro_batch_stride % 4 == 0),
+                 "conv: pro_batch_stride must be 0 or a multiple of 4 >= c1+c2");
     a.vec = d->vec; a.vec_idx = d->vec_idx; a.vec_ld = d->vec_ld;
     a.relu = d->relu; a.res = d->res; a.out = d->out; a.cout = d->cout;
     a.prelu = d->prelu_alpha; a.relu_out = d->relu_out;

@@ -15,7 +15,7 @@ struct ConvArgs {
                               //    2x2x2 conv on the low-resolution input with pre-summed weights
     long w_parity_stride;     // elements (fp32) / halfs (h3) between the packed weight images of two parities
     const void* wpk; int cinpad, coutpad;
-    const float* bias; const float* pscale; const float* pshift;
+    const float* bias; const float* pscale; const float* pshift; long pro_bstride;
     const float* vec; const int* vec_idx; int vec_ld;
     int relu; const float* res; float* out; int cout;
     const float* prelu; int relu_out;      // PReLU slope [od*os, oh*os, ow*os, cout] before res; ReLU after res

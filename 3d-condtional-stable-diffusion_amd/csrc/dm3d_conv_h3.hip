@@ -186,10 +186,11 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
         }
         if (pro) {      // uniform branch; channel offsets clamped the same way (c1+c2 >= 8 is guaranteed by the host)
             const int s0 = ok0 ? c0 + piece * 8 : 0, s1 = ok1 ? c0 + piece * 8 + 4 : 0;
-            sc0 = *reinterpret_cast<const f32x4*>(p.pscale + s0);
-            sh0 = *reinterpret_cast<const f32x4*>(p.pshift + s0);
-            sc1 = *reinterpret_cast<const f32x4*>(p.pscale + s1);
-            sh1 = *reinterpret_cast<const f32x4*>(p.pshift + s1);
+            const size_t bo = (size_t)b * p.pro_bstride;                // 0: one folded-BatchNorm vector; else per-sample (GroupNorm)
+            sc0 = *reinterpret_cast<const f32x4*>(p.pscale + bo + s0);
+            sh0 = *reinterpret_cast<const f32x4*>(p.pshift + bo + s0);
+            sc1 = *reinterpret_cast<const f32x4*>(p.pscale + bo + s1);
+            sh1 = *reinterpret_cast<const f32x4*>(p.pshift + bo + s1);
         }
     };
     load_halo(0);

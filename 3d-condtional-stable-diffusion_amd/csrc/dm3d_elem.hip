@@ -233,6 +233,85 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
     }
 }
 
+// ---- GroupNormalization statistics: per-(sample, channel) sum and sum of squares, float32 partials per thread, float64 atomics
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const float* __restrict__ x, long voxels, int c, double* __restrict__ acc,
+                                                              int c_total, int chan_off) {
+    // grid: (voxel slabs, batch).  Thread -> channel quad q = tid % (c/4) (clamped), voxel lane vl = tid / (c/4); every
+    // thread owns the same 4 channels for all its voxels, so sums stay in registers; LDS reduces threads sharing a quad.
+    extern __shared__ float sred[];             // [256][8]
+    const int c4 = c >> 2;
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int lanes_per_vox = c4 < 256 ? c4 : 256;            // quads handled per pass
+    const int vox_par = 256 / lanes_per_vox;                  // voxels processed in parallel by the block
+    const int q0 = tid % lanes_per_vox, vl = tid / lanes_per_vox;
+    const long slab = (voxels + gridDim.x - 1) / gridDim.x;
+    const long v0 = (long)blockIdx.x * slab, v1 = v0 + slab < voxels ? v0 + slab : voxels;
+    for (int q = q0; q < c4; q += lanes_per_vox) {            // c > 1024 loops
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = s;
+        if (vl < vox_par) {
+            for (long v = v0 + vl; v < v1; v += vox_par) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(x + ((size_t)b * voxels + v) * c + q * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s[e] += t[e]; ss[e] += t[e] * t[e]; }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sred[tid * 8 + e] = s[e]; sred[tid * 8 + 4 + e] = ss[e]; }
+        __syncthreads();
+        if (vl == 0) {                                          // one thread per quad folds the vox_par partials
+            double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
+            for (int k = 0; k < vox_par; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ds[e] += sred[(k * lanes_per_vox + q0) * 8 + e]; dq[e] += sred[(k * lanes_per_vox + q0) * 8 + 4 + e]; }
+            double* a = acc + ((size_t)b * c_total + chan_off + q * 4) * 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { atomicAdd(a + 2 * e, ds[e]); atomicAdd(a + 2 * e + 1, dq[e]); }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void groupnorm_finalize_kernel(double* __restrict__ acc, long voxels, int c_total, int groups, float eps,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* __restrict__ scale, float* __restrict__ shift) {
+    const int b = blockIdx.x, gc = c_total / groups;
+    __shared__ double gmean[64], grstd[64];
+    for (int g = threadIdx.x; g < groups; g += 256) {
+        double s = 0, q = 0;
+        for (int i = 0; i < gc; ++i) { s += acc[((size_t)b * c_total + g * gc + i) * 2]; q += acc[((size_t)b * c_total + g * gc + i) * 2 + 1]; }
+        const double n = (double)voxels * gc, m = s / n;
+        double var = q / n - m * m;
+        var = var > 0 ? var : 0;
+        gmean[g] = m;
+        grstd[g] = 1.0 / sqrt(var + (double)eps);
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < c_total; ch += 256) {
+        const int g = ch / gc;
+        const double sc = (double)gamma[ch] * grstd[g];
+        scale[(size_t)b * c_total + ch] = (float)sc;
+        shift[(size_t)b * c_total + ch] = (float)((double)beta[ch] - gmean[g] * sc);
+        acc[((size_t)b * c_total + ch) * 2] = 0.0;            // ready for the next use (same stream order)
+        acc[((size_t)b * c_total + ch) * 2 + 1] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void affine_act_batched_kernel(const float* __restrict__ x, float* __restrict__ y, long per_sample4,
+                                                                 int c4, const float* scale, const float* shift, int act) {
+    const int b = blockIdx.y;
+    const f32x4* xs = reinterpret_cast<const f32x4*>(x) + (size_t)b * per_sample4;
+    f32x4* ys = reinterpret_cast<f32x4*>(y) + (size_t)b * per_sample4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_sample4; i += (long)gridDim.x * 256) {
+        f32x4 v = xs[i];
+        const int cc = (int)(i % c4);
+        const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[(size_t)b * c4 + cc];
+        const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[(size_t)b * c4 + cc];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = dm3d_act(fmaf(v[e], sc[e], sh[e]), act);
+        ys[i] = v;
+    }
+}
+
 // ---- Philox4x32-10 + Box-Muller ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
@@ -540,4 +619,38 @@ extern "C" int dm3d_vq_assign(const float* z, int64_t rows, int32_t d, const flo
     hipLaunchKernelGGL(vq_assign_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), z,
                        (long)rows, d, sim, k, esq, idx);
     return dm3d_launch_check("vq_assign_kernel");
+}
+
+extern "C" int dm3d_groupnorm_stats(const float* x, int32_t batch, int64_t voxels, int32_t c, double* acc, int32_t c_total,
+                                    int32_t chan_off, void* stream) {
+    DM3D_REQUIRE(x && acc && batch > 0 && batch <= 65535 && voxels > 0 && c > 0 && c % 4 == 0, "groupnorm_stats: bad arguments (c %% 4 == 0)");
+    DM3D_REQUIRE(chan_off >= 0 && chan_off % 4 == 0 && chan_off + c <= c_total, "groupnorm_stats: channel window outside c_total");
+    DM3D_REQUIRE(dm3d_aligned16(x), "groupnorm_stats: x must be 16-byte aligned");
+    const int c4 = c / 4, lanes = c4 < 256 ? c4 : 256;
+    long slabs = voxels / (256 / lanes * 16);                // >= 16 voxels per thread
+    slabs = slabs < 1 ? 1 : (slabs > 64 ? 64 : slabs);
+    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3((unsigned)slabs, (unsigned)batch), dim3(256), 256 * 8 * sizeof(float),
+                       static_cast<hipStream_t>(stream), x, (long)voxels, c, acc, c_total, chan_off);
+    return dm3d_launch_check("groupnorm_stats_kernel");
+}
+
+extern "C" int dm3d_groupnorm_finalize(double* acc, int32_t batch, int64_t voxels, int32_t c_total, int32_t groups, float eps,
+                                       const float* gamma, const float* beta, float* scale, float* shift, void* stream) {
+    DM3D_REQUIRE(acc && gamma && beta && scale && shift && batch > 0 && voxels > 0, "groupnorm_finalize: bad arguments");
+    DM3D_REQUIRE(groups > 0 && groups <= 64 && c_total % groups == 0, "groupnorm_finalize: groups=%d must divide c=%d (<= 64)", groups, c_total);
+    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3((unsigned)batch), dim3(256), 0, static_cast<hipStream_t>(stream), acc,
+                       (long)voxels, c_total, groups, eps, gamma, beta, scale, shift);
+    return dm3d_launch_check("groupnorm_finalize_kernel");
+}
+
+extern "C" int dm3d_affine_act_batched(const float* x, float* y, int32_t batch, int64_t rows_per_sample, int32_t c,
+                                       const float* scale, const float* shift, int32_t act, void* stream) {
+    DM3D_REQUIRE(x && y && scale && shift && batch > 0 && batch <= 65535 && rows_per_sample > 0 && c > 0 && c % 4 == 0,
+                 "affine_act_batched: bad arguments (c %% 4 == 0)");
+    DM3D_REQUIRE(act >= DM3D_ACT_NONE && act <= DM3D_ACT_SILU, "affine_act_batched: unknown act %d", act);
+    DM3D_REQUIRE(dm3d_aligned16(x) && dm3d_aligned16(y) && dm3d_aligned16(scale) && dm3d_aligned16(shift), "affine_act_batched: pointers must be 16-byte aligned");
+    const long per4 = (long)rows_per_sample * (c / 4);
+    hipLaunchKernelGGL(affine_act_batched_kernel, dim3(grid_for(per4, 256), (unsigned)batch), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, y, per4, c / 4, scale, shift, act);
+    return dm3d_launch_check("affine_act_batched_kernel");
 }

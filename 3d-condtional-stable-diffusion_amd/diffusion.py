@@ -44,7 +44,7 @@ class DiffusionModel:
     conditional = True
 
     def __init__(self, latent_size, num_embed, latent_channels, vqvae_load_ckpt, args, *, device="cuda", weights=None,
-                 seed=0, precision=None):
+                 seed=0, precision=None, norm="batch"):
         # conditional_dm3d.py:420-469.  ``args`` is any object with .timesteps .num_gpus .kernel_resize .bs
         self.timesteps = int(args.timesteps)
         self.b = Betas(self.timesteps)
@@ -58,7 +58,7 @@ class DiffusionModel:
         self._precision = precision
         self.network = UNet(
             UNetConfig(img_size=latent_size, img_channels=latent_channels, widths=[64, 128, 256],
-                       has_attention=[False, False, True, True], conditional=self.conditional),
+                       has_attention=[False, False, True, True], conditional=self.conditional, norm=norm),
             device=device, weights=weights, seed=seed, precision=precision)
         self.loss_tracker = _LossTracker("loss")
         self.num_gpus = getattr(args, "num_gpus", 1)

@@ -31,7 +31,7 @@ def swish(x):
 
 
 def build_model(img_size, img_channels, widths, has_attention, has_cross_attention=None, num_res_blocks=2, norm_groups=8,
-                interpolation="nearest", activation_fn=swish, context_dim=1, *, device="cuda", seed=0, precision=None):
+                interpolation="nearest", activation_fn=swish, context_dim=1, *, device="cuda", seed=0, precision=None, norm="batch"):
     """conditional_dm3d.py:324-415.  Returns a callable ``net([image, time, context]) -> eps``.
 
     ``norm_groups`` and ``interpolation`` are accepted and ignored exactly as the reference ignores them (BatchNorm
@@ -42,5 +42,5 @@ def build_model(img_size, img_channels, widths, has_attention, has_cross_attenti
         raise ValueError("only the swish activation of the reference is implemented in the fused kernels")
     cfg = UNetConfig(img_size=img_size, img_channels=img_channels, widths=widths, has_attention=has_attention,
                      num_res_blocks=num_res_blocks, conditional=True, first_conv_channels=first_conv_channels,
-                     context_dim=context_dim, norm_groups=norm_groups)
+                     context_dim=context_dim, norm_groups=norm_groups, norm=norm)
     return UNet(cfg, device=device, seed=seed, precision=precision)

@@ -152,8 +152,12 @@ class UNet:
         return w
 
     def _fold_bn(self, name: str):
-        """Inference BatchNormalization gamma*(x-mean)/sqrt(var+eps)+beta as x*scale+shift."""
+        """Inference BatchNormalization gamma*(x-mean)/sqrt(var+eps)+beta as x*scale+shift.  In the GroupNormalization
+        variant (cfg.norm == "group") the statistics are per sample, so only (gamma, beta) are uploaded and the plan
+        computes scale/shift on the device every step (Plan._norm)."""
         s = self.state
+        if self.cfg.norm == "group":
+            return self._dev(s[f"{name}.gamma"]), self._dev(s[f"{name}.beta"])
         scale = (s[f"{name}.gamma"].astype(np.float64) / np.sqrt(s[f"{name}.var"].astype(np.float64) + BN_EPS))
         shift = s[f"{name}.beta"].astype(np.float64) - s[f"{name}.mean"].astype(np.float64) * scale
         return self._dev(scale.astype(np.float32)), self._dev(shift.astype(np.float32))
@@ -197,14 +201,18 @@ class UNet:
     def _prepare_attn(self, P, blk):
         s, n, u = self.state, blk.name, blk.cout
         if self.cfg.conditional:
-            scale, shift = self._fold_bn(f"{n}.norm")
-            # BN folded into proj_in: W' = diag(scale) W ; b' = b + shift @ W (the latter through the GEMM kernel)
-            plain = self._pack(s[f"{n}.proj_in.kernel"], s[f"{n}.proj_in.bias"])
-            bias2 = torch.empty(u, dtype=torch.float32, device=self.device)
-            self._gemm_now(a=shift, lda=u, b=plain.wpk, ldb=plain.cin_pad, out=bias2, ldo=u, m=1, n=u, k=u, bias=plain.bias)
-            folded = self._pack(s[f"{n}.proj_in.kernel"], None, in_scale=scale)
-            folded.bias = bias2
-            P[f"{n}.proj_in"] = self._with_h2(folded)
+            if self.cfg.norm == "group":
+                P[f"{n}.norm"] = self._fold_bn(f"{n}.norm")                    # (gamma, beta): applied per sample by the plan
+                P[f"{n}.proj_in"] = self._with_h2(self._pack(s[f"{n}.proj_in.kernel"], s[f"{n}.proj_in.bias"]))
+            else:
+                scale, shift = self._fold_bn(f"{n}.norm")
+                # BN folded into proj_in: W' = diag(scale) W ; b' = b + shift @ W (the latter through the GEMM kernel)
+                plain = self._pack(s[f"{n}.proj_in.kernel"], s[f"{n}.proj_in.bias"])
+                bias2 = torch.empty(u, dtype=torch.float32, device=self.device)
+                self._gemm_now(a=shift, lda=u, b=plain.wpk, ldb=plain.cin_pad, out=bias2, ldo=u, m=1, n=u, k=u, bias=plain.bias)
+                folded = self._pack(s[f"{n}.proj_in.kernel"], None, in_scale=scale)
+                folded.bias = bias2
+                P[f"{n}.proj_in"] = self._with_h2(folded)
             P[f"{n}.proj_out"] = self._with_h2(self._pack(s[f"{n}.proj_out.kernel"], s[f"{n}.proj_out.bias"]))
             for ln in ("ln1", "ln2", "ln3"):
                 P[f"{n}.{ln}"] = (self._dev(s[f"{n}.{ln}.gamma"]), self._dev(s[f"{n}.{ln}.beta"]))
@@ -358,6 +366,7 @@ class Plan:
         self.t_idx = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.vec = torch.empty(vec_rows, net.temb_ld, dtype=torch.float32, device=dev)
         self.ctx_bufs: Dict[str, tuple] = {}
+        self._gn_acc = None
         self._build()
 
     # -- buffer / op helpers ---------------------------------------------------------------------------------------
@@ -366,8 +375,30 @@ class Plan:
         self._keep.append(t)
         return t
 
+    def _norm(self, name, x1, c1, edge, x2=None, c2=0):
+        """Prologue vectors of a normalisation layer: (pro, batch_stride).  BatchNorm: the folded constants.  GroupNorm:
+        two launches (per-channel moments, group finalize) write per-sample scale/shift for this step."""
+        P = self.net.P
+        if self.net.cfg.norm != "group":
+            return P[name], 0
+        gamma, beta = P[name]
+        ct, B, vox = c1 + c2, self.B, edge ** 3
+        if self._gn_acc is None or self._gn_acc.numel() < B * ct * 2:
+            self._gn_acc = torch.zeros(B * max(ct, 1024) * 2, dtype=torch.float64, device=self.net.device)
+            self._keep.append(self._gn_acc)
+        scale, shift = self._buf(B, ct), self._buf(B, ct)
+        self._keep += [gamma, beta]
+        st = lib().dm3d_groupnorm_stats
+        self.ops.append((st, (x1.data_ptr(), B, vox, c1, self._gn_acc.data_ptr(), ct, 0), "groupnorm", {}))
+        if x2 is not None:
+            self.ops.append((st, (x2.data_ptr(), B, vox, c2, self._gn_acc.data_ptr(), ct, c1), "groupnorm", {}))
+        self.ops.append((lib().dm3d_groupnorm_finalize, (self._gn_acc.data_ptr(), B, vox, ct, self.net.cfg.norm_groups, BN_EPS,
+                                                         gamma.data_ptr(), beta.data_ptr(), scale.data_ptr(), shift.data_ptr()),
+                         "groupnorm", {}))
+        return (scale, shift), ct
+
     def _conv(self, w: _Conv, x1, out, edge_in, x2=None, c1=None, c2=0, upsample=0, stride=1, pro=None, vec_off=None,
-              relu=0, res=None):
+              relu=0, res=None, pro_bstride=0):
         d = ConvDesc()
         d.x1, d.x2 = _ptr(x1), _ptr(x2)
         d.c1, d.c2 = (c1 if c1 is not None else w.cin), c2
@@ -378,7 +409,7 @@ class Plan:
         d.wpk, d.bias = w.wpk.data_ptr(), _ptr(w.bias)
         d.precision, d.w_exp = w.precision, w.w_exp
         if pro is not None:
-            d.pro_scale, d.pro_shift = _ptr(pro[0]), _ptr(pro[1])
+            d.pro_scale, d.pro_shift, d.pro_batch_stride = _ptr(pro[0]), _ptr(pro[1]), pro_bstride
         if vec_off is not None:
             d.vec, d.vec_idx, d.vec_ld = _ptr(self.vec, vec_off), _ptr(self.t_idx), self.net.temb_ld
         d.relu, d.res, d.out, d.cout = relu, _ptr(res), _ptr(out), w.cout
@@ -441,7 +472,8 @@ class Plan:
                 out = self._buf(B, blk.edge, blk.edge, blk.edge, blk.cout)
                 self._conv(P[blk.name], cur, out, edge, upsample=1)
                 cur, edge = out, blk.edge
-        self._conv(P["out.conv"], cur, self.eps, edge, pro=P["out.norm"])
+        pro, bs = self._norm("out.norm", cur, cur_c, edge)
+        self._conv(P["out.conv"], cur, self.eps, edge, pro=pro, pro_bstride=bs)
 
     def _res_block(self, blk, x1, c1, x2, c2, edge):
         """ResidualBlock (conditional_dm3d.py:238-271): three launches (two when the widths match)."""
@@ -452,10 +484,20 @@ class Plan:
         else:
             res = x1
         hmid = self._buf(B, edge, edge, edge, w)
-        self._conv(P[f"{n}.conv1"], x1, hmid, edge, x2=x2, c1=c1, c2=c2, pro=P[f"{n}.norm1"], vec_off=self.net.temb_off[n])
+        pro, bs = self._norm(f"{n}.norm1", x1, c1, edge, x2, c2)
+        self._conv(P[f"{n}.conv1"], x1, hmid, edge, x2=x2, c1=c1, c2=c2, pro=pro, pro_bstride=bs, vec_off=self.net.temb_off[n])
         out = self._buf(B, edge, edge, edge, w)
-        self._conv(P[f"{n}.conv2"], hmid, out, edge, pro=P[f"{n}.norm2"], res=res)
+        pro, bs = self._norm(f"{n}.norm2", hmid, w, edge)
+        self._conv(P[f"{n}.conv2"], hmid, out, edge, pro=pro, pro_bstride=bs, res=res)
         return out
+
+    def _group_normed(self, n, x, u, edge):
+        """GroupNormalization of an attention block's input, materialised (its consumers are GEMMs and a residual)."""
+        (scale, shift), _ = self._norm(f"{n}.norm", x, u, edge)
+        xn = self._buf(self.B * edge ** 3, u)
+        self.ops.append((lib().dm3d_affine_act_batched, (x.data_ptr(), xn.data_ptr(), self.B, edge ** 3, u, scale.data_ptr(),
+                                                         shift.data_ptr(), ACT_NONE), "affine", {}))
+        return xn
 
     def _attn_core(self, q, q_ld, q_off, k, k_ld, k_off, k_stride, v_t, v_ld, v_off, v_stride, scores, res, out, L, u, h2):
         """softmax(q k^T * u^-0.5) v + res per sample (conditional_dm3d.py:171-180): two batched GEMMs around a
@@ -480,8 +522,9 @@ class Plan:
         W = (lambda w: w.h2) if h2 else (lambda w: w.wpk)
         pin, pout, qk, val = P[f"{n}.proj_in"], P[f"{n}.proj_out"], P[f"{n}.qk"], P[f"{n}.value"]
         m0, m1 = P[f"{n}.mlp.0"], P[f"{n}.mlp.1"]
-        y = self._buf(M, u)                                                   # relu(proj_in(BN(x))), float32
-        self._gemm(a=x, lda=u, b=W(pin), ldb=pin.cin_pad, out=y, ldo=u, m=M, n=u, k=u, bias=pin.bias, act=ACT_RELU,
+        y = self._buf(M, u)                                                   # relu(proj_in(norm(x))), float32
+        xin = self._group_normed(n, x, u, edge) if self.net.cfg.norm == "group" else x      # BatchNorm is folded into proj_in
+        self._gemm(a=xin, lda=u, b=W(pin), ldb=pin.cin_pad, out=y, ldo=u, m=M, n=u, k=u, bias=pin.bias, act=ACT_RELU,
                    h3=h2, b_h2=h2)
         n1, n2, n3 = self._buf(M, u), self._buf(M, u), self._buf(M, u)
         (g1, b1), (g2, b2), (g3, b3) = P[f"{n}.ln1"], P[f"{n}.ln2"], P[f"{n}.ln3"]
@@ -531,8 +574,9 @@ class Plan:
         pin, pout, qk, val = P[f"{n}.proj_in"], P[f"{n}.proj_out"], P[f"{n}.qk"], P[f"{n}.value"]
         m0, m1 = P[f"{n}.mlp.0"], P[f"{n}.mlp.1"]
         hh = dict(h3=True, a_h2=True, b_h2=True)
-        y = self._buf(M, u)                                                   # relu(proj_in(BN(x))), float32
-        self._gemm(a=x, lda=u, b=pin.h2, ldb=pin.cin_pad, out=y, ldo=u, m=M, n=u, k=u, bias=pin.bias, act=ACT_RELU,
+        y = self._buf(M, u)                                                   # relu(proj_in(norm(x))), float32
+        xin = self._group_normed(n, x, u, edge) if self.net.cfg.norm == "group" else x      # BatchNorm is folded into proj_in
+        self._gemm(a=xin, lda=u, b=pin.h2, ldb=pin.cin_pad, out=y, ldo=u, m=M, n=u, k=u, bias=pin.bias, act=ACT_RELU,
                    h3=True, b_h2=True)
         n1, n2, n3 = self._buf(M, u), self._buf(M, u), self._buf(M, u)
         (g1, b1), (g2, b2), (g3, b3) = P[f"{n}.ln1"], P[f"{n}.ln2"], P[f"{n}.ln3"]
@@ -586,11 +630,14 @@ class Plan:
         h2 = self.net._attn_h2(u, L)
         W = (lambda w: w.h2) if h2 else (lambda w: w.wpk)
         qk, val, proj = P[f"{n}.qk"], P[f"{n}.value"], P[f"{n}.proj"]
-        scale, shift = P[f"{n}.norm"]
-        self._keep += [scale, shift]
-        xn = self._buf(M, u)                                                  # float32: also the residual
-        self.ops.append((lib().dm3d_affine_act, (x.data_ptr(), xn.data_ptr(), M, u, scale.data_ptr(), shift.data_ptr(),
-                                                 ACT_NONE), "affine", {}))
+        if self.net.cfg.norm == "group":
+            xn = self._group_normed(n, x, u, edge)
+        else:
+            scale, shift = P[f"{n}.norm"]
+            self._keep += [scale, shift]
+            xn = self._buf(M, u)                                              # float32: also the residual
+            self.ops.append((lib().dm3d_affine_act, (x.data_ptr(), xn.data_ptr(), M, u, scale.data_ptr(), shift.data_ptr(),
+                                                     ACT_NONE), "affine", {}))
         qkb = self._buf(M, 2 * u)
         self._gemm(a=xn, lda=u, b=W(qk), ldb=qk.cin_pad, out=qkb, ldo=2 * u, m=M, n=2 * u, k=u, bias=qk.bias,
                    h3=h2, b_h2=h2, out_h2=h2)

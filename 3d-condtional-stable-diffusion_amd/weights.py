@@ -26,7 +26,8 @@ class UNetConfig:
     conditional: bool = True
     first_conv_channels: Optional[int] = None
     context_dim: int = 1
-    norm_groups: int = 8            # plumbed but unused by the reference (BatchNormalization replaces GroupNorm)
+    norm_groups: int = 8            # plumbed but unused by the reference (BatchNormalization replaces GroupNorm) ...
+    norm: str = "batch"             # ... unless norm="group": the GroupNormalization lines it keeps commented out (:77, 254, 261, 409)
 
     def __post_init__(self):
         if self.first_conv_channels is None:
@@ -35,6 +36,8 @@ class UNetConfig:
         self.has_attention = tuple(bool(a) for a in self.has_attention)
         if len(self.has_attention) < len(self.widths):
             raise ValueError("has_attention needs one entry per width")
+        if self.norm not in ("batch", "group"):
+            raise ValueError("norm must be 'batch' or 'group'")
 
     @property
     def temb_dim(self) -> int:

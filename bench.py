@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--size", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--norm", choices=["batch", "group"], default="batch",
+                    help="batch = the reference's inference BatchNormalization (folded); group = its commented-out "
+                         "GroupNormalization(8) variant (per-sample statistics computed on the device every step)")
     ap.add_argument("--precision", choices=["h3", "fp32"], default="h3",
                     help="Conv3d arithmetic: h3 = float16 hi+lo split, 3 MFMA passes, fp32 accumulate (default); "
                          "fp32 = exact float32 MFMA")
@@ -97,7 +100,7 @@ def main():
     W = dm3d_amd.synthetic_weights(cfg, seed=0) if rank == 0 else None
     W = parallel.broadcast_state(W, spec, src=0, device=comm_dev)              # RCCL broadcast over xGMI (no-op at N=1)
     margs = SimpleNamespace(timesteps=T_FULL, num_gpus=world, kernel_resize=False, bs=B * world)
-    model = cdm.DiffusionModel(S, 1024, Cc, None, margs, device=dev, weights=W, precision=args.precision)
+    model = cdm.DiffusionModel(S, 1024, Cc, None, margs, device=dev, weights=W, precision=args.precision, norm=args.norm)
     smp = model.sampler((B, S, S, S, Cc), context_value=1, seed=parallel.rank_seed(1234, rank),
                         use_graph=not args.no_graph)
     smp.reset()
@@ -220,7 +223,7 @@ def main():
                        "weights": "seeded synthetic (seed 0), rank-0 broadcast", "parallelism": f"batch-shard x{world}" + (" (REHEARSAL: ranks share one GPU, gloo)" if rehearsal else "")},
             "roofline": roofline, "cpu_baseline": cpu, "per_kernel_kind": per_kind,
             "conv_mfma_util_pct": None if roofline is None else round(100 * roofline["executed_mfma_frac_of_peak"], 2),
-            "precision": args.precision,
+            "precision": args.precision, "norm": args.norm,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -130,6 +130,9 @@ typedef struct dm3d_conv_desc {
     int32_t relu_out;           /* 1: ReLU after the residual add (VQVAEResidualUnit: ReLU(x + PReLU(BN(conv)))) */
     int32_t transpose;          /* 1: Conv3DTranspose(k=4, strides=2, padding="same"): out = 2*in; wpk from
                                    dm3d_pack_weights_convt[_h3]; ksize must be 4, stride 2, no upsample */
+    int64_t pro_batch_stride;   /* elements between consecutive samples' pro_scale / pro_shift vectors: 0 = one vector for
+                                   the batch (folded BatchNormalization), c1+c2 = per-sample vectors (GroupNormalization,
+                                   written by dm3d_groupnorm_finalize) */
 } dm3d_conv_desc;
 
 int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream);
@@ -177,6 +180,22 @@ int dm3d_layernorm3_h2(const float* x, int64_t rows, int32_t c, float eps,
                        const float* g1, const float* b1, void* o1,
                        const float* g2, const float* b2, void* o2,
                        const float* g3, const float* b3, void* o3, void* stream);
+
+/* ---- GroupNormalization(groups, epsilon) statistics (the variant the reference keeps commented out, conditional_dm3d.py:77,
+ * 254, 261, 409; keras default epsilon 1e-3).  Per-sample statistics cannot be folded at load time, so two small launches
+ * turn a tensor into the per-(sample, channel) scale / shift that the conv prologue (pro_batch_stride = c) or
+ * dm3d_affine_act_batched then applies, fused with swish:
+ *   dm3d_groupnorm_stats:    acc[b][chan_off + c][0..1] += (sum, sum of squares) of x[b, :, c] in float64 (x [batch, voxels, c];
+ *                            call once per concatenated input with its channel offset);  acc must be zero on entry.
+ *   dm3d_groupnorm_finalize: group moments from acc (float64), scale[b][c] = gamma[c]*rstd, shift[b][c] = beta[c] - mean*scale;
+ *                            acc is zeroed again for the next use. */
+int dm3d_groupnorm_stats(const float* x, int32_t batch, int64_t voxels, int32_t c, double* acc, int32_t c_total,
+                         int32_t chan_off, void* stream);
+int dm3d_groupnorm_finalize(double* acc, int32_t batch, int64_t voxels, int32_t c_total, int32_t groups, float eps,
+                            const float* gamma, const float* beta, float* scale, float* shift, void* stream);
+/* y[b][r][c] = act(x[b][r][c]*scale[b][c] + shift[b][c]) : dm3d_affine_act with per-sample vectors. c % 4 == 0. */
+int dm3d_affine_act_batched(const float* x, float* y, int32_t batch, int64_t rows_per_sample, int32_t c, const float* scale,
+                            const float* shift, int32_t act, void* stream);
 
 /* ---- tf.nn.softmax(scores, -1) in place, one wavefront per row (shuffle reductions) (:178; U:56) ------------ */
 int dm3d_softmax_rows(float* s, int64_t rows, int32_t cols, int64_t ld, void* stream);

@@ -48,7 +48,17 @@ def conv3d_same(x, kernel, bias, stride=1, upsample=False):
     return y + bias
 
 
+NORM = {"mode": "batch", "groups": 8}
+
+
 def bn(x, W, n):
+    if NORM["mode"] == "group" and x.ndim == 5:         # GroupNormalization(groups, eps 1e-3): moments over (D,H,W,C/groups)
+        B, D, H, Wd, C = x.shape
+        g = NORM["groups"]
+        xg = x.reshape(B, D * H * Wd, g, C // g)
+        mu = xg.mean(axis=(1, 3), keepdims=True)
+        var = ((xg - mu) ** 2).mean(axis=(1, 3), keepdims=True)
+        return ((xg - mu) / np.sqrt(var + BN_EPS)).reshape(x.shape) * W[n + ".gamma"] + W[n + ".beta"]
     return W[n + ".gamma"] * (x - W[n + ".mean"]) / np.sqrt(W[n + ".var"] + BN_EPS) + W[n + ".beta"]
 
 
@@ -128,6 +138,7 @@ def unet_forward(W, cfg, x, t, context=None, taps: Optional[dict] = None):
     W = to_f64(W)
     x = np.asarray(x, np.float64)
     widths = list(cfg.widths)
+    NORM["mode"], NORM["groups"] = getattr(cfg, "norm", "batch"), getattr(cfg, "norm_groups", 8)
     keep = (lambda k, v: taps.__setitem__(k, v)) if taps is not None else (lambda k, v: None)
     h = conv3d_same(x, W["conv_in.kernel"], W["conv_in.bias"])
     temb = dense(swish(dense(time_embedding(t, cfg.temb_dim), W, "time_mlp.0")), W, "time_mlp.1")

@@ -46,6 +46,8 @@ class UNetConfig:
     conditional: bool = True          # True: conditional_dm3d.py (CrossAttentionBlock); False: dm3d.py (AttentionBlock)
     first_conv_channels: Optional[int] = None
     context_dim: int = 1
+    norm: str = "batch"               # "batch": what the reference runs; "group": the GroupNormalization(groups=norm_groups)
+    norm_groups: int = 8              #          lines it keeps commented out (C:77, 254, 261, 409), Keras epsilon 1e-3
 
     def __post_init__(self):
         if self.first_conv_channels is None:
@@ -54,6 +56,9 @@ class UNetConfig:
     @property
     def temb_dim(self) -> int:
         return self.first_conv_channels * 4
+
+
+_NORM = {"mode": "batch", "groups": 8}     # set by unet_forward for the duration of a call (test-only module state)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -270,7 +275,11 @@ def _conv3d(x, kernel, bias, stride=1):
 
 
 def _bn_infer(x, W, name):
-    """BatchNormalization(training=False): gamma*(x-mean)/sqrt(var+eps)+beta over the last axis."""
+    """BatchNormalization(training=False): gamma*(x-mean)/sqrt(var+eps)+beta over the last axis — or, in the "group" variant,
+    GroupNormalization(groups, epsilon=1e-3): per-sample moments over (D,H,W,C/groups)."""
+    if _NORM["mode"] == "group" and x.dim() == 5:
+        y = F.group_norm(x.permute(0, 4, 1, 2, 3), _NORM["groups"], W[f"{name}.gamma"], W[f"{name}.beta"], BN_EPS)
+        return y.permute(0, 2, 3, 4, 1)
     return (x - W[f"{name}.mean"]) / torch.sqrt(W[f"{name}.var"] + BN_EPS) * W[f"{name}.gamma"] + W[f"{name}.beta"]
 
 
@@ -366,6 +375,7 @@ def unet_forward(W: Dict[str, torch.Tensor], cfg: UNetConfig, x: torch.Tensor, t
     receives named intermediates for block-level tests."""
     dt = x.dtype
     widths = list(cfg.widths)
+    _NORM["mode"], _NORM["groups"] = cfg.norm, cfg.norm_groups
 
     def tap(name, v):
         if taps is not None:

@@ -167,3 +167,32 @@ def test_unet_eps_full_size_32cube(dev, prec):
     m2, _ = m.sample(y, xd, tt, xd.shape)
     m3, _ = m.sample(2 * xd - 3 * y, 2 * eps - 3 * xd, tt, xd.shape)
     assert float((m3 - (2 * m1 - 3 * m2)).abs().max() / m3.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("cond", [True, False], ids=["conditional", "unconditional"])
+def test_unet_groupnorm_variant(dev, cond):
+    """norm="group": the GroupNormalization(groups=8) variant north_star words and the reference keeps commented out
+    (conditional_dm3d.py:77, 254, 261, 409); per-sample statistics on the device, same fused conv prologue."""
+    import dm3d_amd
+    from dm3d_amd.networks import conditional_dm3d, dm3d
+    from oracle import ref_torch as rt
+    cfg = dm3d_amd.UNetConfig(img_size=8, img_channels=4, conditional=cond, norm="group")
+    W = dm3d_amd.synthetic_weights(cfg, seed=0)
+    mod = conditional_dm3d if cond else dm3d
+    net = mod.build_model(8, 4, [64, 128, 256], [False, False, True, True], norm="group")
+    net.load_state_dict(W)
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(3, 8, 8, 8, 4, generator=g) * torch.tensor([0.5, 1.0, 3.0]).reshape(3, 1, 1, 1, 1)   # per-sample statistics differ
+    t = torch.tensor([0, 17, 999])
+    ctx = torch.tensor([[[1]], [[0]], [[1]]])
+    ocfg = rt.UNetConfig(img_size=8, img_channels=4, conditional=cond, norm="group")
+    Wt = {k: torch.from_numpy(v) for k, v in W.items()}
+    ref = rt.unet_forward(Wt, ocfg, x, t, ctx if cond else None)
+    refb = rt.unet_forward(Wt, rt.UNetConfig(img_size=8, img_channels=4, conditional=cond), x, t, ctx if cond else None)
+    eps = net([x.to(dev), t, ctx] if cond else [x.to(dev), t])
+    torch.cuda.synchronize()
+    err = _rel(eps, ref)
+    print(f"groupnorm variant eps rel err {err:.3e}")
+    assert err < TOL and _rel(refb, ref) > 0.05            # and it really is a different network from the BatchNorm one
+    eps2 = net([x.to(dev), t, ctx] if cond else [x.to(dev), t])      # the stats accumulator is re-zeroed by the finalize kernel
+    assert torch.equal(eps, eps2)
