@@ -15,6 +15,7 @@
 // (ds_write_b128 ~ 70 B/clk/CU); 128 x 128 stages 341 B per MFMA against 427 B for a 256 x 64 tile, and the model's GEMMs
 // (m = B*L = 16384, n = 256...1024) still yield >= 256 workgroups.
 #include "dm3d_h3.h"
+#include <type_traits>
 
 namespace {
 
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
     // F32 source: item = (row, 8-k group g): two float4 -> hi slot g & 1, lo slot 2 + (g & 1) of record g >> 1
     constexpr int A_ITEMS = A_F32 ? 2 : 4;
     constexpr int BI = B_F32 ? 2 : 4;
-    f32x4 ra[4], rb[4];
+    f32x4 ra[2][4], rb[2][4];                   // two register sets: two chunks in flight behind the one being multiplied
     size_t a_src[A_ITEMS];
     int a_dst[A_ITEMS];
 #pragma unroll
@@ -107,7 +108,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
         }
     }
 
-    auto fetch = [&](int k0) {                  // k0 is clamped by the caller to the last chunk
+    auto fetch = [&](auto SET, int k0) {        // k0 is clamped by the caller to the last chunk
+        constexpr int S = decltype(SET)::value;
         // when k % 32 == 16 the last chunk has no second record: its loads re-read the first one (64 bytes earlier)
         // instead of running past the end of the row; publish() zero-fills the LDS image
         const bool sec = k0 + 16 < p.k;
@@ -116,10 +118,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
             const bool second = A_F32 ? (((tid + i * 256) & 3) >= 2) : (((tid + i * 256) & 7) >= 4);
             const size_t koff = (size_t)k0 * 4 - ((!sec && second) ? 64 : 0);
             if (A_F32) {
-                ra[2 * i] = *reinterpret_cast<const f32x4*>(A + a_src[i] + koff);
-                ra[2 * i + 1] = *reinterpret_cast<const f32x4*>(A + a_src[i] + koff + 16);
+                ra[S][2 * i] = *reinterpret_cast<const f32x4*>(A + a_src[i] + koff);
+                ra[S][2 * i + 1] = *reinterpret_cast<const f32x4*>(A + a_src[i] + koff + 16);
             } else {
-                ra[i] = *reinterpret_cast<const f32x4*>(A + a_src[i] + koff);
+                ra[S][i] = *reinterpret_cast<const f32x4*>(A + a_src[i] + koff);
             }
         }
 #pragma unroll
@@ -127,15 +129,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
             const bool second = B_F32 ? (((tid + i * 256) & 3) >= 2) : (((tid + i * 256) & 7) >= 4);
             const size_t koff = (size_t)k0 * 4 - ((!sec && second) ? 64 : 0);
             if (B_F32) {
-                rb[2 * i] = *reinterpret_cast<const f32x4*>(B + b_src[i] + koff);
-                rb[2 * i + 1] = *reinterpret_cast<const f32x4*>(B + b_src[i] + koff + 16);
+                rb[S][2 * i] = *reinterpret_cast<const f32x4*>(B + b_src[i] + koff);
+                rb[S][2 * i + 1] = *reinterpret_cast<const f32x4*>(B + b_src[i] + koff + 16);
             } else {
-                rb[i] = *reinterpret_cast<const f32x4*>(B + b_src[i] + koff);
+                rb[S][i] = *reinterpret_cast<const f32x4*>(B + b_src[i] + koff);
             }
         }
     };
     // k tail: the chunk's second record is absent when k % 32 == 16; its LDS image is zero filled
-    auto publish = [&](int buf, bool second_rec) {
+    auto publish = [&](auto SET, int buf, bool second_rec) {
+        constexpr int S = decltype(SET)::value;
         _Float16* da = lds_a + buf * A_BUF;
         _Float16* db = lds_b + buf * B_BUF;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -144,12 +147,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
             if (A_F32) {
                 const bool ok = second_rec || ((tid + i * 256) & 3) < 2;
                 h8 hi, lo;
-                split8(ra[2 * i], ra[2 * i + 1], ok ? 65504.0f : 0.0f, ok ? 65504.0f : 0.0f, hi, lo);
+                split8(ra[S][2 * i], ra[S][2 * i + 1], ok ? 65504.0f : 0.0f, ok ? 65504.0f : 0.0f, hi, lo);
                 *reinterpret_cast<h8*>(da + a_dst[i]) = hi;
                 *reinterpret_cast<h8*>(da + (a_dst[i] ^ 16)) = lo;
             } else {
                 const bool ok = second_rec || ((tid + i * 256) & 7) < 4;
-                *reinterpret_cast<f32x4*>(da + a_dst[i]) = ok ? ra[i] : z;
+                *reinterpret_cast<f32x4*>(da + a_dst[i]) = ok ? ra[S][i] : z;
             }
         }
 #pragma unroll
@@ -157,12 +160,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
             if (B_F32) {
                 const bool ok = second_rec || ((tid + i * 256) & 3) < 2;
                 h8 hi, lo;
-                split8(rb[2 * i], rb[2 * i + 1], ok ? 65504.0f : 0.0f, ok ? 65504.0f : 0.0f, hi, lo);
+                split8(rb[S][2 * i], rb[S][2 * i + 1], ok ? 65504.0f : 0.0f, ok ? 65504.0f : 0.0f, hi, lo);
                 *reinterpret_cast<h8*>(db + b_dst[i]) = hi;
                 *reinterpret_cast<h8*>(db + (b_dst[i] ^ 16)) = lo;
             } else {
                 const bool ok = second_rec || ((tid + i * 256) & 7) < 4;
-                *reinterpret_cast<f32x4*>(db + b_dst[i]) = ok ? rb[i] : z;
+                *reinterpret_cast<f32x4*>(db + b_dst[i]) = ok ? rb[S][i] : z;
             }
         }
     };
@@ -184,14 +187,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.0f;
 
-    const int nchunks = (p.k + KC - 1) / KC;
-    fetch(0);
-    for (int it = 0; it < nchunks; ++it) {
-        const int buf = it & 1;
-        publish(buf, it * KC + 16 < p.k);
-        __syncthreads();                        // chunk `it` visible; everyone has left chunk it-1 (other buffer)
-        fetch((it + 1 < nchunks ? it + 1 : it) * KC);
-        __builtin_amdgcn_sched_barrier(0);
+    auto compute = [&](int buf) {
         const _Float16* la = lds_a + buf * A_BUF;
         const _Float16* lb = lds_b + buf * B_BUF;
 #pragma unroll
@@ -216,7 +212,36 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
                     acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mr], bh[nr], acc[mr][nr], 0, 0, 0);
                 }
         }
+    };
+
+    // Chunk c travels in register set c & 1 and LDS buffer c & 1; while chunk c is multiplied, c+1 and c+2 are in flight
+    // (a K = 256 GEMM has only 8 chunks of ~0.4 us each — one chunk of lookahead does not cover a memory round trip).
+    const int nchunks = (p.k + KC - 1) / KC, last = nchunks - 1;
+    const std::integral_constant<int, 0> S0;
+    const std::integral_constant<int, 1> S1;
+    auto clampk = [&](int c) { return (c < last ? c : last) * KC; };
+    fetch(S0, 0);
+    fetch(S1, clampk(1));
+    __builtin_amdgcn_sched_barrier(0);
+    int it = 0;
+    for (; it + 1 < nchunks; it += 2) {
+        publish(S0, 0, it * KC + 16 < p.k);
+        __syncthreads();                        // chunk `it` visible; everyone has left chunk it-1 (other buffer)
+        fetch(S0, clampk(it + 2));
         __builtin_amdgcn_sched_barrier(0);
+        compute(0);
+        __builtin_amdgcn_sched_barrier(0);
+        publish(S1, 1, (it + 1) * KC + 16 < p.k);
+        __syncthreads();
+        fetch(S1, clampk(it + 3));
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (it < nchunks) {                         // odd tail: chunk `it` (even) sits in set 0
+        publish(S0, 0, it * KC + 16 < p.k);
+        __syncthreads();
+        compute(0);
     }
 
     // ---- epilogue: lane (l32, half) holds column n and rows acc_row(r, half) of each 32 x 32 tile.  Addresses are a uniform
