@@ -107,10 +107,17 @@ def main():
     torch.cuda.synchronize()
     log("model prepared; warm-up")
     K, Wm = args.steps, args.warmup
-    if K + Wm > T_FULL:
-        raise SystemExit("steps + warmup must not exceed T=1000")
-    for _ in range(Wm):
+    left = [T_FULL]                       # steps left in the current chain; a finished chain (t = 0 done) restarts from x_T
+
+    def one_step():
+        if left[0] == 0:
+            smp.reset()
+            left[0] = T_FULL
         smp.step()
+        left[0] -= 1
+
+    for _ in range(Wm):
+        one_step()
         torch.cuda.synchronize()
         log("warm-up step done")
     if world > 1:
@@ -118,7 +125,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(K):
-        smp.step()
+        one_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
