@@ -418,7 +418,17 @@ class Plan:
         self._keep.append(d)
         up = 2 if upsample else 1
         eo = -(-edge_in * up // stride)
-        kind = "conv_k1" if w.taps == 1 else ("conv_k3s2" if stride == 2 else "conv_k3s1")
+        # kinds follow the kernel instantiations rocprofv3 lists, so bench.py's per-kernel averages can be checked against it
+        if w.taps == 1:
+            kind = "conv_k1"
+        elif stride == 2:
+            kind = "conv_k3s2"
+        elif upsample:
+            kind = "conv_up"            # 8 parity 2x2x2 convs
+        elif w.cout <= 32 and w.precision == _lib.PREC_H3:
+            kind = "conv_k3s1_n32"      # conv_in / conv_out: one 32-column tile
+        else:
+            kind = "conv_k3s1"
         self.ops.append((lib().dm3d_conv3d_ndhwc, (C.byref(d),), kind,
                          {"desc": f"{kind} {edge_in}^3{'x2up' if upsample else ''} cin={w.cin} cout={w.cout}",
                           "flops": 2.0 * w.taps * w.cin * w.cout * self.B * eo ** 3,      # algorithmic
