@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("DM3D_LIB") or os.path.join(_HERE, "csrc", "libdm3d_hi
 
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 PREC_F32, PREC_H3 = 0, 1
+WL_TAP, WL_PAIR = 0, 1
 FMT_F32, FMT_H2 = 0, 1
 COUT_PAD, CIN_PAD = 64, 16
 
@@ -29,7 +30,7 @@ class ConvDesc(C.Structure):
         ("relu", C.c_int32), ("res", _f32p), ("out", _f32p), ("cout", C.c_int32),
         ("precision", C.c_int32), ("w_exp", C.c_int32),
         ("prelu_alpha", _f32p), ("relu_out", C.c_int32), ("transpose", C.c_int32),
-        ("pro_batch_stride", C.c_int64),
+        ("pro_batch_stride", C.c_int64), ("w_layout", C.c_int32),
     ]
 
 
@@ -65,6 +66,9 @@ SIGNATURES = {
     "dm3d_pack_weights": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, _f32p, _f32p, C.c_void_p]),
     "dm3d_packed_weight_h3_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "dm3d_pack_weights_h3": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p, C.c_void_p, C.c_void_p]),
+    "dm3d_packed_weight_h3p_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "dm3d_pack_weights_h3p": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "dm3d_conv_weight_layout": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "dm3d_packed_weight_up_elems": (C.c_int64, [C.c_int32, C.c_int32]),
     "dm3d_pack_weights_up": (C.c_int, [_f32p, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
     "dm3d_packed_weight_up_h3_bytes": (C.c_int64, [C.c_int32, C.c_int32]),

@@ -13,6 +13,7 @@
 // Every input element is fetched from HBM/L2 once per workgroup and chunk (halo overhead 2.3x for a 4x8x8 brick) instead
 // of k^3 times, and activation tensors are read in their raw form, so norm/activation/concat/upsample never round-trip
 // through HBM.  LDS: 600*20*4 + 2*64*20*4 = 58 KB -> two workgroups per CU, whose staging and MFMA phases overlap.
+#include <cstdlib>
 #include "dm3d_conv_args.h"
 #include <math.h>
 
@@ -284,7 +285,31 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
                                : (d->ksize == 1 ? DM3D_CONV_K1 : (d->ksize == 4 ? DM3D_CONV_K4S2 : (d->stride == 2 ? DM3D_CONV_K3S2 : DM3D_CONV_K3S1)));
     if (par_mode) a.w_parity_stride = d->precision == DM3D_PREC_H3
         ? dm3d_packed_weight_h3_bytes(8, cin, d->cout) / 2 : dm3d_packed_weight_elems(8, cin, d->cout);
-    return d->precision == DM3D_PREC_H3 ? dm3d_conv_launch_h3(a, which, st) : dm3d_conv_launch_f32(a, which, st);
+    if (d->precision != DM3D_PREC_H3) return dm3d_conv_launch_f32(a, which, st);
+    const int layout = dm3d_conv_weight_layout(d->ksize, d->stride, d->upsample, d->transpose, d->cout);
+    DM3D_REQUIRE(d->w_layout == layout, "conv: w_layout %d but this geometry reads layout %d (dm3d_conv_weight_layout)", d->w_layout, layout);
+    return layout == DM3D_WL_PAIR ? dm3d_conv_launch_h3v2(a, which, st) : dm3d_conv_launch_h3(a, which, st);
+}
+
+extern "C" int32_t dm3d_conv_weight_layout(int32_t ksize, int32_t stride, int32_t upsample, int32_t transpose, int32_t cout) {
+    static const bool pair_off = [] { const char* e = getenv("DM3D_CONV_PAIR"); return e && e[0] == '0'; }();   // A/B switch
+    if (pair_off) return DM3D_WL_TAP;
+    if (upsample || transpose) return DM3D_WL_PAIR;
+    return (ksize == 3 && stride == 1 && cout > 32) ? DM3D_WL_PAIR : DM3D_WL_TAP;
+}
+
+extern "C" int64_t dm3d_packed_weight_h3p_bytes(int32_t taps, int32_t cin, int32_t cout) {
+    if (taps <= 0 || cin <= 0 || cout <= 0) return 0;
+    return dm3d_h3v2_image_bytes(taps, cin, cout);
+}
+
+extern "C" int dm3d_pack_weights_h3p(const float* keras_kernel, int32_t taps, int32_t cin, int32_t cout, int32_t w_exp,
+                                     const float* in_scale, void* packed, int32_t mode, void* stream) {
+    DM3D_REQUIRE(keras_kernel && packed && taps > 0 && cin > 0 && cout > 0, "pack_weights_h3p: bad arguments");
+    DM3D_REQUIRE(mode >= 0 && mode <= 2 && (mode == 0 || taps == 8), "pack_weights_h3p: mode %d with taps %d", mode, taps);
+    DM3D_REQUIRE(w_exp >= -100 && w_exp <= 100, "pack_weights_h3p: w_exp %d out of range", w_exp);
+    DM3D_REQUIRE(dm3d_aligned16(packed), "pack_weights_h3p: packed must be 16-byte aligned");
+    return dm3d_pack_h3v2(keras_kernel, taps, cin, cout, w_exp, in_scale, packed, mode, static_cast<hipStream_t>(stream));
 }
 
 int dm3d_conv_launch_f32(ConvArgs& a, int which, hipStream_t st) {

@@ -1,0 +1,365 @@
+// dm3d_conv_h3v2.hip — the k3 / stride-1 (and the 2x2x2 parity) Conv3d of dm3d_conv_h3.hip rebuilt on v_mfma_f32_16x16x32_f16.
+//
+// Why a second shape: on MI355X a loop of LDS-fed 16x16x32 MFMAs sustains ~14 % more FLOP/s than the same work as 32x32x16
+// (tools/micro/mfma_shapes.hip: 1690 vs 1478 TFLOP/s on random data; the chip holds a higher clock on this shape), and the
+// 32x32x16 kernel already runs at 75-85 % of its shape's ceiling.  Same split-float16 arithmetic (dm3d_h3.h), same brick /
+// halo / weight-group structure and epilogue fusions; what changes is the operand geometry:
+//   * K = 32 per MFMA = two consecutive taps x 16 channels.  Lane l: row = l & 15, k-group kg = l >> 4; kg >> 1 picks the tap
+//     of the pair (= lane half), kg & 1 the 8-channel half (slot of the 64-byte record).  27 taps are padded to 28 (zero weights).
+//   * A 16-row tile is a 4 x 4 voxel patch; with the halo row stride padded to 12 the 16 records of a patch are distinct mod 16.
+//     The two hardware lane groups of a ds_read_b128, {0-3,12-15,20-27} and {4-11,16-19,28-31}, each mix rows {0-3,12-15} at one
+//     slot with rows {4-11} at the other; under the XOR swizzle two such reads collide iff their records differ by +-4 mod 16,
+//     so rows {0-3,12-15} take the patch columns dx in {0,1} and rows {4-11} take dx in {2,3} (record mod 4 = dx): conflict-free
+//     for every tap.  Weight rows get the same treatment by permuting their LDS position inside each group of 16 (PI below).
+//   * A wave owns one 8 x 8 z-slice = 2 x 2 patches x 64 output channels = 16 tiles of 16 x 16 (64 accumulator registers).
+#include "dm3d_conv_args.h"
+#include "dm3d_h3.h"
+
+#ifndef V2_EXP
+#define V2_EXP 0          // timing experiments only (results are wrong when non-zero): 1 no convert, 2 no halo reload, 4 no weight refetch
+#endif
+
+namespace {
+
+constexpr int REC = DM3D_REC;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// LDS position (within its group of 16) of the weight row read by MFMA column c
+__host__ __device__ constexpr int pi_pos(int c) {
+    return c < 4 ? (c < 2 ? c : c + 2) : (c >= 12 ? (c < 14 ? c - 4 : c - 2) : (((c - 4) >> 1) * 4 + 2 + ((c - 4) & 1)));
+}
+// patch column of MFMA row i (rows 0-3 -> 0, 4-7 -> 2, 8-11 -> 3, 12-15 -> 1); patch row is i & 3
+__device__ __forceinline__ int dx_of_row(int i) { return (0x1320 >> ((i >> 2) * 4)) & 3; }
+
+template <int KS, bool PRO>
+__global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
+    constexpr int TD = 4, TH = 8, TW = 8, CK = 16, NT = 64;
+    constexpr int HD = TD - 1 + KS, HH = TH - 1 + KS, HW = TW - 1 + KS, HWP = 12;
+    constexpr int HVOX = HD * HH * HW;
+    constexpr int TAPS = KS * KS * KS, TAPSP = (TAPS + 3) / 4 * 4;
+    constexpr int G = 4, NG = TAPSP / G;                     // taps per weight group (two MFMA k-steps), groups per chunk
+    constexpr int NSLOT = (HVOX * 2 + 255) / 256;
+    constexpr int WGRP = G * NT * REC;                       // halfs per weight group (16 KB)
+    constexpr int WSLOT = WGRP * 2 / 16 / 256;               // 16-byte pieces per thread = 4
+    static_assert(WGRP * 2 / 16 % 256 == 0, "weight group must be a whole number of pieces per thread");
+
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_v2[];
+    _Float16* lds_w = smem_v2;                  // [2][G][NT][REC]   (first: every weight read is base + a 16-bit immediate)
+    _Float16* lds_in = smem_v2 + 2 * WGRP;      // [HREC][REC]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, q = (lane >> 4) & 1, row = lane & 15, g4 = lane >> 4;
+
+    int brick = blockIdx.x;
+    const int bpv = p.bd * p.bh * p.bw;
+    const int b = brick / bpv;
+    brick -= b * bpv;
+    const int oz0 = (brick / (p.bh * p.bw)) * TD;
+    const int oy0 = ((brick / p.bw) % p.bh) * TH;
+    const int ox0 = (brick % p.bw) * TW;
+    const int ntile = blockIdx.y;
+    int padz = p.padz, pady = p.pady, padx = p.padx, ooz = p.ooz, ooy = p.ooy, oox = p.oox;
+    const _Float16* wbase = static_cast<const _Float16*>(p.wpk);
+    if (p.parity) {
+        const int par = blockIdx.z;
+        ooz = par >> 2; ooy = (par >> 1) & 1; oox = par & 1;
+        padz = 1 - ooz; pady = 1 - ooy; padx = 1 - oox;
+        wbase += (size_t)par * p.w_parity_stride;
+    }
+
+    // ---- halo staging slots (identical to dm3d_conv_h3.hip)
+    const int piece = tid & 1;
+    int gvox[NSLOT], st_off[NSLOT];
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+        const int hv = (tid >> 1) + j * 128;
+        int g = -1;
+        if (hv < HVOX) {
+            const int hz = hv / (HH * HW), hy = (hv / HW) % HH, hx = hv % HW;
+            const int iz = oz0 - padz + hz, iy = oy0 - pady + hy, ix = ox0 - padx + hx;
+            if (iz >= 0 && iz < p.ind && iy >= 0 && iy < p.inh && ix >= 0 && ix < p.inw)
+                g = ((b * p.ind + iz) * p.inh + iy) * p.inw + ix;
+        }
+        gvox[j] = g;
+        const int v = (hv / HW) * HWP + hv % HW;
+        st_off[j] = hv < HVOX ? v * REC + ((piece ^ swz(v)) << 3) : -1;
+    }
+
+    // ---- operand addressing: this lane's voxel inside a 4 x 4 patch, patch (0,0) of the wave's z-slice, tap (0,0,0)
+    const int a_rec0 = (wave * HH + (row & 3)) * HWP + dx_of_row(row);
+    // weight rows: LDS position PI(row) inside the 16-column tile, the lane half picks the tap of the pair
+    const int b_pos = pi_pos(row);
+    const int b_hi = (half * NT + b_pos) * REC + ((q ^ swz(b_pos)) << 3);
+
+    f32x4v acc[4][4];
+#pragma unroll
+    for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[pi][ni] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    // weights go global -> LDS by LDS-DMA (no registers, no ds_write): the packed image IS the LDS image, so group gg is a
+    // linear 16 KB copy; wave w moves the 1 KB pieces w, w+4, w+8, w+12.  Buffer = gg & 1 (NG is odd for k3: runtime parity).
+    const char* w_img = reinterpret_cast<const char*>(wbase + (size_t)ntile * p.nchunks * NG * WGRP) + wave * 1024 + lane * 16;
+    auto fetch_w = [&](int gg) {
+        const char* src = w_img + (size_t)gg * (WGRP * 2);
+        char* dst = reinterpret_cast<char*>(lds_w) + (gg & 1) * (WGRP * 2) + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < WSLOT; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 4096),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+    };
+    fetch_w(0);
+
+    constexpr bool pro = PRO;
+    f32x4 raw0[NSLOT], raw1[NSLOT];
+    f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
+    bool ok0 = false, ok1 = false;
+    auto load_halo = [&](int ch) {
+        const int c0 = ch * CK;
+        const float* src;
+        int ldc, cb;
+        if (c0 < p.c1) { src = p.x1; ldc = p.c1; cb = c0; } else { src = p.x2; ldc = p.c2; cb = c0 - p.c1; }
+        const int cpos = cb + piece * 8;
+        ok0 = cpos < ldc;
+        ok1 = cpos + 4 < ldc;
+        const int off0 = ok0 ? cpos : 0, off1 = ok1 ? cpos + 4 : 0;
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            const float* qp = src + (size_t)(gvox[j] >= 0 ? gvox[j] : 0) * ldc;
+            raw0[j] = *reinterpret_cast<const f32x4*>(qp + off0);
+            raw1[j] = *reinterpret_cast<const f32x4*>(qp + off1);
+        }
+        if (pro) {
+            const int s0 = ok0 ? c0 + piece * 8 : 0, s1 = ok1 ? c0 + piece * 8 + 4 : 0;
+            const size_t bo = (size_t)b * p.pro_bstride;
+            sc0 = *reinterpret_cast<const f32x4*>(p.pscale + bo + s0);
+            sh0 = *reinterpret_cast<const f32x4*>(p.pshift + bo + s0);
+            sc1 = *reinterpret_cast<const f32x4*>(p.pscale + bo + s1);
+            sh1 = *reinterpret_cast<const f32x4*>(p.pshift + bo + s1);
+        }
+    };
+    load_halo(0);
+
+    int a_rec = a_rec0;
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        asm volatile("" : "+v"(a_rec));      // keeps the 14 per-pair operand addresses from being hoisted out of the chunk loop (spills)
+        h8 shi[NSLOT], slo[NSLOT];
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            const bool in = gvox[j] >= 0;
+            f32x4 v0 = raw0[j], v1 = raw1[j];
+            if (pro && !(V2_EXP & 1)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v0[e] = dm3d_silu(fmaf(v0[e], sc0[e], sh0[e]));
+                    v1[e] = dm3d_silu(fmaf(v1[e], sc1[e], sh1[e]));
+                }
+            }
+#if V2_EXP & 1
+            shi[j] = __builtin_bit_cast(h8, v0); slo[j] = __builtin_bit_cast(h8, v1);
+#else
+            split8(v0, v1, (in && ok0) ? 65504.0f : 0.0f, (in && ok1) ? 65504.0f : 0.0f, shi[j], slo[j]);
+#endif
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            if (st_off[j] >= 0) {
+                *reinterpret_cast<h8*>(lds_in + st_off[j]) = shi[j];
+                *reinterpret_cast<h8*>(lds_in + (st_off[j] ^ 16)) = slo[j];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk's first weight group (issued a group ago)
+        __syncthreads();
+#if !(V2_EXP & 2)
+        load_halo(ch + 1 < p.nchunks ? ch + 1 : ch);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const bool last_group = g + 1 == NG;
+            {
+                const int nxt = ch * NG + g + 1;
+#if !(V2_EXP & 4)
+                if (nxt < p.nchunks * NG) fetch_w(nxt);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const _Float16* wbuf = lds_w + ((ch * NG + g) & 1) * WGRP;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {                            // two tap pairs per group
+                // taps of the pair (compile-time after unrolling); the pad tap (>= TAPS) re-reads the last real tap's voxels
+                const int ta = g * G + pr * 2, tb = ta + 1;
+                const int tac = ta < TAPS ? ta : TAPS - 1, tbc = tb < TAPS ? tb : TAPS - 1;
+                const int rec_a = ((tac / (KS * KS)) * HH + (tac / KS) % KS) * HWP + tac % KS;
+                const int rec_b = ((tbc / (KS * KS)) * HH + (tbc / KS) % KS) * HWP + tbc % KS;
+                const int v0 = a_rec + (half ? rec_b : rec_a);          // patch column px = 0
+                const int v1 = v0 + 4;                                   // px = 1 (different swizzle term)
+                const int o0 = v0 * REC + ((q ^ swz(v0)) << 3);
+                const int o1 = v1 * REC + ((q ^ swz(v1)) << 3);
+                h8 ah[4], al[4];
+#pragma unroll
+                for (int py = 0; py < 2; ++py) {                         // patch rows are 4*HWP = 48 records apart: same swizzle
+                    ah[py * 2 + 0] = *reinterpret_cast<const h8*>(lds_in + o0 + py * (48 * REC));
+                    al[py * 2 + 0] = *reinterpret_cast<const h8*>(lds_in + (o0 ^ 16) + py * (48 * REC));
+                    ah[py * 2 + 1] = *reinterpret_cast<const h8*>(lds_in + o1 + py * (48 * REC));
+                    al[py * 2 + 1] = *reinterpret_cast<const h8*>(lds_in + (o1 ^ 16) + py * (48 * REC));
+                }
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {                         // weights in two batches of two column tiles
+                    h8 bh[2], bl[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int ni = nb * 2 + k;
+                        bh[k] = *reinterpret_cast<const h8*>(wbuf + (pr * 2 * NT + ni * 16) * REC + b_hi);
+                        bl[k] = *reinterpret_cast<const h8*>(wbuf + (pr * 2 * NT + ni * 16) * REC + (b_hi ^ 16));
+                    }
+#pragma unroll
+                    for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            f32x4v& c = acc[pi][nb * 2 + k];
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[pi], bh[k], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi], bl[k], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi], bh[k], c, 0, 0, 0);
+                        }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!last_group) __syncthreads();      // the DMA of the next group has landed (vmcnt) and every wave is done with this one
+        }
+    }
+
+    // ---- epilogue.  Accumulator register r of tile (patch pi, column tile ni): voxel (dy = 4*(pi>>1) + r, dx = 4*(pi&1) +
+    // dx_of_row(4*g4)), output channel ni*16 + row.
+    const int vrow = p.vec ? (p.vec_idx ? p.vec_idx[b] : b) : 0;
+    const int n0 = ntile * NT;
+    const bool full = oz0 + TD <= p.od && oy0 + TH <= p.oh && ox0 + TW <= p.ow && n0 + NT <= p.cout;
+    const int oz = oz0 + wave;
+    const bool z_ok = oz < p.od;
+    const size_t zbase = (((size_t)b * p.fd + (z_ok ? oz * p.os + ooz : 0)) * p.fh) * p.fw * p.cout;
+    float* outz = p.out + zbase;
+    const float* resz = p.res ? p.res + zbase : nullptr;
+    const float* prz = p.prelu ? p.prelu + (zbase - (size_t)b * p.fd * p.fh * p.fw * p.cout) : nullptr;
+    const int dxl = dx_of_row(4 * g4);
+    const int ystep = p.os * p.fw * p.cout;                              // one brick row further in the output
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + ni * 16 + row;
+        const bool n_ok = n < p.cout;
+        const int nc = n_ok ? n : p.cout - 1;
+        float add = p.bias ? p.bias[nc] : 0.0f;
+        if (p.vec) add += p.vec[(size_t)vrow * p.vec_ld + nc];
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) {
+            const int oyb = oy0 + 4 * (pi >> 1), ox = ox0 + 4 * (pi & 1) + dxl;
+            const int base = ((oyb * p.os + ooy) * p.fw + ox * p.os + oox) * p.cout + nc;
+            float rv[4];
+            if (full) {
+                if (resz) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rv[r] = resz[base + r * ystep];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = base + r * ystep;
+                    float v = fmaf(acc[pi][ni][r], p.out_scale, add);
+                    if (p.relu) v = fmaxf(v, 0.0f);
+                    if (prz) { const float al = prz[o]; v = v > 0.0f ? v : al * v; }
+                    if (resz) v += rv[r];
+                    if (p.relu_out) v = fmaxf(v, 0.0f);
+                    outz[o] = v;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = n_ok && z_ok && oyb + r < p.oh && ox < p.ow;
+                    const int o = ok ? base + r * ystep : 0;
+                    float v = fmaf(acc[pi][ni][r], p.out_scale, add);
+                    if (p.relu) v = fmaxf(v, 0.0f);
+                    if (prz) { const float al = prz[o]; v = v > 0.0f ? v : al * v; }
+                    if (resz) v += resz[o];
+                    if (p.relu_out) v = fmaxf(v, 0.0f);
+                    if (ok) outz[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int KS, bool PRO>
+int launch_v2(ConvArgs& a, hipStream_t st) {
+    constexpr int HREC = (3 + KS) * (7 + KS) * 12;
+    constexpr size_t lds = (size_t)(HREC * REC + 2 * 4 * 64 * REC) * sizeof(_Float16);
+    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+    a.bd = (a.od + 3) / 4;
+    a.bh = (a.oh + 7) / 8;
+    a.bw = (a.ow + 7) / 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3v2<KS, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64), a.parity ? 8u : 1u);
+    hipLaunchKernelGGL((conv3d_igemm_h3v2<KS, PRO>), grid, dim3(256), lds, st, a);
+    return dm3d_launch_check("conv3d_igemm_h3v2");
+}
+
+// weight image of the v2 kernel: [coutpad/64][cinpad/16][TAPSP][64 positions][REC]; position 16*t16 + PI(c) holds output channel
+// 64*ntile + 16*t16 + c; taps >= taps are zero; slots swizzled by the position.  mode: 0 plain, 1 UpSample sums, 2 Conv3DTranspose
+__global__ __launch_bounds__(256) void pack_weights_h3v2_kernel(const float* __restrict__ w, int taps, int tapsp, int cin, int cout,
+                                                                int nchunks, int ntiles, float scale, const float* in_scale,
+                                                                _Float16* __restrict__ out, int mode) {
+    const long nrec = (long)ntiles * nchunks * tapsp * 64;
+    const int npar = mode ? 8 : 1;
+    for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < nrec * 16 * npar; i0 += (long)gridDim.x * 256) {
+        const int par = (int)(i0 / (nrec * 16));
+        const long i = i0 % (nrec * 16);
+        const int k = (int)(i & 15);
+        const long rec = i >> 4;
+        const int pos = (int)(rec % 64);
+        const int tap = (int)((rec / 64) % tapsp);
+        const int chunk = (int)((rec / (64L * tapsp)) % nchunks);
+        const int nt = (int)(rec / (64L * tapsp * nchunks));
+        // invert PI inside the group of 16
+        const int p16 = pos & 15;
+        int c = 0;
+        for (int cc = 0; cc < 16; ++cc) if (pi_pos(cc) == p16) c = cc;
+        const int ci = chunk * 16 + k, co = nt * 64 + (pos & ~15) + c;
+        float v = 0.f;
+        if (ci < cin && co < cout && tap < taps) {
+            v = mode == 1 ? dm3d_up_weight(w, cin, cout, par, tap, ci, co)
+              : mode == 2 ? dm3d_convt_weight(w, cin, cout, par, tap, ci, co) : w[((long)tap * cin + ci) * cout + co];
+            if (in_scale) v *= in_scale[ci];
+            v *= scale;
+        }
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        _Float16* r = out + ((long)par * nrec + rec) * REC;
+        const int sw = (pos >> 2) & 3;
+        r[(((k >> 3) ^ sw) << 3) + (k & 7)] = hi;
+        r[(((2 + (k >> 3)) ^ sw) << 3) + (k & 7)] = lo;
+    }
+}
+
+}  // namespace
+
+int dm3d_conv_launch_h3v2(ConvArgs& a, int which, hipStream_t st) {
+    if (which == DM3D_CONV_UP) return a.pscale ? launch_v2<2, true>(a, st) : launch_v2<2, false>(a, st);
+    return a.pscale ? launch_v2<3, true>(a, st) : launch_v2<3, false>(a, st);
+}
+
+int64_t dm3d_h3v2_image_bytes(int taps, int cin, int cout) {
+    const int tapsp = (taps + 3) / 4 * 4;
+    return (int64_t)tapsp * dm3d_round_up(cout, 64) * (dm3d_round_up(cin, 16) / 16) * REC * (int64_t)sizeof(_Float16);
+}
+
+int dm3d_pack_h3v2(const float* keras_kernel, int taps, int cin, int cout, int w_exp, const float* in_scale, void* packed, int mode,
+                   hipStream_t st) {
+    const int nchunks = (int)(dm3d_round_up(cin, 16) / 16), ntiles = (int)(dm3d_round_up(cout, 64) / 64);
+    hipLaunchKernelGGL(pack_weights_h3v2_kernel, dim3(4096), dim3(256), 0, st, keras_kernel, taps, (taps + 3) / 4 * 4, cin, cout,
+                       nchunks, ntiles, ldexpf(1.0f, w_exp), in_scale, static_cast<_Float16*>(packed), mode);
+    return dm3d_launch_check("pack_weights_h3v2_kernel");
+}

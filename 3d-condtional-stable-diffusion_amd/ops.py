@@ -41,8 +41,9 @@ def pack_weights(kernel: torch.Tensor, in_scale: Optional[torch.Tensor] = None) 
     return out
 
 
-def pack_weights_h3(kernel: torch.Tensor, in_scale: Optional[torch.Tensor] = None):
-    """Keras kernel -> (float16 hi/lo image for the H3 conv kernels, w_exp).  max|w|*2^w_exp lands in [2^13, 2^14)."""
+def pack_weights_h3(kernel: torch.Tensor, in_scale: Optional[torch.Tensor] = None, stride: int = 1):
+    """Keras kernel -> (float16 hi/lo image for the H3 conv kernels, w_exp).  max|w|*2^w_exp lands in [2^13, 2^14).
+    ``stride`` is the stride of the conv that will read the image: it selects the layout (dm3d_conv_weight_layout)."""
     _f32c(kernel, "kernel")
     if kernel.dim() not in (2, 5):
         raise ValueError("kernel must be [in,out] or [kd,kh,kw,cin,cout]")
@@ -51,6 +52,12 @@ def pack_weights_h3(kernel: torch.Tensor, in_scale: Optional[torch.Tensor] = Non
     wmax = float(kernel.abs().max())
     import math
     w_exp = 0 if wmax == 0.0 or not math.isfinite(wmax) else int(13 - math.floor(math.log2(wmax)))
+    ksize = {1: 1, 27: 3, 64: 4}.get(taps, 0)
+    if ksize and lib().dm3d_conv_weight_layout(ksize, stride, 0, 0, cout) == _lib.WL_PAIR:
+        out = torch.empty(lib().dm3d_packed_weight_h3p_bytes(taps, cin, cout) // 2, dtype=torch.float16, device=kernel.device)
+        check(lib().dm3d_pack_weights_h3p(kernel.data_ptr(), taps, cin, cout, w_exp, _p(in_scale), out.data_ptr(), 0, _st()),
+              "pack_weights_h3p")
+        return out, w_exp
     out = torch.empty(lib().dm3d_packed_weight_h3_bytes(taps, cin, cout) // 2, dtype=torch.float16, device=kernel.device)
     check(lib().dm3d_pack_weights_h3(kernel.data_ptr(), taps, cin, cout, w_exp, _p(in_scale), out.data_ptr(), _st()),
           "pack_weights_h3")
@@ -125,6 +132,8 @@ def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False
         raise ValueError("res must have the output's shape")
     d.relu, d.res, d.out, d.cout = int(bool(relu)), _p(res), out.data_ptr(), cout
     d.precision, d.w_exp = precision, w_exp
+    if precision == _lib.PREC_H3:
+        d.w_layout = lib().dm3d_conv_weight_layout(ksize, stride, int(bool(upsample)), int(bool(transpose)), cout)
     if prelu_alpha is not None and tuple(prelu_alpha.shape) != (od, oh, ow, cout):
         raise ValueError("prelu_alpha must be [out_d, out_h, out_w, cout]")
     d.prelu_alpha, d.relu_out, d.transpose = _p(prelu_alpha), int(bool(relu_out)), int(bool(transpose))

@@ -106,7 +106,7 @@ class UNet:
         return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(self.device)
 
     def _pack(self, kernel: np.ndarray, bias: Optional[np.ndarray], in_scale: Optional[torch.Tensor] = None,
-              conv: bool = False, up: bool = False) -> _Conv:
+              conv: bool = False, up: bool = False, stride: int = 1) -> _Conv:
         """``conv=True``: weights of a dm3d_conv3d_ndhwc launch (packed for self.precision); otherwise GEMM operand.
         ``up=True``: UpSample conv — packed as the 8 parity 2x2x2 kernels the upsample launch expects."""
         shape = kernel.shape
@@ -129,10 +129,14 @@ class UNet:
             wmax = float(np.abs(kernel).max())
             w_exp = 0 if wmax == 0.0 or not np.isfinite(wmax) else int(13 - np.floor(np.log2(wmax)))
             w_exp = max(-100, min(100, w_exp))
-            nbytes = lib().dm3d_packed_weight_h3_bytes(taps, cin, cout)
-            wpk = torch.empty(nbytes // 2, dtype=torch.float16, device=self.device)
-            check(lib().dm3d_pack_weights_h3(raw.data_ptr(), taps, cin, cout, w_exp, _ptr(in_scale), wpk.data_ptr(),
-                                             _stream()), "pack_weights_h3")
+            if lib().dm3d_conv_weight_layout({1: 1, 27: 3}[taps], stride, 0, 0, cout) == _lib.WL_PAIR:
+                wpk = torch.empty(lib().dm3d_packed_weight_h3p_bytes(taps, cin, cout) // 2, dtype=torch.float16, device=self.device)
+                check(lib().dm3d_pack_weights_h3p(raw.data_ptr(), taps, cin, cout, w_exp, _ptr(in_scale), wpk.data_ptr(), 0,
+                                                  _stream()), "pack_weights_h3p")
+            else:
+                wpk = torch.empty(lib().dm3d_packed_weight_h3_bytes(taps, cin, cout) // 2, dtype=torch.float16, device=self.device)
+                check(lib().dm3d_pack_weights_h3(raw.data_ptr(), taps, cin, cout, w_exp, _ptr(in_scale), wpk.data_ptr(),
+                                                 _stream()), "pack_weights_h3")
             return _Conv(wpk, self._dev(bias) if bias is not None else None, taps, cin, cout, _lib.PREC_H3, w_exp)
         n = lib().dm3d_packed_weight_elems(taps, cin, cout)
         wpk = torch.empty(n, dtype=torch.float32, device=self.device)
@@ -186,7 +190,7 @@ class UNet:
                 self.temb_off[n] = off
                 off += blk.cout
             elif blk.kind in ("down", "up"):
-                P[n] = self._pack(s[f"{n}.kernel"], s[f"{n}.bias"], conv=True, up=blk.kind == "up")
+                P[n] = self._pack(s[f"{n}.kernel"], s[f"{n}.bias"], conv=True, up=blk.kind == "up", stride=2 if blk.kind == "down" else 1)
             elif blk.kind == "attn":
                 self._prepare_attn(P, blk)
         self.temb_ld = off
@@ -408,6 +412,8 @@ class Plan:
         d.ksize = {1: 1, 27: 3}[w.taps]
         d.wpk, d.bias = w.wpk.data_ptr(), _ptr(w.bias)
         d.precision, d.w_exp = w.precision, w.w_exp
+        if w.precision == _lib.PREC_H3:
+            d.w_layout = lib().dm3d_conv_weight_layout(d.ksize, stride, upsample, 0, w.cout)
         if pro is not None:
             d.pro_scale, d.pro_shift, d.pro_batch_stride = _ptr(pro[0]), _ptr(pro[1]), pro_bstride
         if vec_off is not None:

@@ -158,8 +158,8 @@ def main():
         n, ms, fl, by, ex = acc["conv_k3s1"]
         achieved = fl / (ms * 1e-3) / 1e12
         if args.precision == "h3":
-            kname = ("conv3d_igemm_h3<4, 8, 8, 1, 3, 4, 1, 2, 0> (k3 stride-1 Conv3d; float16 hi+lo split, 3 x "
-                     "v_mfma_f32_32x32x16_f16 per algorithmic product, fp32 accumulate)")
+            kname = ("conv3d_igemm_h3v2<3, true> (k3 stride-1 Conv3d with the fused norm+SiLU prologue; float16 hi+lo split, 3 x "
+                     "v_mfma_f32_16x16x32_f16 per algorithmic product, fp32 accumulate)")
             peak, passes = PEAK_F16_MFMA_TFLOPS, 3
         else:
             kname, peak, passes = "conv3d_igemm_f32<4, 8, 8, 1, 3, 4, 1> (k3 stride-1 Conv3d, v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS, 1
@@ -182,7 +182,7 @@ def main():
         try:
             import csv
             path = os.path.join(ROOT, "profiles", "r01_h3_pmc_hbm.csv" if args.precision == "h3" else "r01_fp32_pmc_hbm.csv")
-            want = "conv3d_igemm_h3<4, 8, 8, 1, 3, 4, 1, 2, 0>" if args.precision == "h3" else "conv3d_igemm_f32<4, 8, 8, 1, 3, 4, 1>"
+            want = "conv3d_igemm_h3v2<3, true>" if args.precision == "h3" else "conv3d_igemm_f32<4, 8, 8, 1, 3, 4, 1>"
             for row in csv.reader(l for l in open(path) if not l.startswith("#")):
                 if row and row[0] == want:
                     roofline["traffic"] = float(row[4]) * 1e6

@@ -69,8 +69,8 @@ int64_t dm3d_packed_weight_elems(int32_t taps, int32_t cin, int32_t cout);
 int     dm3d_pack_weights(const float* keras_kernel, int32_t taps, int32_t cin, int32_t cout,
                           const float* in_scale, float* packed, void* stream);
 
-/* H3 image: [CoutPad/64][CinPad/16][taps][64][40 halfs] = per output channel 16 hi, 16 lo, 8 pad float16 (an 80-byte LDS
- * record), weights multiplied by 2^w_exp before the split.  Same element count as dm3d_packed_weight_elems * 5/4 halfs;
+/* H3 image: [CoutPad/64][CinPad/16][taps][64][32 halfs] = per output channel one 64-byte LDS record (hi c0-7, hi c8-15,
+ * lo c0-7, lo c8-15; the four 16-byte slots XOR-swizzled by the row), weights multiplied by 2^w_exp before the split.
  * dm3d_packed_weight_h3_bytes gives the buffer size. */
 int64_t dm3d_packed_weight_h3_bytes(int32_t taps, int32_t cin, int32_t cout);
 int     dm3d_pack_weights_h3(const float* keras_kernel, int32_t taps, int32_t cin, int32_t cout, int32_t w_exp,
@@ -84,11 +84,25 @@ int64_t dm3d_packed_weight_up_elems(int32_t cin, int32_t cout);
 int     dm3d_pack_weights_up(const float* keras_kernel, int32_t cin, int32_t cout, float* packed, void* stream);
 int64_t dm3d_packed_weight_up_h3_bytes(int32_t cin, int32_t cout);
 int     dm3d_pack_weights_up_h3(const float* keras_kernel, int32_t cin, int32_t cout, int32_t w_exp, void* packed, void* stream);
+/* (the _up_h3 and _convt_h3 packers write whichever layout dm3d_conv_weight_layout names for their conv, see below) */
 
 /* Conv3DTranspose(k=4, strides=2, padding="same") kernels are [4,4,4,Cout,Cin] in Keras; packed as 8 parity images of a
  * taps=8 conv like the UpSample case (same buffer sizes: dm3d_packed_weight_up_elems / _up_h3_bytes with cin, cout). */
 int     dm3d_pack_weights_convt(const float* keras_kernel, int32_t cin, int32_t cout, float* packed, void* stream);
 int     dm3d_pack_weights_convt_h3(const float* keras_kernel, int32_t cin, int32_t cout, int32_t w_exp, void* packed, void* stream);
+
+/* Second H3 weight layout, DM3D_WL_PAIR: the image read by the v_mfma_f32_16x16x32_f16 conv kernel (k3/s1 with cout > 32,
+ * UpSample, Conv3DTranspose): taps padded to a multiple of 4 with zeros and consumed two at a time, rows permuted inside each
+ * group of 16 output channels so that the operand reads are bank-conflict free.  mode 0: plain [taps,Cin,Cout] kernel;
+ * mode 1: UpSample [3,3,3,Cin,Cout] -> 8 parity images of 8 taps; mode 2: Conv3DTranspose [4,4,4,Cout,Cin] -> 8 parity images.
+ * dm3d_packed_weight_h3p_bytes is the size of ONE image (multiply by 8 for modes 1 and 2, where taps must be 8). */
+#define DM3D_WL_TAP   0
+#define DM3D_WL_PAIR  1
+int64_t dm3d_packed_weight_h3p_bytes(int32_t taps, int32_t cin, int32_t cout);
+int     dm3d_pack_weights_h3p(const float* keras_kernel, int32_t taps, int32_t cin, int32_t cout, int32_t w_exp,
+                              const float* in_scale, void* packed, int32_t mode, void* stream);
+/* the layout dm3d_conv3d_ndhwc wants in wpk for a DM3D_PREC_H3 conv of this geometry (what w_layout must say) */
+int32_t dm3d_conv_weight_layout(int32_t ksize, int32_t stride, int32_t upsample, int32_t transpose, int32_t cout);
 
 /* ---- Conv3D(padding="same") as implicit GEMM on MFMA ---------------------------------------------------------
  * Replaces layers.Conv3D for k=3/s=1 (:257-259, :348-353, :412-414), k=3/s=2 (DownSample :274-285, TF SAME pad 0
@@ -133,6 +147,7 @@ typedef struct dm3d_conv_desc {
     int64_t pro_batch_stride;   /* elements between consecutive samples' pro_scale / pro_shift vectors: 0 = one vector for
                                    the batch (folded BatchNormalization), c1+c2 = per-sample vectors (GroupNormalization,
                                    written by dm3d_groupnorm_finalize) */
+    int32_t w_layout;           /* H3 only: DM3D_WL_TAP or DM3D_WL_PAIR, must equal dm3d_conv_weight_layout(...) */
 } dm3d_conv_desc;
 
 int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream);

@@ -94,7 +94,7 @@ def test_conv3d(dev, case, prec):
                     relu="relu" in extras, res=res)
     c = lambda t: None if t is None else t.to(dev).contiguous()
     if prec == "h3":
-        wpk, w_exp = ops.pack_weights_up(c(kern), h3=True) if ups else ops.pack_weights_h3(c(kern))
+        wpk, w_exp = ops.pack_weights_up(c(kern), h3=True) if ups else ops.pack_weights_h3(c(kern), stride=stride)
         pk = dict(precision=_lib.PREC_H3, w_exp=w_exp)
     else:
         wpk, pk = (ops.pack_weights_up(c(kern)) if ups else ops.pack_weights(c(kern))), {}

@@ -27,7 +27,7 @@ for name, e, c1, c2, cout, ks, stride, ups, pro, res, vec in CASES:
     x2 = torch.randn(B, e, e, e, c2, device=dev) if c2 else None
     k = torch.randn(ks, ks, ks, c1 + c2, cout, device=dev) * 0.05
     if prec == "h3":
-        wpk, w_exp = ops.pack_weights_up(k, h3=True) if ups else ops.pack_weights_h3(k)
+        wpk, w_exp = ops.pack_weights_up(k, h3=True) if ups else ops.pack_weights_h3(k, stride=stride)
         kw = dict(precision=_lib.PREC_H3, w_exp=w_exp)
     else:
         wpk, kw = (ops.pack_weights_up(k) if ups else ops.pack_weights(k)), {}
