@@ -15,10 +15,6 @@
 #include "dm3d_conv_args.h"
 #include "dm3d_h3.h"
 
-#ifndef V2_EXP
-#define V2_EXP 0          // timing experiments only (results are wrong when non-zero): 1 no convert, 2 no halo reload, 4 no weight refetch
-#endif
-
 namespace {
 
 constexpr int REC = DM3D_REC;
@@ -149,18 +145,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
         for (int j = 0; j < NSLOT; ++j) {
             const bool in = gvox[j] >= 0;
             f32x4 v0 = raw0[j], v1 = raw1[j];
-            if (pro && !(V2_EXP & 1)) {
+            if (pro) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v0[e] = dm3d_silu(fmaf(v0[e], sc0[e], sh0[e]));
                     v1[e] = dm3d_silu(fmaf(v1[e], sc1[e], sh1[e]));
                 }
             }
-#if V2_EXP & 1
-            shi[j] = __builtin_bit_cast(h8, v0); slo[j] = __builtin_bit_cast(h8, v1);
-#else
             split8(v0, v1, (in && ok0) ? 65504.0f : 0.0f, (in && ok1) ? 65504.0f : 0.0f, shi[j], slo[j]);
-#endif
         }
         __syncthreads();
 #pragma unroll
@@ -172,9 +164,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk's first weight group (issued a group ago)
         __syncthreads();
-#if !(V2_EXP & 2)
         load_halo(ch + 1 < p.nchunks ? ch + 1 : ch);
-#endif
         __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
@@ -182,9 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
             const bool last_group = g + 1 == NG;
             {
                 const int nxt = ch * NG + g + 1;
-#if !(V2_EXP & 4)
                 if (nxt < p.nchunks * NG) fetch_w(nxt);
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             const _Float16* wbuf = lds_w + ((ch * NG + g) & 1) * WGRP;
@@ -245,6 +233,42 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
     const float* prz = p.prelu ? p.prelu + (zbase - (size_t)b * p.fd * p.fh * p.fw * p.cout) : nullptr;
     const int dxl = dx_of_row(4 * g4);
     const int ystep = p.os * p.fw * p.cout;                              // one brick row further in the output
+    if (full) {
+        // full brick (the common case): all 64 residual values of this lane are requested before the first one is used, so the
+        // epilogue pays one memory latency instead of sixteen
+        float rv[4][4][4];
+        if (resz) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        rv[ni][pi][r] = resz[((oy0 + 4 * (pi >> 1)) * p.os + ooy) * p.fw * p.cout
+                                             + ((ox0 + 4 * (pi & 1) + dxl) * p.os + oox) * p.cout + n0 + ni * 16 + row + r * ystep];
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + ni * 16 + row;
+            float add = p.bias ? p.bias[n] : 0.0f;
+            if (p.vec) add += p.vec[(size_t)vrow * p.vec_ld + n];
+#pragma unroll
+            for (int pi = 0; pi < 4; ++pi) {
+                const int base = (((oy0 + 4 * (pi >> 1)) * p.os + ooy) * p.fw + (ox0 + 4 * (pi & 1) + dxl) * p.os + oox) * p.cout + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = base + r * ystep;
+                    float v = fmaf(acc[pi][ni][r], p.out_scale, add);
+                    if (p.relu) v = fmaxf(v, 0.0f);
+                    if (prz) { const float al = prz[o]; v = v > 0.0f ? v : al * v; }
+                    if (resz) v += rv[ni][pi][r];
+                    if (p.relu_out) v = fmaxf(v, 0.0f);
+                    outz[o] = v;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
         const int n = n0 + ni * 16 + row;
@@ -256,34 +280,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
         for (int pi = 0; pi < 4; ++pi) {
             const int oyb = oy0 + 4 * (pi >> 1), ox = ox0 + 4 * (pi & 1) + dxl;
             const int base = ((oyb * p.os + ooy) * p.fw + ox * p.os + oox) * p.cout + nc;
-            float rv[4];
-            if (full) {
-                if (resz) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) rv[r] = resz[base + r * ystep];
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = base + r * ystep;
-                    float v = fmaf(acc[pi][ni][r], p.out_scale, add);
-                    if (p.relu) v = fmaxf(v, 0.0f);
-                    if (prz) { const float al = prz[o]; v = v > 0.0f ? v : al * v; }
-                    if (resz) v += rv[r];
-                    if (p.relu_out) v = fmaxf(v, 0.0f);
-                    outz[o] = v;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = n_ok && z_ok && oyb + r < p.oh && ox < p.ow;
-                    const int o = ok ? base + r * ystep : 0;
-                    float v = fmaf(acc[pi][ni][r], p.out_scale, add);
-                    if (p.relu) v = fmaxf(v, 0.0f);
-                    if (prz) { const float al = prz[o]; v = v > 0.0f ? v : al * v; }
-                    if (resz) v += resz[o];
-                    if (p.relu_out) v = fmaxf(v, 0.0f);
-                    if (ok) outz[o] = v;
-                }
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = n_ok && z_ok && oyb + r < p.oh && ox < p.ow;
+                const int o = ok ? base + r * ystep : 0;
+                float v = fmaf(acc[pi][ni][r], p.out_scale, add);
+                if (p.relu) v = fmaxf(v, 0.0f);
+                if (prz) { const float al = prz[o]; v = v > 0.0f ? v : al * v; }
+                if (resz) v += resz[o];
+                if (p.relu_out) v = fmaxf(v, 0.0f);
+                if (ok) outz[o] = v;
             }
         }
     }

@@ -199,7 +199,7 @@ def main():
         torch.set_num_threads(cores)
         ocfg = rt.UNetConfig(img_size=S, img_channels=Cc)
         Wt = {k: torch.from_numpy(v) for k, v in W.items()}
-        cb, csteps = 2, 3
+        cb, csteps = 8, 10                 # ~10-20 s of host work: a bounded sample of the same workload
         g = torch.Generator().manual_seed(1234)
         x = torch.randn(cb, S, S, S, Cc, generator=g)
         noises = {i: torch.randn(cb, S, S, S, Cc, generator=g) for i in range(T_FULL - csteps - 1, T_FULL)}

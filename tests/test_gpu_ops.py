@@ -108,6 +108,39 @@ def test_conv3d(dev, case, prec):
     assert err < 2e-5, f"{name}: rel err {err:.3e}"
 
 
+def test_conv3d_h3_tap_layout_arm(dev):
+    """DM3D_CONV_PAIR=0 (read when the library is loaded) routes every H3 conv to the 32x32x16 kernel with the DM3D_WL_TAP weight
+    layout: the A/B arm of the 16x16x32 kernel must stay correct.  One child interpreter, same parity cases."""
+    import os, subprocess, sys
+    if os.environ.get("DM3D_CONV_PAIR") == "0":
+        pytest.skip("already inside the tap-layout arm")
+    env = dict(os.environ, DM3D_CONV_PAIR="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_conv3d and h3",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
+def test_conv3d_weight_layout_is_checked(dev):
+    from dm3d_amd import ops, _lib
+    lib = _lib.lib()
+    assert lib.dm3d_conv_weight_layout(3, 1, 0, 0, 64) in (_lib.WL_TAP, _lib.WL_PAIR)
+    assert lib.dm3d_conv_weight_layout(3, 2, 0, 0, 64) == _lib.WL_TAP
+    assert lib.dm3d_conv_weight_layout(1, 1, 0, 0, 64) == _lib.WL_TAP
+    assert lib.dm3d_conv_weight_layout(3, 1, 0, 0, 8) == _lib.WL_TAP
+    x = torch.randn(1, 8, 8, 8, 16, device=dev)
+    k = torch.randn(3, 3, 3, 16, 64, device=dev)
+    wpk, w_exp = ops.pack_weights_h3(k, stride=2)            # stride-2 image ...
+    if lib.dm3d_conv_weight_layout(3, 1, 0, 0, 64) == _lib.WL_PAIR:
+        d = _lib.ConvDesc()
+        out = torch.empty(1, 8, 8, 8, 64, device=dev)
+        d.x1, d.c1, d.batch, d.in_d, d.in_h, d.in_w, d.ksize, d.stride = x.data_ptr(), 16, 1, 8, 8, 8, 3, 1
+        d.wpk, d.out, d.cout, d.precision, d.w_exp, d.w_layout = wpk.data_ptr(), out.data_ptr(), 64, _lib.PREC_H3, w_exp, _lib.WL_TAP
+        assert lib.dm3d_conv3d_ndhwc(C.byref(d), None) != 0     # ... handed to a stride-1 conv: the layout tag does not match
+        assert b"w_layout" in lib.dm3d_last_error()
+
+
 def test_conv3d_h3_extreme_magnitudes(dev):
     """H3 split: tiny and huge activations / weights keep float32-grade relative accuracy (power-of-two weight scaling,
     float16 subnormal lo terms, clamp at 65504)."""
