@@ -245,50 +245,98 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
     }
 
     // ---- epilogue: lane (l32, half) holds column n and rows acc_row(r, half) of each 32 x 32 tile.  Addresses are a uniform
-    // 64-bit tile base plus 32-bit lane offsets; a small-K GEMM has only ~200 MFMAs per wave, so per-element 64-bit index
-    // arithmetic and predicates would cost more issue slots than the contraction itself.
+    // 64-bit tile base plus 32-bit lane offsets.  A small-K GEMM has only ~200 MFMAs per wave, so the epilogue is written for
+    // latency: every option is a uniform select (no per-element branch — hipcc waits vmcnt(0) behind each load that sits under
+    // one), the residual / row-bias loads of a 64-column half are all issued before the first is used (absent operands read
+    // element 0 of A instead and are discarded), and the H2 pair exchange is one DPP move.
     const bool full = m0 + TM <= p.m && n0 + NT <= p.n;
     char* O = static_cast<char*>(p.out) + ((size_t)bz * p.so + (size_t)m0 * p.ldo) * 4;
-    const float* R = p.res ? p.res + (size_t)bz * p.sr + (size_t)m0 * p.ldr : nullptr;
-    const float* R2 = p.res2 ? p.res2 + (size_t)bz * p.sr + (size_t)m0 * p.ldr : nullptr;
+    const bool has_r = p.res != nullptr, has_r2 = p.res2 != nullptr, has_bm = p.bias && p.bias_m, has_bn = p.bias && !p.bias_m;
+    const float* dummy = static_cast<const float*>(p.a);
+    const float* R = has_r ? p.res + (size_t)bz * p.sr + (size_t)m0 * p.ldr : dummy;
+    const float* R2 = p.res2 + (size_t)bz * p.sr + (size_t)m0 * p.ldr;
+    const float* Bm = p.bias + m0;
+    const float* Bn = has_bn ? p.bias : dummy;
+    const int r_mul = has_r ? 1 : 0, bn_mul = has_bn ? 1 : 0;
     const int lrow = wm * 64 + 4 * half;                       // + mr*32 + (r&3) + 8*(r>>2)
     const int ldo = (int)p.ldo, ldr = (int)p.ldr;
+    const float lo_bound = p.act == DM3D_ACT_RELU ? 0.0f : -3.4e38f;
+    const int row_max = p.m - 1 - m0;                          // last valid row of this tile (partial tiles clamp their loads)
+    auto epilogue = [&](auto FULL_T, auto H2_T) {
+        constexpr bool FULL = decltype(FULL_T)::value, H2 = decltype(H2_T)::value;
 #pragma unroll
-    for (int nr = 0; nr < 2; ++nr) {
-        const int n = n0 + wn * 64 + nr * 32 + l32;
-        const bool n_ok = n < p.n;
-        const int nc = n_ok ? n : p.n - 1;
-        const float bn = (p.bias && !p.bias_m) ? p.bias[nc] : 0.0f;
-        // H2 column position inside its row: record n >> 4, slot (n >> 3) & 1 (+2 for lo), element n & 7; lanes n and n^1
-        // exchange halves so that every lane stores one dword: even lanes the hi pair, odd lanes the lo pair
-        const int h2col = (n >> 4) * 64 + ((n >> 3) & 1) * 16 + ((n & 7) >> 1) * 4 + (n & 1) * 32;
-        const int ocol = p.out_h2 ? h2col : n * 4;
+        for (int nr = 0; nr < 2; ++nr) {
+            const int n = n0 + wn * 64 + nr * 32 + l32;
+            const bool n_ok = FULL || n < p.n;
+            const int nc = n_ok ? n : p.n - 1;
+            const float bnv = Bn[nc * bn_mul];
+            const float bn = has_bn ? bnv : 0.0f;
+            // H2 column position inside its row: record n >> 4, slot (n >> 3) & 1 (+2 for lo), element n & 7; lanes n and n^1
+            // exchange halves so that every lane stores one dword: even lanes the hi pair, odd lanes the lo pair
+            const int ocol = H2 ? (n >> 4) * 64 + ((n >> 3) & 1) * 16 + ((n & 7) >> 1) * 4 + (n & 1) * 32 : n * 4;
 #pragma unroll
-        for (int mr = 0; mr < 2; ++mr) {
-            float rv[16], bm[16];
+            for (int mr = 0; mr < 2; ++mr) {
+                __builtin_amdgcn_sched_barrier(0);                   // one 32 x 32 block at a time: 16 loads in flight, not 64
+                float rv[16], v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = lrow + mr * 32 + (r & 3) + 8 * (r >> 2);
-                const int rc = full ? row : (m0 + row < p.m ? row : p.m - 1 - m0);
-                rv[r] = R ? R[rc * ldr + nc] : 0.0f;
-                if (R2) rv[r] += R2[rc * ldr + nc];
-                bm[r] = (p.bias && p.bias_m) ? p.bias[m0 + rc] : 0.0f;
-            }
+                for (int r = 0; r < 16; ++r) {                       // the common residual: requested first, unconditionally
+                    const int row = lrow + mr * 32 + (r & 3) + 8 * (r >> 2);
+                    const int rc = FULL ? row : (row < row_max ? row : row_max);
+                    rv[r] = R[(unsigned)((rc * ldr + nc) * r_mul)];
+                }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = lrow + mr * 32 + (r & 3) + 8 * (r >> 2);
-                const bool ok = full || (n_ok && m0 + row < p.m);
-                float v = dm3d_act(acc[mr][nr][r] * p.alpha + bn + bm[r], p.act) + rv[r];
-                if (p.out_h2) {
-                    const unsigned int mine = split1_bits(v);
-                    const unsigned int oth = (unsigned int)__shfl_xor((int)mine, 1, 64);
-                    const unsigned int word = (n & 1) ? ((oth >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (oth << 16));
-                    if (ok) *reinterpret_cast<unsigned int*>(O + (size_t)(unsigned)(row * ldo) * 4 + ocol) = word;
-                } else {
-                    if (ok) *reinterpret_cast<float*>(O + (size_t)(unsigned)(row * ldo) * 4 + ocol) = v;
+                for (int r = 0; r < 16; ++r) v[r] = acc[mr][nr][r] * p.alpha + bn;
+                if (has_bm) {                                        // rare options: one uniform branch around a batch of loads
+                    float bm[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = lrow + mr * 32 + (r & 3) + 8 * (r >> 2);
+                        bm[r] = Bm[(unsigned)(FULL ? row : (row < row_max ? row : row_max))];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] += bm[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], lo_bound);
+                if (p.act == DM3D_ACT_SILU) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = dm3d_silu(v[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += has_r ? rv[r] : 0.0f;
+                if (has_r2) {
+                    float rv2[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = lrow + mr * 32 + (r & 3) + 8 * (r >> 2);
+                        rv2[r] = R2[(unsigned)((FULL ? row : (row < row_max ? row : row_max)) * ldr + nc)];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] += rv2[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = lrow + mr * 32 + (r & 3) + 8 * (r >> 2);
+                    const float o = v[r];
+                    const bool ok = FULL || (n_ok && m0 + row < p.m);
+                    if (H2) {
+                        const unsigned int mine = split1_bits(o);
+                        const unsigned int oth = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, false);   // lane ^ 1
+                        const unsigned int word = (n & 1) ? ((oth >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (oth << 16));
+                        if (ok) *reinterpret_cast<unsigned int*>(O + (size_t)(unsigned)(row * ldo) * 4 + ocol) = word;
+                    } else {
+                        if (ok) *reinterpret_cast<float*>(O + (size_t)(unsigned)(row * ldo) * 4 + ocol) = o;
+                    }
                 }
             }
         }
+    };
+    const std::true_type yes;
+    const std::false_type no;
+    if (full) {
+        if (p.out_h2) epilogue(yes, yes); else epilogue(yes, no);
+    } else {
+        if (p.out_h2) epilogue(no, yes); else epilogue(no, no);
     }
 }
 
