@@ -23,6 +23,7 @@ struct ConvArgs {
     int nchunks;
     int batch;
     float out_scale;          // H3: 2^-w_exp, applied to the accumulator
+    int ksplit;               // h3v2: 1, or 2 = two workgroups share a brick (half of the Cin chunks each) and add atomically
 };
 
 // which tile configuration a (ksize, stride) pair uses

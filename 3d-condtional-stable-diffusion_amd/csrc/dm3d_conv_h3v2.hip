@@ -54,7 +54,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
     const int oz0 = (brick / (p.bh * p.bw)) * TD;
     const int oy0 = ((brick / p.bw) % p.bh) * TH;
     const int ox0 = (brick % p.bw) * TW;
-    const int ntile = blockIdx.y;
+    // blockIdx.y = ntile + ntiles * khalf.  ksplit == 2 (small grids, linear epilogue): this workgroup contracts chunks
+    // [c_lo, c_hi) only and adds its partial sums into the zeroed output; the khalf == 0 half also carries bias / vec / residual.
+    // 0 + a + b == 0 + b + a in floating point, so the result does not depend on which half arrives first.
+    const int ntiles = p.coutpad / NT;
+    const int ntile = blockIdx.y % ntiles, khalf = blockIdx.y / ntiles;
+    const int c_lo = khalf * (p.nchunks / p.ksplit), c_hi = c_lo + p.nchunks / p.ksplit;
     int padz = p.padz, pady = p.pady, padx = p.padx, ooz = p.ooz, ooy = p.ooy, oox = p.oox;
     const _Float16* wbase = static_cast<const _Float16*>(p.wpk);
     if (p.parity) {
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 4096),
                                              (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
     };
-    fetch_w(0);
+    fetch_w(c_lo * NG);
 
     constexpr bool pro = PRO;
     f32x4 raw0[NSLOT], raw1[NSLOT];
@@ -135,10 +140,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
             sh1 = *reinterpret_cast<const f32x4*>(p.pshift + bo + s1);
         }
     };
-    load_halo(0);
+    load_halo(c_lo);
 
     int a_rec = a_rec0;
-    for (int ch = 0; ch < p.nchunks; ++ch) {
+    for (int ch = c_lo; ch < c_hi; ++ch) {
         asm volatile("" : "+v"(a_rec));      // keeps the 14 per-pair operand addresses from being hoisted out of the chunk loop (spills)
         h8 shi[NSLOT], slo[NSLOT];
 #pragma unroll
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk's first weight group (issued a group ago)
         __syncthreads();
-        load_halo(ch + 1 < p.nchunks ? ch + 1 : ch);
+        load_halo(ch + 1 < c_hi ? ch + 1 : ch);
         __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
             const bool last_group = g + 1 == NG;
             {
                 const int nxt = ch * NG + g + 1;
-                if (nxt < p.nchunks * NG) fetch_w(nxt);
+                if (nxt < c_hi * NG) fetch_w(nxt);
             }
             __builtin_amdgcn_sched_barrier(0);
             const _Float16* wbuf = lds_w + ((ch * NG + g) & 1) * WGRP;
@@ -229,7 +234,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
     const bool z_ok = oz < p.od;
     const size_t zbase = (((size_t)b * p.fd + (z_ok ? oz * p.os + ooz : 0)) * p.fh) * p.fw * p.cout;
     float* outz = p.out + zbase;
-    const float* resz = p.res ? p.res + zbase : nullptr;
+    const bool lead = khalf == 0, split = p.ksplit > 1;
+    const float* resz = (p.res && lead) ? p.res + zbase : nullptr;
     const float* prz = p.prelu ? p.prelu + (zbase - (size_t)b * p.fd * p.fh * p.fw * p.cout) : nullptr;
     const int dxl = dx_of_row(4 * g4);
     const int ystep = p.os * p.fw * p.cout;                              // one brick row further in the output
@@ -252,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
             const int n = n0 + ni * 16 + row;
             float add = p.bias ? p.bias[n] : 0.0f;
             if (p.vec) add += p.vec[(size_t)vrow * p.vec_ld + n];
+            if (!lead) add = 0.0f;
 #pragma unroll
             for (int pi = 0; pi < 4; ++pi) {
                 const int base = (((oy0 + 4 * (pi >> 1)) * p.os + ooy) * p.fw + (ox0 + 4 * (pi & 1) + dxl) * p.os + oox) * p.cout + n;
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
                     if (prz) { const float al = prz[o]; v = v > 0.0f ? v : al * v; }
                     if (resz) v += rv[ni][pi][r];
                     if (p.relu_out) v = fmaxf(v, 0.0f);
-                    outz[o] = v;
+                    if (split) unsafeAtomicAdd(outz + o, v); else outz[o] = v;
                 }
             }
         }
@@ -276,6 +283,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
         const int nc = n_ok ? n : p.cout - 1;
         float add = p.bias ? p.bias[nc] : 0.0f;
         if (p.vec) add += p.vec[(size_t)vrow * p.vec_ld + nc];
+        if (!lead) add = 0.0f;
 #pragma unroll
         for (int pi = 0; pi < 4; ++pi) {
             const int oyb = oy0 + 4 * (pi >> 1), ox = ox0 + 4 * (pi & 1) + dxl;
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
                 if (prz) { const float al = prz[o]; v = v > 0.0f ? v : al * v; }
                 if (resz) v += resz[o];
                 if (p.relu_out) v = fmaxf(v, 0.0f);
-                if (ok) outz[o] = v;
+                if (ok) { if (split) unsafeAtomicAdd(outz + o, v); else outz[o] = v; }
             }
         }
     }
@@ -308,7 +316,15 @@ int launch_v2(ConvArgs& a, hipStream_t st) {
         DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3v2<KS, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64), a.parity ? 8u : 1u);
+    // Small grids (the 8^3 level at B = 32 has 64 bricks x 4 channel tiles = one workgroup per CU, i.e. one wave per SIMD with
+    // nothing to hide its barriers and LDS latency behind: in-kernel stamps showed 58 % MFMA occupancy inside the tap loop there)
+    // are doubled by splitting the Cin chunks over two workgroups per brick when the epilogue is linear.
+    const long wgs = (long)a.batch * a.bd * a.bh * a.bw * (a.coutpad / 64) * (a.parity ? 8 : 1);
+    a.ksplit = (wgs <= 256 && a.nchunks >= 8 && a.nchunks % 2 == 0 && !a.relu && !a.prelu && !a.relu_out && a.res != a.out &&
+                a.x1 != a.out && a.x2 != a.out) ? 2 : 1;
+    if (a.ksplit == 2)
+        DM3D_HIP(hipMemsetAsync(a.out, 0, (size_t)a.batch * a.fd * a.fh * a.fw * a.cout * sizeof(float), st));
+    dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64 * a.ksplit), a.parity ? 8u : 1u);
     hipLaunchKernelGGL((conv3d_igemm_h3v2<KS, PRO>), grid, dim3(256), lds, st, a);
     return dm3d_launch_check("conv3d_igemm_h3v2");
 }
