@@ -1,0 +1,111 @@
+"""Builds the stamped variant libraries read by tools/conv_stamps.py and tools/gemm_stamps.py:
+    python tools/mk_stamp_variants.py        ->  <package>/csrc/variants/{cst,gst}.so
+A stamped kernel writes __builtin_readcyclecounter() at phase boundaries (thread 0 of the first workgroups) into a buffer set
+through dm3d_debug_set_stamps[_conv]; the product library carries none of this.  Run the tools with DM3D_LIB=<variant>."""
+import os, subprocess
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "3d-condtional-stable-diffusion_amd", "csrc")
+os.chdir(CSRC)
+subprocess.check_call(["make"])
+os.makedirs("variants", exist_ok=True)
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I../../include", "-Wno-unused-function", "-ffp-contract=off"]
+OBJS = ["dm3d_api.o", "dm3d_conv.o", "dm3d_conv_h3.o", "dm3d_conv_h3v2.o", "dm3d_gemm.o", "dm3d_gemm_h3.o", "dm3d_elem.o"]
+
+
+def build(src_text, tmp_name, replaces, out):
+    open(tmp_name, "w").write(src_text)
+    try:
+        subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, "-c", tmp_name, "-o", tmp_name + ".o"])
+    finally:
+        os.remove(tmp_name)
+    objs = [tmp_name + ".o" if o == replaces else o for o in OBJS]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", out, *objs])
+    os.remove(tmp_name + ".o")
+
+
+def must(s, old, new, count=-1):
+    assert old in s, old[:60]
+    return s.replace(old, new, count) if count > 0 else s.replace(old, new)
+
+# ---- conv3d_igemm_h3v2
+s = open('dm3d_conv_h3v2.hip').read()
+s=s.replace("""namespace {
+
+constexpr int REC = DM3D_REC;""","""__device__ unsigned long long* g_dbg_stamps_c = nullptr;
+extern "C" int dm3d_debug_set_stamps_conv(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_stamps_c), &p, sizeof(p)); }
+#define STAMP(i) do { if (g_dbg_stamps_c && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 4096) g_dbg_stamps_c[blockIdx.x * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+
+namespace {
+
+constexpr int REC = DM3D_REC;""",1)
+s=s.replace("""    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;""","""    STAMP(0);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;""",1)
+s=s.replace("""    load_halo(0);
+
+    int a_rec = a_rec0;""","""    load_halo(0);
+    STAMP(1);
+
+    int a_rec = a_rec0;""")
+s=s.replace("""        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk's first weight group (issued a group ago)
+        __syncthreads();""","""        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk's first weight group (issued a group ago)
+        __syncthreads();
+        if (ch < 12) STAMP(2 + 2 * ch);""")
+s=s.replace("""            if (!last_group) __syncthreads();""","""            if (!last_group) __syncthreads();
+            if (last_group && ch < 12) STAMP(3 + 2 * ch);""")
+s=s.replace("""    // ---- epilogue.  Accumulator register r of tile""","""    STAMP(28);
+    // ---- epilogue.  Accumulator register r of tile""")
+s=s.replace("""                    outz[o] = v;
+                }
+            }
+        }
+        return;
+    }""","""                    outz[o] = v;
+                }
+            }
+        }
+        STAMP(29);
+        return;
+    }""")
+build(s, '_cst.hip', 'dm3d_conv_h3v2.o', 'variants/cst.so')
+
+# ---- gemm_tn_h3
+s = open('dm3d_gemm_h3.hip').read()
+s=s.replace("""namespace {
+
+struct GemmH3Args {""","""__device__ unsigned long long* g_dbg_stamps = nullptr;
+extern "C" int dm3d_debug_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_stamps), &p, sizeof(p)); }
+#define STAMP(i) do { if (g_dbg_stamps && threadIdx.x == 0 && blockIdx.x < 2048) g_dbg_stamps[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+
+namespace {
+
+struct GemmH3Args {""",1)
+s=s.replace("""    int which = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_GROUP; ++i) which +=""","""    STAMP(0);
+    int which = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_GROUP; ++i) which +=""",1)
+s=s.replace("""    fetch(S0, 0);
+    fetch(S1, clampk(1));""","""    STAMP(1);
+    fetch(S0, 0);
+    fetch(S1, clampk(1));""")
+s=s.replace("""        __syncthreads();                        // chunk `it` visible; everyone has left chunk it-1 (other buffer)""","""        __syncthreads();                        // chunk `it` visible; everyone has left chunk it-1 (other buffer)
+        if (it < 8) STAMP(2 + it);""")
+s=s.replace("""        publish(S1, 1, (it + 1) * KC + 16 < p.k);
+        __syncthreads();""","""        publish(S1, 1, (it + 1) * KC + 16 < p.k);
+        __syncthreads();
+        if (it < 8) STAMP(3 + it);""")
+s=s.replace("""    const bool full = m0 + TM <= p.m && n0 + NT <= p.n;
+    char* O = static_cast<char*>(p.out)""","""    STAMP(10);
+    const bool full = m0 + TM <= p.m && n0 + NT <= p.n;
+    char* O = static_cast<char*>(p.out)""")
+s=s.replace("""    } else {
+        if (p.out_h2) epilogue(no, yes); else epilogue(no, no);
+    }
+}""","""    } else {
+        if (p.out_h2) epilogue(no, yes); else epilogue(no, no);
+    }
+    STAMP(11);
+}""")
+build(s, '_gst.hip', 'dm3d_gemm_h3.o', 'variants/gst.so')
