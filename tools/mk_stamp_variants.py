@@ -28,7 +28,7 @@ def must(s, old, new, count=-1):
 
 # ---- conv3d_igemm_h3v2
 s = open('dm3d_conv_h3v2.hip').read()
-s=s.replace("""namespace {
+s=must(s, """namespace {
 
 constexpr int REC = DM3D_REC;""","""__device__ unsigned long long* g_dbg_stamps_c = nullptr;
 extern "C" int dm3d_debug_set_stamps_conv(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_stamps_c), &p, sizeof(p)); }
@@ -37,30 +37,30 @@ extern "C" int dm3d_debug_set_stamps_conv(void* p) { return (int)hipMemcpyToSymb
 namespace {
 
 constexpr int REC = DM3D_REC;""",1)
-s=s.replace("""    const int tid = threadIdx.x;
+s=must(s, """    const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;""","""    STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;""",1)
-s=s.replace("""    load_halo(0);
+s=must(s, """    load_halo(0);
 
     int a_rec = a_rec0;""","""    load_halo(0);
     STAMP(1);
 
     int a_rec = a_rec0;""")
-s=s.replace("""        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk's first weight group (issued a group ago)
+s=must(s, """        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk's first weight group (issued a group ago)
         __syncthreads();""","""        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk's first weight group (issued a group ago)
         __syncthreads();
         if (ch < 12) STAMP(2 + 2 * ch);""")
-s=s.replace("""            if (!last_group) __syncthreads();""","""            if (!last_group) __syncthreads();
+s=must(s, """            if (!last_group) __syncthreads();""","""            if (!last_group) __syncthreads();
             if (last_group && ch < 12) STAMP(3 + 2 * ch);""")
-s=s.replace("""    // ---- epilogue.  Accumulator register r of tile""","""    STAMP(28);
+s=must(s, """    // ---- epilogue.  Accumulator register r of tile""","""    STAMP(28);
     // ---- epilogue.  Accumulator register r of tile""")
-s=s.replace("""                    outz[o] = v;
+s=must(s, """                    if (split) unsafeAtomicAdd(outz + o, v); else outz[o] = v;
                 }
             }
         }
         return;
-    }""","""                    outz[o] = v;
+    }""","""                    if (split) unsafeAtomicAdd(outz + o, v); else outz[o] = v;
                 }
             }
         }
@@ -71,7 +71,7 @@ build(s, '_cst.hip', 'dm3d_conv_h3v2.o', 'variants/cst.so')
 
 # ---- gemm_tn_h3
 s = open('dm3d_gemm_h3.hip').read()
-s=s.replace("""namespace {
+s=must(s, """namespace {
 
 struct GemmH3Args {""","""__device__ unsigned long long* g_dbg_stamps = nullptr;
 extern "C" int dm3d_debug_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_stamps), &p, sizeof(p)); }
@@ -80,27 +80,27 @@ extern "C" int dm3d_debug_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HI
 namespace {
 
 struct GemmH3Args {""",1)
-s=s.replace("""    int which = 0;
+s=must(s, """    int which = 0;
 #pragma unroll
     for (int i = 1; i < MAX_GROUP; ++i) which +=""","""    STAMP(0);
     int which = 0;
 #pragma unroll
     for (int i = 1; i < MAX_GROUP; ++i) which +=""",1)
-s=s.replace("""    fetch(S0, 0);
+s=must(s, """    fetch(S0, 0);
     fetch(S1, clampk(1));""","""    STAMP(1);
     fetch(S0, 0);
     fetch(S1, clampk(1));""")
-s=s.replace("""        __syncthreads();                        // chunk `it` visible; everyone has left chunk it-1 (other buffer)""","""        __syncthreads();                        // chunk `it` visible; everyone has left chunk it-1 (other buffer)
+s=must(s, """        __syncthreads();                        // chunk `it` visible; everyone has left chunk it-1 (other buffer)""","""        __syncthreads();                        // chunk `it` visible; everyone has left chunk it-1 (other buffer)
         if (it < 8) STAMP(2 + it);""")
-s=s.replace("""        publish(S1, 1, (it + 1) * KC + 16 < p.k);
+s=must(s, """        publish(S1, 1, (it + 1) * KC + 16 < p.k);
         __syncthreads();""","""        publish(S1, 1, (it + 1) * KC + 16 < p.k);
         __syncthreads();
         if (it < 8) STAMP(3 + it);""")
-s=s.replace("""    const bool full = m0 + TM <= p.m && n0 + NT <= p.n;
+s=must(s, """    const bool full = m0 + TM <= p.m && n0 + NT <= p.n;
     char* O = static_cast<char*>(p.out)""","""    STAMP(10);
     const bool full = m0 + TM <= p.m && n0 + NT <= p.n;
     char* O = static_cast<char*>(p.out)""")
-s=s.replace("""    } else {
+s=must(s, """    } else {
         if (p.out_h2) epilogue(no, yes); else epilogue(no, no);
     }
 }""","""    } else {
