@@ -41,18 +41,18 @@ s=must(s, """    const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;""","""    STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;""",1)
-s=must(s, """    load_halo(0);
+s=must(s, """    load_halo(c_lo);
 
-    int a_rec = a_rec0;""","""    load_halo(0);
+    int a_rec = a_rec0;""","""    load_halo(c_lo);
     STAMP(1);
 
     int a_rec = a_rec0;""")
 s=must(s, """        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk's first weight group (issued a group ago)
         __syncthreads();""","""        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk's first weight group (issued a group ago)
         __syncthreads();
-        if (ch < 12) STAMP(2 + 2 * ch);""")
+        if (ch - c_lo < 12) STAMP(2 + 2 * (ch - c_lo));""")
 s=must(s, """            if (!last_group) __syncthreads();""","""            if (!last_group) __syncthreads();
-            if (last_group && ch < 12) STAMP(3 + 2 * ch);""")
+            if (last_group && ch - c_lo < 12) STAMP(3 + 2 * (ch - c_lo));""")
 s=must(s, """    // ---- epilogue.  Accumulator register r of tile""","""    STAMP(28);
     // ---- epilogue.  Accumulator register r of tile""")
 s=must(s, """                    if (split) unsafeAtomicAdd(outz + o, v); else outz[o] = v;
