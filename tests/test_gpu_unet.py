@@ -138,6 +138,31 @@ def test_unconditional_config1_generate(dev):
     assert torch.isfinite(full).all()
 
 
+def test_batch_shards_are_independent_and_repeatable(dev):
+    """volumes shard across ranks because no sample sees another.  eps of a batch of 6 must equal eps of its
+    shards [0:2], [2:6] run separately (different grid sizes: the split-K and tile choices may differ, hence 1e-6 rather than
+    bitwise), and the same call twice must be bit-identical (the split-K path adds two partial sums atomically)."""
+    import dm3d_amd
+    from dm3d_amd.unet import UNet
+    cfg = dm3d_amd.UNetConfig(img_size=16, img_channels=8)
+    net = UNet(cfg, weights=dm3d_amd.synthetic_weights(cfg, seed=3))
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(6, 16, 16, 16, 8, generator=g).to(dev)
+    t = torch.tensor([999, 0, 17, 500, 500, 3])
+    ctx = torch.ones(6, 1, 1, dtype=torch.int64)
+    full = net([x, t, ctx]).clone()
+    again = net([x, t, ctx]).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(full, again)
+    parts = []
+    for r in range(2):
+        lo, hi = (0, 2) if r == 0 else (2, 6)
+        parts.append(net([x[lo:hi].contiguous(), t[lo:hi], ctx[lo:hi]]).clone())
+    torch.cuda.synchronize()
+    joined = torch.cat(parts, 0)
+    assert float((joined - full).abs().max() / full.abs().max()) < 1e-6
+
+
 @pytest.mark.parametrize("prec", ["fp32", "h3"])
 def test_unet_eps_full_size_32cube(dev, prec):
     """BASELINE configs 2-4 shape (32^3 x 8ch, real widths) at B=1 against the oracle run on this box's CPU."""
