@@ -47,6 +47,17 @@ class GemmDesc(C.Structure):
     ]
 
 
+class AttentionDesc(C.Structure):
+    _fields_ = [
+        ("q", _f32p), ("ldq", C.c_int64),
+        ("k", _f32p), ("ldk", C.c_int64), ("stride_k", C.c_int64),
+        ("vt", _f32p), ("ldv", C.c_int64), ("stride_vt", C.c_int64),
+        ("out", _f32p), ("ldo", C.c_int64), ("res", _f32p),
+        ("batch", C.c_int32), ("lq", C.c_int32), ("lk", C.c_int32), ("c", C.c_int32),
+        ("scale", C.c_float), ("precision", C.c_int32), ("fmt", C.c_int32),
+    ]
+
+
 class DdpmDesc(C.Structure):
     _fields_ = [
         ("x", _f32p), ("eps", _f32p), ("noise", _f32p), ("batch", C.c_int32), ("per_sample", C.c_int64),
@@ -69,6 +80,8 @@ SIGNATURES = {
     "dm3d_packed_weight_h3p_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "dm3d_pack_weights_h3p": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p, C.c_void_p, C.c_int32, C.c_void_p]),
     "dm3d_conv_weight_layout": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "dm3d_attention_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "dm3d_attention": (C.c_int, [C.POINTER(AttentionDesc), C.c_void_p, C.c_void_p]),
     "dm3d_packed_weight_up_elems": (C.c_int64, [C.c_int32, C.c_int32]),
     "dm3d_pack_weights_up": (C.c_int, [_f32p, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
     "dm3d_packed_weight_up_h3_bytes": (C.c_int64, [C.c_int32, C.c_int32]),

@@ -138,3 +138,40 @@ extern "C" int dm3d_gemm_tn(const dm3d_gemm_desc* d, void* stream) {
     hipLaunchKernelGGL(gemm_tn_f32, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return dm3d_launch_check("gemm_tn_f32");
 }
+
+// ---- dm3d_attention: the three launches of one attention product behind one entry (see include/dm3d.h)
+extern "C" int64_t dm3d_attention_workspace_bytes(int32_t batch, int32_t lq, int32_t lk) {
+    if (batch <= 0 || lq <= 0 || lk <= 0) return 0;
+    return (int64_t)batch * lq * dm3d_round_up(lk, 16) * (int64_t)sizeof(float);
+}
+
+extern "C" int dm3d_attention(const dm3d_attention_desc* d, void* scratch, void* stream) {
+    DM3D_REQUIRE(d != nullptr && scratch != nullptr, "attention: null descriptor or scratch");
+    DM3D_REQUIRE(d->q && d->k && d->vt && d->out, "attention: q/k/vt/out must be non-null");
+    DM3D_REQUIRE(d->batch > 0 && d->lq > 0 && d->lk > 0 && d->c > 0, "attention: non-positive extent");
+    DM3D_REQUIRE(d->fmt == DM3D_FMT_F32 || (d->fmt == DM3D_FMT_H2 && d->precision == DM3D_PREC_H3), "attention: H2 operands need precision H3");
+    DM3D_REQUIRE(d->fmt == DM3D_FMT_F32 || d->lk % 16 == 0, "attention: H2 operands need lk %% 16 == 0");
+    DM3D_REQUIRE(dm3d_aligned16(scratch), "attention: scratch must be 16-byte aligned");
+    const bool h2 = d->fmt == DM3D_FMT_H2;
+    const int64_t lds = dm3d_round_up(d->lk, 16);             // row stride of the probabilities
+    float* p = static_cast<float*>(scratch);
+    dm3d_gemm_desc g{};
+    g.a = d->q; g.lda = d->ldq; g.stride_a = (int64_t)d->lq * d->ldq;
+    g.b = d->k; g.ldb = d->ldk; g.stride_b = d->stride_k;
+    g.out = p; g.ldo = lds; g.stride_o = (int64_t)d->lq * lds;
+    g.m = d->lq; g.n = d->lk; g.k = d->c; g.batch = d->batch; g.alpha = d->scale;
+    g.precision = d->precision; g.a_fmt = g.b_fmt = d->fmt; g.out_fmt = DM3D_FMT_F32;
+    int rc = dm3d_gemm_tn(&g, stream);
+    if (rc) return rc;
+    rc = h2 ? dm3d_softmax_rows_h2(p, (int64_t)d->batch * d->lq, d->lk, lds, stream)
+            : dm3d_softmax_rows(p, (int64_t)d->batch * d->lq, d->lk, lds, stream);
+    if (rc) return rc;
+    dm3d_gemm_desc v{};
+    v.a = p; v.lda = lds; v.stride_a = (int64_t)d->lq * lds;
+    v.b = d->vt; v.ldb = d->ldv; v.stride_b = d->stride_vt;
+    v.out = d->out; v.ldo = d->ldo; v.stride_o = (int64_t)d->lq * d->ldo;
+    v.m = d->lq; v.n = d->c; v.k = d->lk; v.batch = d->batch; v.alpha = 1.0f;
+    v.res = d->res; v.ldr = d->ldo; v.stride_r = (int64_t)d->lq * d->ldo;
+    v.precision = d->precision; v.a_fmt = h2 ? DM3D_FMT_H2 : DM3D_FMT_F32; v.b_fmt = d->fmt; v.out_fmt = DM3D_FMT_F32;
+    return dm3d_gemm_tn(&v, stream);
+}

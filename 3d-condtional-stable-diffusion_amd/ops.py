@@ -188,6 +188,23 @@ def gemm_tn(a, b, *, m=None, n=None, k=None, lda=None, ldb=None, batch=1, stride
     return out
 
 
+def attention(q, k, vt, scale, *, res=None, precision=_lib.PREC_F32, fmt=_lib.FMT_F32) -> torch.Tensor:
+    """softmax(q k^T * scale) v + res per sample through dm3d_attention.  q [B, Lq, C]; k [B or 1, Lk, C]; vt [B or 1, C, Lk]
+    (the value tensor transposed); with fmt=FMT_H2 the three operands are DM3D_FMT_H2 buffers of those logical shapes."""
+    B, Lq, Cc = q.shape
+    Lk = k.shape[1]
+    out = torch.empty(B, Lq, Cc, dtype=torch.float32, device=q.device)
+    scratch = torch.empty(lib().dm3d_attention_workspace_bytes(B, Lq, Lk) // 4, dtype=torch.float32, device=q.device)
+    d = _lib.AttentionDesc()
+    d.q, d.ldq = q.data_ptr(), q.shape[-1]
+    d.k, d.ldk, d.stride_k = k.data_ptr(), k.shape[-1], (Lk * k.shape[-1] if k.shape[0] == B and B > 1 else 0)
+    d.vt, d.ldv, d.stride_vt = vt.data_ptr(), vt.shape[-1], (vt.shape[1] * vt.shape[-1] if vt.shape[0] == B and B > 1 else 0)
+    d.out, d.ldo, d.res = out.data_ptr(), Cc, _p(res)
+    d.batch, d.lq, d.lk, d.c, d.scale, d.precision, d.fmt = B, Lq, Lk, Cc, float(scale), precision, fmt
+    check(lib().dm3d_attention(C.byref(d), scratch.data_ptr(), _st()), "attention")
+    return out
+
+
 def layernorm3(x, params, eps=1e-3):
     """params: up to three (gamma, beta) pairs -> list of outputs sharing one statistics pass."""
     _f32c(x, "x")

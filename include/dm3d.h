@@ -217,6 +217,28 @@ int dm3d_softmax_rows(float* s, int64_t rows, int32_t cols, int64_t ld, void* st
 /* same, result left in place in DM3D_FMT_H2 (cols % 16 == 0, ld % 16 == 0, cols <= 1024): it only feeds the P.V contraction */
 int dm3d_softmax_rows_h2(float* s, int64_t rows, int32_t cols, int64_t ld, void* stream);
 
+/* ---- single-head attention  out = softmax(q k^T * scale) v (+ res)  per sample (:163-184; U:47-61) in one call: the score
+ * product, the row softmax and the P.V product that a host otherwise issues itself, on caller-provided scratch.  L = D*H*W
+ * flattened tokens (<= 1024 per row for the H2 softmax), single head (the reference never uses num_heads > 1).
+ *   q   [batch, lq, c]       row stride ldq
+ *   k   [batch | 1, lk, c]   row stride ldk; stride_k = 0 broadcasts one context's keys to the whole batch
+ *   vt  [batch | 1, c, lk]   the value tensor TRANSPOSED (it is the K-contiguous operand of P.V); row stride ldv, stride_vt
+ *   out [batch, lq, c]       row stride ldo; res: optional float32 tensor with out's layout, added to the result
+ *   fmt DM3D_FMT_F32 (precision F32 or H3) or DM3D_FMT_H2 (precision H3): format of q, k and vt; out and res are float32.
+ *   scratch: >= dm3d_attention_workspace_bytes(batch, lq, lk) bytes, 16-byte aligned (the [batch, lq, lk] probabilities). */
+typedef struct dm3d_attention_desc {
+    const float* q;  int64_t ldq;
+    const float* k;  int64_t ldk; int64_t stride_k;
+    const float* vt; int64_t ldv; int64_t stride_vt;
+    float* out;      int64_t ldo;
+    const float* res;
+    int32_t batch, lq, lk, c;
+    float scale;                /* units^-0.5 in the reference */
+    int32_t precision, fmt;
+} dm3d_attention_desc;
+int64_t dm3d_attention_workspace_bytes(int32_t batch, int32_t lq, int32_t lk);
+int     dm3d_attention(const dm3d_attention_desc* d, void* scratch, void* stream);
+
 /* ---- y = act(x*scale[c] + shift[c]) over the last axis (inference BatchNormalization of AttentionBlock, U:45;
  * swish of the time embedding, :250); scale/shift may be NULL (identity). */
 int dm3d_affine_act(const float* x, float* y, int64_t rows, int32_t c, const float* scale, const float* shift,

@@ -320,6 +320,28 @@ def test_gemm_strided_views(dev):
     assert _rel(out, ref) < 2e-5
 
 
+@pytest.mark.parametrize("mode", ["fp32", "h3_f32", "h3_h2"])
+def test_attention_entry(dev, mode):
+    """dm3d_attention (score product + row softmax + P.V in one call) against the oracle's _attention, self- and cross-
+    (one context's keys/values broadcast to the batch) forms, with a residual."""
+    from dm3d_amd import ops, _lib
+    from oracle import ref_torch as rt
+    g = torch.Generator().manual_seed(77)
+    B, L, u = 3, 64, 32
+    q = torch.randn(B, L, u, generator=g)
+    res = torch.randn(B, L, u, generator=g)
+    prec = _lib.PREC_F32 if mode == "fp32" else _lib.PREC_H3
+    fmt = _lib.FMT_H2 if mode == "h3_h2" else _lib.FMT_F32
+    enc = (lambda t: ops.split_h2(t.to(dev).contiguous()).view(*t.shape[:-1], -1)) if mode == "h3_h2" else (lambda t: t.to(dev).contiguous())
+    for kb in (B, 1):                                       # per-sample keys, then one broadcast context
+        k = torch.randn(kb, 48, u, generator=g)
+        v = torch.randn(kb, 48, u, generator=g)
+        ref = rt._attention(q.double(), k.double().expand(B, -1, -1), v.double().expand(B, -1, -1), u) + res.double()
+        out = ops.attention(enc(q), enc(k), enc(v.transpose(1, 2).contiguous()), float(u) ** -0.5, res=res.to(dev), precision=prec, fmt=fmt)
+        torch.cuda.synchronize()
+        assert _rel(out, ref) < 2e-5, (mode, kb)
+
+
 @pytest.mark.parametrize("rows,c", [(37, 256), (5, 48), (1024, 256), (3, 1024)])
 def test_layernorm3(dev, rows, c):
     from dm3d_amd import ops
