@@ -114,6 +114,27 @@ class DiffusionModel:
         self.network.load_state_dict(sd, strict)
         self._drop_graphs()
 
+    def load_weights(self, path, root=("network",)):
+        """keras ``model.load_weights(ckpt)`` (main_conditional_dm.py:207-213): reads the U-Net from a TF2 checkpoint prefix
+        saved by the reference (``root``: where the U-Net sits in the saved object, ("network",) for a DiffusionModel
+        checkpoint, () for ``network.save_weights``), or from an .npz state dict.  If the checkpoint also holds the
+        autoencoder under ``vqvae_trainer`` it is loaded too."""
+        if str(path).endswith(".npz"):
+            self.load_state_dict(dict(np.load(path)))
+            return
+        from . import tf_checkpoint as tc
+        self.load_state_dict(tc.load_unet_state(str(path), self.network.cfg, root=tuple(root)))
+        rd = tc.BundleReader(str(path))
+        if any(k.startswith("vqvae_trainer/") for k in rd.entries):
+            self.vqvae_trainer.load_weights(path, root=("vqvae_trainer",))
+
+    def save_weights(self, path, root=("network",)):
+        if str(path).endswith(".npz"):
+            np.savez(path, **self.network.state_dict())
+            return
+        from . import tf_checkpoint as tc
+        tc.save_unet_checkpoint(str(path), self.network.state_dict(), self.network.cfg, root=tuple(root))
+
     def _drop_graphs(self):
         for g in self._graphs.values():
             lib().dm3d_graph_destroy(g)

@@ -139,11 +139,22 @@ class VQVAE:
             new[name] = arr
         self.state, self._prepared = new, False
 
-    def load_weights(self, path):
-        """The reference loads TF checkpoints (conditional_dm3d.py:451-454); here: an .npz of the state dict."""
-        if not str(path).endswith(".npz"):
-            raise NotImplementedError("TF-checkpoint import is not built (SURVEY.md §8(f) next-3); pass an .npz state dict")
-        self.load_state_dict(dict(np.load(path)))
+    def load_weights(self, path, root=()):
+        """keras ``model.load_weights`` (conditional_dm3d.py:451-454): a TF2 checkpoint prefix written by the reference's
+        ``save_weights`` (tf_checkpoint.load_vqvae_state; ``root`` = attribute path of the autoencoder inside the saved object),
+        or an .npz of the state dict."""
+        if str(path).endswith(".npz"):
+            self.load_state_dict(dict(np.load(path)))
+            return
+        from ..tf_checkpoint import load_vqvae_state
+        self.load_state_dict(load_vqvae_state(str(path), self.spec, root=tuple(root)))
+
+    def save_weights(self, path, root=()):
+        if str(path).endswith(".npz"):
+            np.savez(path, **self.state)
+            return
+        from ..tf_checkpoint import save_vqvae_checkpoint
+        save_vqvae_checkpoint(str(path), self.state, self.spec, root=tuple(root))
 
     def _dev(self, a):
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
