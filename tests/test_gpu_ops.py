@@ -113,6 +113,38 @@ def test_conv3d(dev, case, prec):
     assert err < 2e-5, f"{name}: rel err {err:.3e}"
 
 
+def _random_conv_cases(n, seed):
+    """Seeded sweep over ragged extents, channel counts (multiples of 4; c1 % 16 == 0 with a second input), kernel kinds and
+    epilogue options: the shapes nobody thought of when writing CONV_CASES."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(n):
+        kind = rng.choice(["k3", "k3", "k3", "k3s2", "up", "k1"])
+        dims = tuple(int(v) for v in rng.integers(1, 13, size=3))
+        dual = kind in ("k3", "k1") and rng.random() < 0.35
+        c1 = int(rng.choice([16, 32, 48, 96, 144])) if dual else int(rng.choice([4, 8, 12, 16, 20, 36, 64, 100, 132, 160]))
+        c2 = int(rng.choice([4, 12, 16, 40])) if dual else 0
+        cout = int(rng.choice([4, 8, 24, 32, 40, 64, 72, 130]))
+        opts = [o for o in ("bias", "pro", "vec", "res", "relu") if rng.random() < 0.5]
+        if "vec" in opts and rng.random() < 0.5:
+            opts.append("vecidx")
+        ks, stride, ups = (1, 1, False) if kind == "k1" else (3, 2 if kind == "k3s2" else 1, kind == "up")
+        if kind == "k1":
+            opts = [o for o in opts if o != "pro" or True]
+        cases.append((f"rand{i}_{kind}_{dims[0]}x{dims[1]}x{dims[2]}_{c1}+{c2}to{cout}_{'-'.join(opts) or 'plain'}", int(rng.integers(1, 4)),
+                      dims, c1, c2, cout, ks, stride, ups, " ".join(opts)))
+    return cases
+
+
+RANDOM_CONV_CASES = _random_conv_cases(36, 20260101)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "h3"])
+@pytest.mark.parametrize("case", RANDOM_CONV_CASES, ids=[c[0] for c in RANDOM_CONV_CASES])
+def test_conv3d_random_shapes(dev, case, prec):
+    test_conv3d(dev, case, prec)
+
+
 def test_conv3d_h3_tap_layout_arm(dev):
     """DM3D_CONV_PAIR=0 (read when the library is loaded) routes every H3 conv to the 32x32x16 kernel with the DM3D_WL_TAP weight
     layout: the A/B arm of the 16x16x32 kernel must stay correct.  One child interpreter, same parity cases."""
@@ -120,7 +152,7 @@ def test_conv3d_h3_tap_layout_arm(dev):
     if os.environ.get("DM3D_CONV_PAIR") == "0":
         pytest.skip("already inside the tap-layout arm")
     env = dict(os.environ, DM3D_CONV_PAIR="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_conv3d and h3",
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "(test_conv3d or random_shapes) and h3",
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
