@@ -306,6 +306,34 @@ def test_gemm_tn_h3(dev, case):
     assert err < 2e-5, f"{name}: rel err {err:.3e}"
 
 
+def _random_h3_gemm_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(n):
+        kw = dict(m=int(rng.integers(1, 400)), n=int(rng.integers(1, 20)) * 16, k=int(rng.integers(1, 24)) * 16)
+        if rng.random() < 0.3:
+            kw["batch"] = int(rng.integers(2, 5))
+            kw["bcast_b"] = bool(rng.random() < 0.5)
+        for opt, p in (("a_f32", 0.3), ("b_f32", 0.3), ("bias", 0.5), ("res", 0.5), ("out_h2", 0.4)):
+            if rng.random() < p:
+                kw[opt] = True
+        if kw.get("bias") and rng.random() < 0.3:
+            kw["bias_m"] = True
+        kw["act"] = int(rng.integers(0, 3))
+        if rng.random() < 0.3:
+            kw["alpha"] = float(rng.choice([0.0625, 0.5, 2.0]))
+        cases.append((f"rand{i}_" + "_".join(f"{k}{v if not isinstance(v, bool) else ''}" for k, v in kw.items()), kw))
+    return cases
+
+
+RANDOM_H3_GEMM = _random_h3_gemm_cases(24, 20260102)
+
+
+@pytest.mark.parametrize("case", RANDOM_H3_GEMM, ids=[c[0] for c in RANDOM_H3_GEMM])
+def test_gemm_tn_h3_random_shapes(dev, case):
+    test_gemm_tn_h3(dev, case)
+
+
 def test_h2_format_roundtrip_and_norm_kernels(dev):
     from dm3d_amd import ops
     g = torch.Generator().manual_seed(77)
