@@ -276,6 +276,8 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
     a.vec = d->vec; a.vec_idx = d->vec_idx; a.vec_ld = d->vec_ld;
     a.relu = d->relu; a.res = d->res; a.out = d->out; a.cout = d->cout;
     a.prelu = d->prelu_alpha; a.relu_out = d->relu_out;
+    a.scratch = d->scratch; a.scratch_bytes = d->scratch_bytes;
+    DM3D_REQUIRE(dm3d_aligned16(d->scratch) && d->scratch_bytes >= 0, "conv: scratch must be 16-byte aligned");
     a.batch = d->batch;
     DM3D_REQUIRE(d->precision == DM3D_PREC_F32 || d->precision == DM3D_PREC_H3, "conv: unknown precision %d", d->precision);
     DM3D_REQUIRE(d->w_exp >= -100 && d->w_exp <= 100, "conv: w_exp %d out of range", d->w_exp);
@@ -289,6 +291,20 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
     const int layout = dm3d_conv_weight_layout(d->ksize, d->stride, d->upsample, d->transpose, d->cout);
     DM3D_REQUIRE(d->w_layout == layout, "conv: w_layout %d but this geometry reads layout %d (dm3d_conv_weight_layout)", d->w_layout, layout);
     return layout == DM3D_WL_PAIR ? dm3d_conv_launch_h3v2(a, which, st) : dm3d_conv_launch_h3(a, which, st);
+}
+
+extern "C" int64_t dm3d_conv_scratch_bytes(const dm3d_conv_desc* d) {
+    if (!d || d->precision != DM3D_PREC_H3 || d->batch <= 0 || d->cout <= 0 || d->in_d <= 0 || d->in_h <= 0 || d->in_w <= 0) return 0;
+    if (dm3d_conv_weight_layout(d->ksize, d->stride, d->upsample, d->transpose, d->cout) != DM3D_WL_PAIR) return 0;
+    const bool par = d->upsample || d->transpose;
+    ConvArgs a{};
+    a.batch = d->batch; a.od = d->in_d; a.oh = d->in_h; a.ow = d->in_w; a.parity = par ? 1 : 0;
+    a.coutpad = (int)dm3d_round_up(d->cout, DM3D_COUT_PAD);
+    a.nchunks = (int)(dm3d_round_up(d->c1 + d->c2, DM3D_CIN_PAD) / 16);
+    const int ks = dm3d_conv_h3v2_ksplit(a, true);
+    if (ks <= 1) return 0;
+    const int os = par ? 2 : 1;
+    return (int64_t)ks * d->batch * d->in_d * os * d->in_h * os * d->in_w * os * d->cout * (int64_t)sizeof(float);
 }
 
 extern "C" int32_t dm3d_conv_weight_layout(int32_t ksize, int32_t stride, int32_t upsample, int32_t transpose, int32_t cout) {

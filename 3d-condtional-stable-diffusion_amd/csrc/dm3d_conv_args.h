@@ -23,7 +23,10 @@ struct ConvArgs {
     int nchunks;
     int batch;
     float out_scale;          // H3: 2^-w_exp, applied to the accumulator
-    int ksplit;               // h3v2: 1, or 2 = two workgroups share a brick (half of the Cin chunks each) and add atomically
+    int ksplit;               // h3v2: workgroups per brick along Cin (each contracts nchunks / ksplit chunks)
+    int split_atomic;         // ksplit == 2 without scratch: both halves add into the zeroed output (order-independent for two)
+    long split_stride;        // ksplit > 1 with scratch: elements between the partial-sum images; out points at image 0
+    void* scratch; long scratch_bytes;
 };
 
 // which tile configuration a (ksize, stride) pair uses
@@ -32,6 +35,7 @@ enum { DM3D_CONV_K3S1 = 0, DM3D_CONV_K3S2 = 1, DM3D_CONV_K1 = 2, DM3D_CONV_UP = 
 int dm3d_conv_launch_f32(ConvArgs& a, int which, hipStream_t st);
 int dm3d_conv_launch_h3(ConvArgs& a, int which, hipStream_t st);
 int dm3d_conv_launch_h3v2(ConvArgs& a, int which, hipStream_t st);     // DM3D_WL_PAIR weights; which in {K3S1, UP}
+int dm3d_conv_h3v2_ksplit(const ConvArgs& a, bool with_scratch);       // split factor the launch would choose
 int64_t dm3d_h3v2_image_bytes(int taps, int cin, int cout);
 int dm3d_pack_h3v2(const float* keras_kernel, int taps, int cin, int cout, int w_exp, const float* in_scale, void* packed, int mode,
                    hipStream_t st);

@@ -233,8 +233,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
     const int oz = oz0 + wave;
     const bool z_ok = oz < p.od;
     const size_t zbase = (((size_t)b * p.fd + (z_ok ? oz * p.os + ooz : 0)) * p.fh) * p.fw * p.cout;
-    float* outz = p.out + zbase;
-    const bool lead = khalf == 0, split = p.ksplit > 1;
+    float* outz = p.out + zbase + (size_t)khalf * p.split_stride;
+    // atomic mode: half 0 carries the epilogue operands; scratch mode: every part stores its raw partial sums into its own
+    // image (the launcher cleared the epilogue operands; dm3d_conv_split_reduce applies them)
+    const bool split = p.split_atomic != 0, lead = khalf == 0 || !split;
     const float* resz = (p.res && lead) ? p.res + zbase : nullptr;
     const float* prz = p.prelu ? p.prelu + (zbase - (size_t)b * p.fd * p.fh * p.fw * p.cout) : nullptr;
     const int dxl = dx_of_row(4 * g4);
@@ -303,6 +305,46 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
     }
 }
 
+// out = epilogue(sum of the ksplit partial-sum images, added in image order): + bias[c] + vec[row(b)][c] -> ReLU -> PReLU -> + res ->
+// ReLU.  One thread per 4 consecutive channels (or per element when cout % 4 != 0).
+__global__ __launch_bounds__(256) void conv_split_reduce_kernel(const float* __restrict__ part, int nsplit, long stride, float* __restrict__ out,
+                                                                int cout, long per_sample, const float* __restrict__ bias,
+                                                                const float* __restrict__ vec, const int* __restrict__ vec_idx, int vec_ld,
+                                                                int relu, const float* __restrict__ prelu, const float* __restrict__ res,
+                                                                int relu_out, int vec4) {
+    const int w = vec4 ? 4 : 1;
+    const long total = stride / w;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long e0 = i * w;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < nsplit; ++s) {
+            if (vec4) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(part + (size_t)s * stride + e0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += q[j];
+            } else {
+                v[0] += part[(size_t)s * stride + e0];
+            }
+        }
+        const unsigned e32 = (unsigned)e0;                  // the launcher guarantees stride < 2^31
+        const int c0 = (int)(e32 % (unsigned)cout);
+        const unsigned b = e32 / (unsigned)per_sample;
+        const int vrow = vec ? (vec_idx ? vec_idx[b] : (int)b) : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j >= w) break;
+            float x = v[j];
+            if (bias) x += bias[c0 + j];
+            if (vec) x += vec[(size_t)vrow * vec_ld + c0 + j];
+            if (relu) x = fmaxf(x, 0.0f);
+            if (prelu) { const float al = prelu[e32 % (unsigned)per_sample + j]; x = x > 0.0f ? x : al * x; }
+            if (res) x += res[e0 + j];
+            if (relu_out) x = fmaxf(x, 0.0f);
+            out[e0 + j] = x;
+        }
+    }
+}
+
 template <int KS, bool PRO>
 int launch_v2(ConvArgs& a, hipStream_t st) {
     constexpr int HREC = (3 + KS) * (7 + KS) * 12;
@@ -317,16 +359,39 @@ int launch_v2(ConvArgs& a, hipStream_t st) {
         attr_set = true;
     }
     // Small grids (the 8^3 level at B = 32 has 64 bricks x 4 channel tiles = one workgroup per CU, i.e. one wave per SIMD with
-    // nothing to hide its barriers and LDS latency behind: in-kernel stamps showed 58 % MFMA occupancy inside the tap loop there)
-    // are doubled by splitting the Cin chunks over two workgroups per brick when the epilogue is linear.
-    const long wgs = (long)a.batch * a.bd * a.bh * a.bw * (a.coutpad / 64) * (a.parity ? 8 : 1);
-    a.ksplit = (wgs <= 256 && a.nchunks >= 8 && a.nchunks % 2 == 0 && !a.relu && !a.prelu && !a.relu_out && a.res != a.out &&
-                a.x1 != a.out && a.x2 != a.out) ? 2 : 1;
-    if (a.ksplit == 2)
-        DM3D_HIP(hipMemsetAsync(a.out, 0, (size_t)a.batch * a.fd * a.fh * a.fw * a.cout * sizeof(float), st));
+    // nothing to hide its barriers and LDS latency behind: in-kernel stamps showed 58 % MFMA occupancy inside the tap loop there;
+    // at B = 1 that level has 8 workgroups for 256 CUs) split the Cin chunks over several workgroups per brick.
+    const bool with_scratch = a.scratch != nullptr;
+    a.ksplit = dm3d_conv_h3v2_ksplit(a, with_scratch);
+    const size_t out_elems = (size_t)a.batch * a.fd * a.fh * a.fw * a.cout;
+    a.split_atomic = 0;
+    a.split_stride = 0;
+    ConvArgs k = a;
+    const bool linear = !a.relu && !a.prelu && !a.relu_out && a.res != a.out && a.x1 != a.out && a.x2 != a.out;
+    const bool atomic2 = a.ksplit == 2 && linear && a.nchunks >= 8;       // cheaper than a reduce launch when two parts suffice
+    if (a.ksplit > 1 && (!with_scratch || atomic2)) {         // two halves, order-independent atomic add into the zeroed output
+        k.split_atomic = 1;
+        DM3D_HIP(hipMemsetAsync(a.out, 0, out_elems * sizeof(float), st));
+    } else if (a.ksplit > 1) {                                // raw partial sums -> scratch; epilogue in the reduce launch
+        DM3D_REQUIRE((size_t)a.scratch_bytes >= out_elems * sizeof(float) * a.ksplit, "conv: scratch of %ld bytes is too small", a.scratch_bytes);
+        DM3D_REQUIRE(out_elems < (1ull << 31), "conv: split-K output of %zu elements overflows the reduce kernel's 32-bit index", out_elems);
+        k.out = static_cast<float*>(a.scratch);
+        k.split_stride = (long)out_elems;
+        k.bias = nullptr; k.vec = nullptr; k.res = nullptr; k.relu = 0; k.prelu = nullptr; k.relu_out = 0;
+    }
     dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64 * a.ksplit), a.parity ? 8u : 1u);
-    hipLaunchKernelGGL((conv3d_igemm_h3v2<KS, PRO>), grid, dim3(256), lds, st, a);
-    return dm3d_launch_check("conv3d_igemm_h3v2");
+    hipLaunchKernelGGL((conv3d_igemm_h3v2<KS, PRO>), grid, dim3(256), lds, st, k);
+    int rc = dm3d_launch_check("conv3d_igemm_h3v2");
+    if (rc || !(a.ksplit > 1 && with_scratch && !atomic2)) return rc;
+    const long n4 = (long)(out_elems / 4);                    // cout % 4 == 0 is not required of cout: fall back to scalar lanes
+    const bool vec4 = a.cout % 4 == 0;
+    const long work = vec4 ? n4 : (long)out_elems;
+    long g = (work + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(conv_split_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, static_cast<const float*>(a.scratch), a.ksplit,
+                       (long)out_elems, a.out, a.cout, (long)a.fd * a.fh * a.fw * a.cout, a.bias, a.vec, a.vec_idx, a.vec_ld, a.relu, a.prelu,
+                       a.res, a.relu_out, vec4 ? 1 : 0);
+    return dm3d_launch_check("conv_split_reduce_kernel");
 }
 
 // weight image of the v2 kernel: [coutpad/64][cinpad/16][TAPSP][64 positions][REC]; position 16*t16 + PI(c) holds output channel
@@ -367,6 +432,25 @@ __global__ __launch_bounds__(256) void pack_weights_h3v2_kernel(const float* __r
 }
 
 }  // namespace
+
+// Workgroups per brick along Cin.  Goal: at least ~2 workgroups per CU (512) while every part keeps >= 2 chunks.  Without scratch
+// only the two-way atomic form exists, and only behind a linear epilogue.
+int dm3d_conv_h3v2_ksplit(const ConvArgs& a, bool with_scratch) {
+    const long bd = (a.od + 3) / 4, bh = (a.oh + 7) / 8, bw = (a.ow + 7) / 8;
+    const long wgs = (long)a.batch * bd * bh * bw * (a.coutpad / 64) * (a.parity ? 8 : 1);
+    if (wgs > 256 || a.nchunks < 4) return 1;
+    if (!with_scratch) {
+        const bool linear = !a.relu && !a.prelu && !a.relu_out && a.res != a.out && a.x1 != a.out && a.x2 != a.out;
+        return (linear && a.nchunks >= 8 && a.nchunks % 2 == 0) ? 2 : 1;
+    }
+    int best = 1;                                             // smallest divisor that fills the chip, else the largest allowed
+    for (int d = 2; d <= 16; ++d) {
+        if (a.nchunks % d != 0 || a.nchunks / d < 2) continue;
+        best = d;
+        if (wgs * d >= 512) break;
+    }
+    return best;
+}
 
 int dm3d_conv_launch_h3v2(ConvArgs& a, int which, hipStream_t st) {
     if (which == DM3D_CONV_UP) return a.pscale ? launch_v2<2, true>(a, st) : launch_v2<2, false>(a, st);

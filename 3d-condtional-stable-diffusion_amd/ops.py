@@ -137,6 +137,10 @@ def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False
     if prelu_alpha is not None and tuple(prelu_alpha.shape) != (od, oh, ow, cout):
         raise ValueError("prelu_alpha must be [out_d, out_h, out_w, cout]")
     d.prelu_alpha, d.relu_out, d.transpose = _p(prelu_alpha), int(bool(relu_out)), int(bool(transpose))
+    need = lib().dm3d_conv_scratch_bytes(C.byref(d))
+    if need:
+        scratch = torch.empty(need // 4, dtype=torch.float32, device=x1.device)     # stays alive until the launches are enqueued:
+        d.scratch, d.scratch_bytes = scratch.data_ptr(), need                       # same stream, so the allocator cannot reuse it early
     check(lib().dm3d_conv3d_ndhwc(C.byref(d), _st()), "conv3d")
     return out
 

@@ -372,6 +372,13 @@ class Plan:
         self.ctx_bufs: Dict[str, tuple] = {}
         self._gn_acc = None
         self._build()
+        # one workspace for every conv that can split its Cin range (dm3d_conv_scratch_bytes): launches are stream-ordered
+        need = max([lib().dm3d_conv_scratch_bytes(C.byref(d)) for d in self._keep if isinstance(d, ConvDesc)] + [0])
+        if need:
+            self.scratch = torch.empty(need // 4, dtype=torch.float32, device=dev)
+            for d in self._keep:
+                if isinstance(d, ConvDesc):
+                    d.scratch, d.scratch_bytes = self.scratch.data_ptr(), need
 
     # -- buffer / op helpers ---------------------------------------------------------------------------------------
     def _buf(self, *shape) -> torch.Tensor:

@@ -148,9 +148,16 @@ typedef struct dm3d_conv_desc {
                                    the batch (folded BatchNormalization), c1+c2 = per-sample vectors (GroupNormalization,
                                    written by dm3d_groupnorm_finalize) */
     int32_t w_layout;           /* H3 only: DM3D_WL_TAP or DM3D_WL_PAIR, must equal dm3d_conv_weight_layout(...) */
+    void* scratch;              /* optional workspace (16-byte aligned) of scratch_bytes bytes, or NULL.  With it, convs whose grid
+                                   would leave most of the chip idle (small batches, the 8^3 level) split their Cin range over up
+                                   to 16 workgroups per brick; the partial sums meet in a fixed order in a second launch that also
+                                   applies the epilogue, so results do not depend on timing.  dm3d_conv_scratch_bytes(d) says how
+                                   much a descriptor can use (0: none).  Without it such convs split at most two ways. */
+    int64_t scratch_bytes;
 } dm3d_conv_desc;
 
-int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream);
+int     dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream);
+int64_t dm3d_conv_scratch_bytes(const dm3d_conv_desc* d);
 
 /* ---- Dense / einsum contractions: out[b][m][n] = act(alpha * sum_k A[b][m][k]*B[b][n][k] + bias) + res -------
  * Both operands K-contiguous ("TN").  Replaces layers.Dense on the last axis (:131-137, 164-169, 251, 301-304, 313),
