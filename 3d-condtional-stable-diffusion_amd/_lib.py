@@ -30,7 +30,9 @@ class ConvDesc(C.Structure):
         ("relu", C.c_int32), ("res", _f32p), ("out", _f32p), ("cout", C.c_int32),
         ("precision", C.c_int32), ("w_exp", C.c_int32),
         ("prelu_alpha", _f32p), ("relu_out", C.c_int32), ("transpose", C.c_int32),
-        ("pro_batch_stride", C.c_int64), ("w_layout", C.c_int32), ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64),
+        ("pro_batch_stride", C.c_int64), ("w_layout", C.c_int32),
+        ("skip_x1", _f32p), ("skip_x2", _f32p), ("skip_c1", C.c_int32), ("skip_c2", C.c_int32), ("skip_wpk", C.c_void_p),
+        ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64),
     ]
 
 
@@ -79,6 +81,8 @@ SIGNATURES = {
     "dm3d_pack_weights_h3": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p, C.c_void_p, C.c_void_p]),
     "dm3d_packed_weight_h3p_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "dm3d_pack_weights_h3p": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "dm3d_packed_weight_skip_h3p_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
+    "dm3d_pack_weights_skip_h3p": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "dm3d_conv_scratch_bytes": (C.c_int64, [C.POINTER(ConvDesc)]),
     "dm3d_conv_weight_layout": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "dm3d_attention_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),

@@ -277,6 +277,15 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
     a.relu = d->relu; a.res = d->res; a.out = d->out; a.cout = d->cout;
     a.prelu = d->prelu_alpha; a.relu_out = d->relu_out;
     a.scratch = d->scratch; a.scratch_bytes = d->scratch_bytes;
+    if (d->skip_wpk) {
+        DM3D_REQUIRE(d->precision == DM3D_PREC_H3 && d->ksize == 3 && d->stride == 1 && !d->upsample && !d->transpose && d->cout > 32,
+                     "conv: the fused skip conv needs precision H3, ksize 3, stride 1, no upsample / transpose, cout > 32");
+        DM3D_REQUIRE(d->skip_x1 && d->skip_c1 > 0 && d->skip_c1 % 4 == 0 && d->skip_c2 >= 0 && d->skip_c2 % 4 == 0, "conv: skip_c1=%d skip_c2=%d must be multiples of 4", d->skip_c1, d->skip_c2);
+        DM3D_REQUIRE((d->skip_c2 == 0) == (d->skip_x2 == nullptr) && (d->skip_c2 == 0 || d->skip_c1 % 16 == 0), "conv: skip_x2 / skip_c2 go together and need skip_c1 %% 16 == 0");
+        DM3D_REQUIRE(dm3d_aligned16(d->skip_x1) && dm3d_aligned16(d->skip_x2) && dm3d_aligned16(d->skip_wpk), "conv: skip pointers must be 16-byte aligned");
+        a.sx1 = d->skip_x1; a.sx2 = d->skip_x2; a.sc1 = d->skip_c1; a.sc2 = d->skip_c2; a.swpk = d->skip_wpk;
+        a.s_npairs = (int)(dm3d_round_up(d->skip_c1 + d->skip_c2, 32) / 32);
+    }
     DM3D_REQUIRE(dm3d_aligned16(d->scratch) && d->scratch_bytes >= 0, "conv: scratch must be 16-byte aligned");
     a.batch = d->batch;
     DM3D_REQUIRE(d->precision == DM3D_PREC_F32 || d->precision == DM3D_PREC_H3, "conv: unknown precision %d", d->precision);
@@ -291,6 +300,16 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
     const int layout = dm3d_conv_weight_layout(d->ksize, d->stride, d->upsample, d->transpose, d->cout);
     DM3D_REQUIRE(d->w_layout == layout, "conv: w_layout %d but this geometry reads layout %d (dm3d_conv_weight_layout)", d->w_layout, layout);
     return layout == DM3D_WL_PAIR ? dm3d_conv_launch_h3v2(a, which, st) : dm3d_conv_launch_h3(a, which, st);
+}
+
+extern "C" int64_t dm3d_packed_weight_skip_h3p_bytes(int32_t cin, int32_t cout) {
+    return (cin > 0 && cout > 0) ? dm3d_h3v2_skip_image_bytes(cin, cout) : 0;
+}
+
+extern "C" int dm3d_pack_weights_skip_h3p(const float* keras_kernel, int32_t cin, int32_t cout, int32_t w_exp, void* packed, void* stream) {
+    DM3D_REQUIRE(keras_kernel && packed && cin > 0 && cout > 0, "pack_weights_skip_h3p: bad arguments");
+    DM3D_REQUIRE(w_exp >= -100 && w_exp <= 100 && dm3d_aligned16(packed), "pack_weights_skip_h3p: w_exp out of range or packed unaligned");
+    return dm3d_pack_skip_h3v2(keras_kernel, cin, cout, w_exp, packed, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int64_t dm3d_conv_scratch_bytes(const dm3d_conv_desc* d) {

@@ -27,6 +27,8 @@ struct ConvArgs {
     int split_atomic;         // ksplit == 2 without scratch: both halves add into the zeroed output (order-independent for two)
     long split_stride;        // ksplit > 1 with scratch: elements between the partial-sum images; out points at image 0
     void* scratch; long scratch_bytes;
+    // h3v2 only: a 1x1 conv over a second (raw, un-normalised) input accumulated into the same tile (ResidualBlock skip path)
+    const float* sx1; const float* sx2; int sc1, sc2; const void* swpk; int s_npairs;   // s_npairs = round_up(sc1+sc2, 32) / 32
 };
 
 // which tile configuration a (ksize, stride) pair uses
@@ -35,7 +37,9 @@ enum { DM3D_CONV_K3S1 = 0, DM3D_CONV_K3S2 = 1, DM3D_CONV_K1 = 2, DM3D_CONV_UP = 
 int dm3d_conv_launch_f32(ConvArgs& a, int which, hipStream_t st);
 int dm3d_conv_launch_h3(ConvArgs& a, int which, hipStream_t st);
 int dm3d_conv_launch_h3v2(ConvArgs& a, int which, hipStream_t st);     // DM3D_WL_PAIR weights; which in {K3S1, UP}
-int dm3d_conv_h3v2_ksplit(const ConvArgs& a, bool with_scratch);       // split factor the launch would choose
+int dm3d_conv_h3v2_ksplit(const ConvArgs& a, bool with_scratch);
+int64_t dm3d_h3v2_skip_image_bytes(int cin, int cout);
+int dm3d_pack_skip_h3v2(const float* keras_kernel, int cin, int cout, int w_exp, void* packed, hipStream_t st);       // split factor the launch would choose
 int64_t dm3d_h3v2_image_bytes(int taps, int cin, int cout);
 int dm3d_pack_h3v2(const float* keras_kernel, int taps, int cin, int cout, int w_exp, const float* in_scale, void* packed, int mode,
                    hipStream_t st);

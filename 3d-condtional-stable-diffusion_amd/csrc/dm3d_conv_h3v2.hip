@@ -225,6 +225,107 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
         }
     }
 
+    // ---- fused 1x1 conv over a second, raw input (ResidualBlock: out = conv2(...) + Conv3D(width, 1)(x), conditional_dm3d.py:243-248,
+    // 268).  K = 32 per MFMA = two 16-channel chunks of the SAME voxel instead of two taps: chunk 2i goes to LDS region 0, chunk
+    // 2i+1 to region 1 (brick voxels only, rows padded to 12 records like the halo so the patch reads stay conflict-free), the
+    // lane half picks the region.  One pair of chunks = one barrier pair + 48 MFMAs per wave; the next pair's weights (8 KB by
+    // LDS-DMA) and voxels (registers) are in flight meanwhile.  Part 0 of a split-K launch carries it.
+    if (p.s_npairs > 0 && khalf == 0) {
+        constexpr int SREC = TD * TH * HWP;                                // 384 records per region
+        _Float16* lds_sa = smem_v2;                                        // [2][SREC][REC]            (0 .. 48 KB)
+        _Float16* lds_sw = smem_v2 + 2 * SREC * REC;                       // [2 buffers][2][NT][REC]   (48 .. 64 KB)
+        static_assert((2 * SREC * REC + 2 * 2 * NT * REC) * 2 <= (HD * HH * HWP * REC + 2 * WGRP) * 2, "skip phase LDS carve");
+        int sgv[4], sst[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int item = tid + j * 256, t = item >> 9, iv = (item & 511) >> 1;
+            const int z = iv >> 6, y = (iv >> 3) & 7, x = iv & 7;
+            const bool in = oz0 + z < p.ind && oy0 + y < p.inh && ox0 + x < p.inw;
+            sgv[j] = in ? ((b * p.ind + oz0 + z) * p.inh + oy0 + y) * p.inw + ox0 + x : -1;
+            const int v = (z * TH + y) * HWP + x;
+            sst[j] = (t * SREC + v) * REC + ((piece ^ swz(v)) << 3);       // piece = tid & 1 = item & 1
+        }
+        f32x4 sr0[4], sr1[4];
+        bool sok0[4], sok1[4];
+        auto sload = [&](int pp) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c0 = (pp * 2 + ((tid + j * 256) >> 9)) * CK;
+                const float* src;
+                int ldc, cb;
+                if (c0 < p.sc1) { src = p.sx1; ldc = p.sc1; cb = c0; } else { src = p.sx2; ldc = p.sc2; cb = c0 - p.sc1; }
+                const int cpos = cb + piece * 8;
+                const bool real = src != nullptr && cb < ldc;               // a pad chunk past the last channel reads zeros
+                sok0[j] = real && cpos < ldc;
+                sok1[j] = real && cpos + 4 < ldc;
+                const float* qp = (real ? src : p.sx1) + (size_t)(sgv[j] >= 0 ? sgv[j] : 0) * (real ? ldc : p.sc1);
+                sr0[j] = *reinterpret_cast<const f32x4*>(qp + (sok0[j] ? cpos : 0));
+                sr1[j] = *reinterpret_cast<const f32x4*>(qp + (sok1[j] ? cpos + 4 : 0));
+            }
+        };
+        const char* sw_img = reinterpret_cast<const char*>(p.swpk) + (size_t)ntile * p.s_npairs * (2 * NT * REC * 2) + wave * 1024 + lane * 16;
+        auto sdma = [&](int pp) {                                          // 8 KB per pair: two 1 KB pieces per wave
+            const char* src = sw_img + (size_t)pp * (2 * NT * REC * 2);
+            char* dst = reinterpret_cast<char*>(lds_sw) + (pp & 1) * (2 * NT * REC * 2) + wave * 1024;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 4096),
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+        };
+        const int sa_rec = (wave * TH + (row & 3)) * HWP + dx_of_row(row) + half * SREC;
+        const int sb_hi = b_hi;                                            // same [2 taps][NT][REC] row layout as a main weight pair
+        sload(0);
+        for (int pp = 0; pp < p.s_npairs; ++pp) {
+            h8 shi[4], slo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                split8(sr0[j], sr1[j], (sgv[j] >= 0 && sok0[j]) ? 65504.0f : 0.0f, (sgv[j] >= 0 && sok1[j]) ? 65504.0f : 0.0f, shi[j], slo[j]);
+            __syncthreads();                                               // everyone has left the previous LDS image
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *reinterpret_cast<h8*>(lds_sa + sst[j]) = shi[j];
+                *reinterpret_cast<h8*>(lds_sa + (sst[j] ^ 16)) = slo[j];
+            }
+            if (pp == 0) sdma(0);                                          // (its buffer overlays the halo: only free after the barrier)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (pp + 1 < p.s_npairs) sdma(pp + 1);
+            sload(pp + 1 < p.s_npairs ? pp + 1 : pp);
+            __builtin_amdgcn_sched_barrier(0);
+            const _Float16* wbuf = lds_sw + (pp & 1) * (2 * NT * REC);
+            const int v0 = sa_rec, v1 = sa_rec + 4;
+            const int o0 = v0 * REC + ((q ^ swz(v0)) << 3);
+            const int o1 = v1 * REC + ((q ^ swz(v1)) << 3);
+            h8 ah[4], al[4];
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                ah[py * 2 + 0] = *reinterpret_cast<const h8*>(lds_sa + o0 + py * (48 * REC));
+                al[py * 2 + 0] = *reinterpret_cast<const h8*>(lds_sa + (o0 ^ 16) + py * (48 * REC));
+                ah[py * 2 + 1] = *reinterpret_cast<const h8*>(lds_sa + o1 + py * (48 * REC));
+                al[py * 2 + 1] = *reinterpret_cast<const h8*>(lds_sa + (o1 ^ 16) + py * (48 * REC));
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                h8 bh[2], bl[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    bh[k] = *reinterpret_cast<const h8*>(wbuf + ((nb * 2 + k) * 16) * REC + sb_hi);
+                    bl[k] = *reinterpret_cast<const h8*>(wbuf + ((nb * 2 + k) * 16) * REC + (sb_hi ^ 16));
+                }
+#pragma unroll
+                for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        f32x4v& c = acc[pi][nb * 2 + k];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[pi], bh[k], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi], bl[k], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi], bh[k], c, 0, 0, 0);
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
     // ---- epilogue.  Accumulator register r of tile (patch pi, column tile ni): voxel (dy = 4*(pi>>1) + r, dx = 4*(pi&1) +
     // dx_of_row(4*g4)), output channel ni*16 + row.
     const int vrow = p.vec ? (p.vec_idx ? p.vec_idx[b] : b) : 0;
@@ -431,7 +532,44 @@ __global__ __launch_bounds__(256) void pack_weights_h3v2_kernel(const float* __r
     }
 }
 
+// skip-conv weight image: [coutpad/64][npairs][2 chunks][64 positions][REC] from a Keras 1x1 kernel [cin][cout]; chunk t of pair i holds
+// input channels (2i+t)*16 .. +15 (zeros past cin), rows permuted / slots swizzled like the main image
+__global__ __launch_bounds__(256) void pack_skip_h3v2_kernel(const float* __restrict__ w, int cin, int cout, int npairs, int ntiles,
+                                                             float scale, _Float16* __restrict__ out) {
+    const long nrec = (long)ntiles * npairs * 2 * 64;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nrec * 16; i += (long)gridDim.x * 256) {
+        const int k = (int)(i & 15);
+        const long rec = i >> 4;
+        const int pos = (int)(rec % 64);
+        const int t = (int)((rec / 64) % 2);
+        const int pair = (int)((rec / 128) % npairs);
+        const int nt = (int)(rec / (128L * npairs));
+        const int p16 = pos & 15;
+        int c = 0;
+        for (int cc = 0; cc < 16; ++cc) if (pi_pos(cc) == p16) c = cc;
+        const int ci = (pair * 2 + t) * 16 + k, co = nt * 64 + (pos & ~15) + c;
+        const float v = (ci < cin && co < cout) ? w[(long)ci * cout + co] * scale : 0.0f;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        _Float16* r = out + rec * REC;
+        const int sw = (pos >> 2) & 3;
+        r[(((k >> 3) ^ sw) << 3) + (k & 7)] = hi;
+        r[(((2 + (k >> 3)) ^ sw) << 3) + (k & 7)] = lo;
+    }
+}
+
 }  // namespace
+
+int64_t dm3d_h3v2_skip_image_bytes(int cin, int cout) {
+    return (int64_t)(dm3d_round_up(cin, 32) / 32) * 2 * dm3d_round_up(cout, 64) * REC * (int64_t)sizeof(_Float16);
+}
+
+int dm3d_pack_skip_h3v2(const float* keras_kernel, int cin, int cout, int w_exp, void* packed, hipStream_t st) {
+    const int npairs = (int)(dm3d_round_up(cin, 32) / 32), ntiles = (int)(dm3d_round_up(cout, 64) / 64);
+    hipLaunchKernelGGL(pack_skip_h3v2_kernel, dim3(1024), dim3(256), 0, st, keras_kernel, cin, cout, npairs, ntiles, ldexpf(1.0f, w_exp),
+                       static_cast<_Float16*>(packed));
+    return dm3d_launch_check("pack_skip_h3v2_kernel");
+}
 
 // Workgroups per brick along Cin.  Goal: at least ~2 workgroups per CU (512) while every part keeps >= 2 chunks.  Without scratch
 // only the two-way atomic form exists, and only behind a linear epilogue.

@@ -41,7 +41,23 @@ def pack_weights(kernel: torch.Tensor, in_scale: Optional[torch.Tensor] = None) 
     return out
 
 
-def pack_weights_h3(kernel: torch.Tensor, in_scale: Optional[torch.Tensor] = None, stride: int = 1):
+def h3_weight_exponent(*kernels) -> int:
+    """Power-of-two pre-scale of the H3 weight images: the largest |w| of all given kernels lands in [2^13, 2^14)."""
+    import math
+    wmax = max(float(k.abs().max()) for k in kernels)
+    return 0 if wmax == 0.0 or not math.isfinite(wmax) else max(-100, min(100, int(13 - math.floor(math.log2(wmax)))))
+
+
+def pack_weights_skip_h3p(kernel: torch.Tensor, w_exp: int) -> torch.Tensor:
+    """Keras 1x1 kernel ([1,1,1,cin,cout] or [cin,cout]) -> image for conv3d(skip=...), packed with the main conv's w_exp."""
+    _f32c(kernel, "kernel")
+    cin, cout = kernel.shape[-2], kernel.shape[-1]
+    out = torch.empty(lib().dm3d_packed_weight_skip_h3p_bytes(cin, cout) // 2, dtype=torch.float16, device=kernel.device)
+    check(lib().dm3d_pack_weights_skip_h3p(kernel.data_ptr(), cin, cout, w_exp, out.data_ptr(), _st()), "pack_weights_skip_h3p")
+    return out
+
+
+def pack_weights_h3(kernel: torch.Tensor, in_scale: Optional[torch.Tensor] = None, stride: int = 1, w_exp: Optional[int] = None):
     """Keras kernel -> (float16 hi/lo image for the H3 conv kernels, w_exp).  max|w|*2^w_exp lands in [2^13, 2^14).
     ``stride`` is the stride of the conv that will read the image: it selects the layout (dm3d_conv_weight_layout)."""
     _f32c(kernel, "kernel")
@@ -49,9 +65,8 @@ def pack_weights_h3(kernel: torch.Tensor, in_scale: Optional[torch.Tensor] = Non
         raise ValueError("kernel must be [in,out] or [kd,kh,kw,cin,cout]")
     taps = 1 if kernel.dim() == 2 else kernel.shape[0] * kernel.shape[1] * kernel.shape[2]
     cin, cout = kernel.shape[-2], kernel.shape[-1]
-    wmax = float(kernel.abs().max())
-    import math
-    w_exp = 0 if wmax == 0.0 or not math.isfinite(wmax) else int(13 - math.floor(math.log2(wmax)))
+    if w_exp is None:
+        w_exp = h3_weight_exponent(kernel)
     ksize = {1: 1, 27: 3, 64: 4}.get(taps, 0)
     if ksize and lib().dm3d_conv_weight_layout(ksize, stride, 0, 0, cout) == _lib.WL_PAIR:
         out = torch.empty(lib().dm3d_packed_weight_h3p_bytes(taps, cin, cout) // 2, dtype=torch.float16, device=kernel.device)
@@ -105,8 +120,9 @@ def pack_weights_convt(kernel: torch.Tensor, h3: bool = False):
 
 def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False, pro_scale=None, pro_shift=None,
            vec=None, vec_idx=None, relu=False, res=None, precision=_lib.PREC_F32, w_exp=0, prelu_alpha=None,
-           relu_out=False, transpose=False) -> torch.Tensor:
-    """Conv3D(padding="same") on NDHWC with the fused prologue / concat / upsample / epilogue of dm3d_conv3d_ndhwc."""
+           relu_out=False, transpose=False, skip=None) -> torch.Tensor:
+    """Conv3D(padding="same") on NDHWC with the fused prologue / concat / upsample / epilogue of dm3d_conv3d_ndhwc.
+    ``skip=(sx1, sx2_or_None, skip_wpk)``: also accumulate Conv3D(cout, 1) of the raw concat(sx1, sx2) (H3, k3, stride 1)."""
     _f32c(x1, "x1")
     if x1.dim() != 5:
         raise ValueError("x1 must be [B,D,H,W,C]")
@@ -137,6 +153,10 @@ def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False
     if prelu_alpha is not None and tuple(prelu_alpha.shape) != (od, oh, ow, cout):
         raise ValueError("prelu_alpha must be [out_d, out_h, out_w, cout]")
     d.prelu_alpha, d.relu_out, d.transpose = _p(prelu_alpha), int(bool(relu_out)), int(bool(transpose))
+    if skip is not None:
+        sx1, sx2, swpk = skip
+        _f32c(sx1, "skip x1")
+        d.skip_x1, d.skip_x2, d.skip_c1, d.skip_c2, d.skip_wpk = sx1.data_ptr(), _p(sx2), sx1.shape[-1], (sx2.shape[-1] if sx2 is not None else 0), swpk.data_ptr()
     need = lib().dm3d_conv_scratch_bytes(C.byref(d))
     if need:
         scratch = torch.empty(need // 4, dtype=torch.float32, device=x1.device)     # stays alive until the launches are enqueued:

@@ -41,6 +41,12 @@ def _ptr(t: Optional[torch.Tensor], offset_elems: int = 0) -> Optional[int]:
     return t.data_ptr() + 4 * offset_elems
 
 
+def _h3_exponent(*kernels) -> int:
+    """power-of-two pre-scale so that max|w| over the given kernels lands in [2^13, 2^14): hi stays finite, lo a normal float16"""
+    wmax = max(float(np.abs(k).max()) for k in kernels)
+    return 0 if wmax == 0.0 or not np.isfinite(wmax) else max(-100, min(100, int(13 - np.floor(np.log2(wmax)))))
+
+
 class _Conv:
     """Packed Conv3D / Dense weights on the device."""
 
@@ -64,6 +70,7 @@ class UNet:
         if precision not in ("fp32", "h3"):
             raise ValueError("precision must be 'fp32' or 'h3'")
         self.precision = precision
+        self.fuse_skip = os.environ.get("DM3D_FUSE_SKIP", "1") != "0"      # A/B switch: ResidualBlock 1x1 skip conv inside conv2's launch
         self.cfg = cfg
         self.blocks, self.spec = walk(cfg)
         self.device = torch.device(device)
@@ -106,7 +113,7 @@ class UNet:
         return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(self.device)
 
     def _pack(self, kernel: np.ndarray, bias: Optional[np.ndarray], in_scale: Optional[torch.Tensor] = None,
-              conv: bool = False, up: bool = False, stride: int = 1) -> _Conv:
+              conv: bool = False, up: bool = False, stride: int = 1, w_exp: Optional[int] = None) -> _Conv:
         """``conv=True``: weights of a dm3d_conv3d_ndhwc launch (packed for self.precision); otherwise GEMM operand.
         ``up=True``: UpSample conv — packed as the 8 parity 2x2x2 kernels the upsample launch expects."""
         shape = kernel.shape
@@ -126,9 +133,8 @@ class UNet:
             return _Conv(wpk, dbias, taps, cin, cout)
         if conv and self.precision == "h3":
             # power-of-two pre-scale so that max|w| lands in [2^13, 2^14): hi stays finite, lo stays a normal float16
-            wmax = float(np.abs(kernel).max())
-            w_exp = 0 if wmax == 0.0 or not np.isfinite(wmax) else int(13 - np.floor(np.log2(wmax)))
-            w_exp = max(-100, min(100, w_exp))
+            if w_exp is None:
+                w_exp = _h3_exponent(kernel)
             if lib().dm3d_conv_weight_layout({1: 1, 27: 3}[taps], stride, 0, 0, cout) == _lib.WL_PAIR:
                 wpk = torch.empty(lib().dm3d_packed_weight_h3p_bytes(taps, cin, cout) // 2, dtype=torch.float16, device=self.device)
                 check(lib().dm3d_pack_weights_h3p(raw.data_ptr(), taps, cin, cout, w_exp, _ptr(in_scale), wpk.data_ptr(), 0,
@@ -179,10 +185,21 @@ class UNet:
         for blk in self.blocks:
             n = blk.name
             if blk.kind == "res":
-                if f"{n}.skip.kernel" in s:
-                    P[f"{n}.skip"] = self._pack(s[f"{n}.skip.kernel"], s[f"{n}.skip.bias"], conv=True)
                 P[f"{n}.conv1"] = self._pack(s[f"{n}.conv1.kernel"], s[f"{n}.conv1.bias"], conv=True)
-                P[f"{n}.conv2"] = self._pack(s[f"{n}.conv2.kernel"], s[f"{n}.conv2.bias"], conv=True)
+                if f"{n}.skip.kernel" in s and self.precision == "h3" and self.fuse_skip:
+                    # the 1x1 skip conv rides in conv2's launch (dm3d_conv_desc.skip_*): both images share one exponent, the
+                    # skip bias joins conv2's
+                    e = _h3_exponent(s[f"{n}.conv2.kernel"], s[f"{n}.skip.kernel"])
+                    P[f"{n}.conv2"] = self._pack(s[f"{n}.conv2.kernel"], s[f"{n}.conv2.bias"] + s[f"{n}.skip.bias"], conv=True, w_exp=e)
+                    ks = self._dev(s[f"{n}.skip.kernel"])
+                    cin_s, cout_s = int(ks.shape[-2]), int(ks.shape[-1])
+                    img = torch.empty(lib().dm3d_packed_weight_skip_h3p_bytes(cin_s, cout_s) // 2, dtype=torch.float16, device=self.device)
+                    check(lib().dm3d_pack_weights_skip_h3p(ks.data_ptr(), cin_s, cout_s, e, img.data_ptr(), _stream()), "pack_weights_skip_h3p")
+                    P[f"{n}.skip_fused"] = img
+                else:
+                    if f"{n}.skip.kernel" in s:
+                        P[f"{n}.skip"] = self._pack(s[f"{n}.skip.kernel"], s[f"{n}.skip.bias"], conv=True)
+                    P[f"{n}.conv2"] = self._pack(s[f"{n}.conv2.kernel"], s[f"{n}.conv2.bias"], conv=True)
                 P[f"{n}.norm1"] = self._fold_bn(f"{n}.norm1")
                 P[f"{n}.norm2"] = self._fold_bn(f"{n}.norm2")
                 temb_k.append(s[f"{n}.temb.kernel"])
@@ -409,7 +426,7 @@ class Plan:
         return (scale, shift), ct
 
     def _conv(self, w: _Conv, x1, out, edge_in, x2=None, c1=None, c2=0, upsample=0, stride=1, pro=None, vec_off=None,
-              relu=0, res=None, pro_bstride=0):
+              relu=0, res=None, pro_bstride=0, skip=None):
         d = ConvDesc()
         d.x1, d.x2 = _ptr(x1), _ptr(x2)
         d.c1, d.c2 = (c1 if c1 is not None else w.cin), c2
@@ -428,6 +445,11 @@ class Plan:
         d.relu, d.res, d.out, d.cout = relu, _ptr(res), _ptr(out), w.cout
         if d.c1 + d.c2 != w.cin:
             raise ValueError(f"conv input channels {d.c1}+{d.c2} != weight cin {w.cin}")
+        skip_flops = 0.0
+        if skip is not None:
+            sx1, sx2, sc1, sc2, simg = skip
+            d.skip_x1, d.skip_x2, d.skip_c1, d.skip_c2, d.skip_wpk = _ptr(sx1), _ptr(sx2), sc1, sc2, simg.data_ptr()
+            skip_flops = 2.0 * (sc1 + sc2) * w.cout * self.B * edge_in ** 3
         self._keep.append(d)
         up = 2 if upsample else 1
         eo = -(-edge_in * up // stride)
@@ -443,12 +465,15 @@ class Plan:
         else:
             kind = "conv_k3s1"
         self.ops.append((lib().dm3d_conv3d_ndhwc, (C.byref(d),), kind,
-                         {"desc": f"{kind} {edge_in}^3{'x2up' if upsample else ''} cin={w.cin} cout={w.cout}",
-                          "flops": 2.0 * w.taps * w.cin * w.cout * self.B * eo ** 3,      # algorithmic
+                         {"desc": f"{kind} {edge_in}^3{'x2up' if upsample else ''} cin={w.cin} cout={w.cout}"
+                                  + (f" +k1 skip cin={skip[2] + skip[3]}" if skip is not None else ""),
+                          # algorithmic; a fused 1x1 skip conv counts its own FLOPs here
+                          "flops": 2.0 * w.taps * w.cin * w.cout * self.B * eo ** 3 + skip_flops,
                           # MFMA work actually issued: the upsample conv runs as 8 parity convs of 8 taps on the low-res grid
-                          "exec_flops": 2.0 * (8 if upsample else w.taps) * w.cin * w.cout * self.B * eo ** 3
+                          "exec_flops": (2.0 * (8 if upsample else w.taps) * w.cin * w.cout * self.B * eo ** 3 + skip_flops)
                                         * (3 if w.precision == _lib.PREC_H3 else 1),
-                          "bytes": 4.0 * self.B * (edge_in ** 3 * w.cin + eo ** 3 * w.cout)}))
+                          "bytes": 4.0 * self.B * (edge_in ** 3 * (w.cin + (skip[2] + skip[3] if skip is not None else 0))
+                                                   + eo ** 3 * w.cout)}))
 
     def _gemm(self, **kw):
         d = _gemm_desc(**kw)
@@ -501,7 +526,10 @@ class Plan:
     def _res_block(self, blk, x1, c1, x2, c2, edge):
         """ResidualBlock (conditional_dm3d.py:238-271): three launches (two when the widths match)."""
         P, B, n, w = self.net.P, self.B, blk.name, blk.cout
-        if f"{n}.skip" in P:
+        skip = None
+        if f"{n}.skip_fused" in P:
+            res, skip = None, (x1, x2, c1, c2, P[f"{n}.skip_fused"])
+        elif f"{n}.skip" in P:
             res = self._buf(B, edge, edge, edge, w)
             self._conv(P[f"{n}.skip"], x1, res, edge, x2=x2, c1=c1, c2=c2)
         else:
@@ -511,7 +539,7 @@ class Plan:
         self._conv(P[f"{n}.conv1"], x1, hmid, edge, x2=x2, c1=c1, c2=c2, pro=pro, pro_bstride=bs, vec_off=self.net.temb_off[n])
         out = self._buf(B, edge, edge, edge, w)
         pro, bs = self._norm(f"{n}.norm2", hmid, w, edge)
-        self._conv(P[f"{n}.conv2"], hmid, out, edge, pro=pro, pro_bstride=bs, res=res)
+        self._conv(P[f"{n}.conv2"], hmid, out, edge, pro=pro, pro_bstride=bs, res=res, skip=skip)
         return out
 
     def _group_normed(self, n, x, u, edge):

@@ -103,6 +103,9 @@ int     dm3d_pack_weights_h3p(const float* keras_kernel, int32_t taps, int32_t c
                               const float* in_scale, void* packed, int32_t mode, void* stream);
 /* the layout dm3d_conv3d_ndhwc wants in wpk for a DM3D_PREC_H3 conv of this geometry (what w_layout must say) */
 int32_t dm3d_conv_weight_layout(int32_t ksize, int32_t stride, int32_t upsample, int32_t transpose, int32_t cout);
+/* image of a 1x1 kernel [cin, cout] for dm3d_conv_desc.skip_wpk (two 16-channel chunks per MFMA k-step) */
+int64_t dm3d_packed_weight_skip_h3p_bytes(int32_t cin, int32_t cout);
+int     dm3d_pack_weights_skip_h3p(const float* keras_kernel, int32_t cin, int32_t cout, int32_t w_exp, void* packed, void* stream);
 
 /* ---- Conv3D(padding="same") as implicit GEMM on MFMA ---------------------------------------------------------
  * Replaces layers.Conv3D for k=3/s=1 (:257-259, :348-353, :412-414), k=3/s=2 (DownSample :274-285, TF SAME pad 0
@@ -148,6 +151,12 @@ typedef struct dm3d_conv_desc {
                                    the batch (folded BatchNormalization), c1+c2 = per-sample vectors (GroupNormalization,
                                    written by dm3d_groupnorm_finalize) */
     int32_t w_layout;           /* H3 only: DM3D_WL_TAP or DM3D_WL_PAIR, must equal dm3d_conv_weight_layout(...) */
+    /* ResidualBlock skip path fused into this launch (DM3D_PREC_H3, DM3D_WL_PAIR, ksize 3, stride 1, no upsample only):
+       out += Conv3D(cout, 1)(concat(skip_x1, skip_x2)) on the raw tensors (no prologue), i.e. layers.Add()([x, residual]) with
+       residual = layers.Conv3D(width, kernel_size=1)(x) (conditional_dm3d.py:243-248, 268) without a launch, a tensor or a
+       residual read of its own.  skip_wpk from dm3d_pack_weights_skip_h3p, packed with THIS conv's w_exp; add the skip bias into
+       bias.  All NULL / 0 when unused. */
+    const float* skip_x1; const float* skip_x2; int32_t skip_c1, skip_c2; const void* skip_wpk;
     void* scratch;              /* optional workspace (16-byte aligned) of scratch_bytes bytes, or NULL.  With it, convs whose grid
                                    would leave most of the chip idle (small batches, the 8^3 level) split their Cin range over up
                                    to 16 workgroups per brick; the partial sums meet in a fixed order in a second launch that also

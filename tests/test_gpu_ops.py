@@ -145,6 +145,40 @@ def test_conv3d_random_shapes(dev, case, prec):
     test_conv3d(dev, case, prec)
 
 
+@pytest.mark.parametrize("case", [
+    # name, B, dims, main cin, skip c1, skip c2, cout, extras
+    ("skip_single", 2, (8, 8, 8), 64, 32, 0, 64, "bias pro vec"),
+    ("skip_dual_ragged", 1, (6, 5, 7), 32, 48, 20, 72, "bias pro"),
+    ("skip_deep_splitk", 1, (8, 8, 8), 128, 256, 128, 128, "bias pro vec"),     # small grid: part 0 of the split carries the skip
+    ("skip_odd_chunks", 2, (4, 8, 8), 16, 16, 0, 64, ""),                       # 16 skip channels: one real + one zero chunk
+], ids=lambda c: c[0])
+def test_conv3d_fused_skip(dev, case):
+    """ResidualBlock tail in one launch: conv_k3(silu(bn(h))) + bias + temb + Conv3D(width, 1)(concat(x, skip)) against the two
+    separate float64 convolutions."""
+    from dm3d_amd import ops, _lib
+    name, B, (D, H, W), cm, s1, s2, cout, extras = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    h = rnd(B, D, H, W, cm)
+    x1, x2 = rnd(B, D, H, W, s1), (rnd(B, D, H, W, s2) if s2 else None)
+    kern = rnd(3, 3, 3, cm, cout) / math.sqrt(cm * 27)
+    kskip = rnd(1, 1, 1, s1 + s2, cout) / math.sqrt(s1 + s2) * 3.0            # deliberately a different magnitude than kern
+    bias = rnd(cout) if "bias" in extras else None
+    pro = (torch.rand(cm, generator=g) + 0.5, rnd(cm) * 0.1) if "pro" in extras else None
+    vec = rnd(5, cout + 8) if "vec" in extras else None
+    ref = _conv_ref(h, kern, bias, pro=pro, vec=vec) + _conv_ref(x1, kskip, None, x2=x2)
+    c = lambda t: None if t is None else t.to(dev).contiguous()
+    w_exp = ops.h3_weight_exponent(kern, kskip)
+    wpk, _ = ops.pack_weights_h3(c(kern), w_exp=w_exp)
+    swpk = ops.pack_weights_skip_h3p(c(kskip), w_exp)
+    out = ops.conv3d(c(h), wpk, cout, 3, bias=c(bias), pro_scale=c(pro[0]) if pro else None, pro_shift=c(pro[1]) if pro else None,
+                     vec=c(vec), precision=_lib.PREC_H3, w_exp=w_exp, skip=(c(x1), c(x2), swpk))
+    torch.cuda.synchronize()
+    err = _rel(out, ref)
+    print(f"{name}: rel err {err:.2e}")
+    assert err < 2e-5, f"{name}: rel err {err:.3e}"
+
+
 def test_conv3d_h3_tap_layout_arm(dev):
     """DM3D_CONV_PAIR=0 (read when the library is loaded) routes every H3 conv to the 32x32x16 kernel with the DM3D_WL_TAP weight
     layout: the A/B arm of the 16x16x32 kernel must stay correct.  One child interpreter, same parity cases."""
