@@ -353,8 +353,6 @@ def keras_layer_plan(cfg) -> List[Tuple[str, str]]:
     plan = [("conv3d", "conv_in"), ("dense", "time_mlp.0"), ("dense", "time_mlp.1")]
     if cfg.conditional:
         plan.append(("embedding", "ctx_embed"))
-    widths = list(cfg.widths)
-
     def res(name, cin, width):
         if cin != width:
             plan.append(("conv3d", f"{name}.skip"))
@@ -373,7 +371,6 @@ def keras_layer_plan(cfg) -> List[Tuple[str, str]]:
         elif blk.kind in ("down", "up"):
             plan.append(("conv3d", blk.name))
     plan.extend([("batch_normalization", "out.norm"), ("conv3d", "out.conv")])
-    del widths
     return plan
 
 
@@ -489,12 +486,11 @@ def save_unet_checkpoint(prefix: str, state: Dict[str, np.ndarray], cfg, root: T
     sublayers under their attribute names.  Lets weights trained here flow back into the reference, and is the fixture
     generator of the tests."""
     plan = keras_layer_plan(cfg)
-    counters = dict(first_index or {})
-    sub_counters = counters                                 # sublayers draw from the same per-class counters
+    counters = dict(first_index or {})                      # per-class creation counters; sublayers draw from the same ones
 
     def auto(cls):
-        i = sub_counters.get(cls, 0)
-        sub_counters[cls] = i + 1
+        i = counters.get(cls, 0)
+        counters[cls] = i + 1
         return cls if i == 0 else f"{cls}_{i}"
 
     inv_var = {v: k for k, v in _VAR.items()}
