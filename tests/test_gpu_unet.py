@@ -77,6 +77,33 @@ def test_unet_eps_live_oracle_blocks(dev):
     assert torch.equal(e1, e2)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(widths=(32, 64), has_attention=(False, True), num_res_blocks=1, first_conv_channels=16),          # narrow: Cout <= 32 kernels
+    dict(widths=(48, 80, 112), has_attention=(True, False, True), num_res_blocks=1),                        # not multiples of 64
+    dict(widths=(64,), has_attention=(True,), num_res_blocks=3),                                            # one level, no down/up path
+    dict(widths=(64, 128), has_attention=(False, False), num_res_blocks=2, conditional=False, first_conv_channels=64),
+], ids=["narrow", "odd_widths", "single_level", "uncond_no_attn"])
+@pytest.mark.parametrize("prec", ["h3", "fp32"])
+def test_unet_other_build_model_arguments(dev, kw, prec):
+    """build_model is parametric (conditional_dm3d.py:324-335): widths, attention flags, block counts other than the
+    reference's defaults go through the same plan builder and must match the oracle as well."""
+    import dm3d_amd
+    from dm3d_amd.unet import UNet
+    from oracle import ref_torch as rt
+    cfg = dm3d_amd.UNetConfig(img_size=8, img_channels=4, **kw)
+    W = dm3d_amd.synthetic_weights(cfg, seed=6)
+    net = UNet(cfg, weights=W, precision=prec)
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(2, 8, 8, 8, 4, generator=g)
+    t = torch.tensor([0, 731])
+    ctx = torch.tensor([[[0]], [[1]]])
+    ocfg = rt.UNetConfig(img_size=8, img_channels=4, **kw)
+    ref = rt.unet_forward({k: torch.from_numpy(v) for k, v in W.items()}, ocfg, x, t, ctx if cfg.conditional else None)
+    eps = net([x.to(dev), t, ctx] if cfg.conditional else [x.to(dev), t])
+    torch.cuda.synchronize()
+    assert _rel(eps, ref) < TOL
+
+
 def test_generate_matches_golden_trajectory(dev):
     import dm3d_amd
     from dm3d_amd.networks import conditional_dm3d as cdm
