@@ -215,6 +215,59 @@ __global__ __launch_bounds__(256) void softmax_rows_h2_kernel(float* __restrict_
     }
 }
 
+// Rows longer than 1024 (attention over 16^3 = 4096 tokens at 64^3 latents): three passes over the row (max, sum, write), the
+// row stays in L2.  Lanes g and g^1 share one 64-byte record and sit in the same wave iteration, so both have loaded their
+// float32 halves before either stores float16 pieces over them.
+__global__ __launch_bounds__(256) void softmax_rows_h2_stream_kernel(float* __restrict__ s, long rows, int cols, long ld) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* r = s + row * ld;
+    const int ng = cols >> 3, iters = (ng + 63) / 64;
+    float mx = -INFINITY;
+    for (int j = 0; j < iters; ++j) {
+        const int g = lane + j * 64;
+        if (g < ng) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(r + g * 8), b = *reinterpret_cast<const f32x4*>(r + g * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fmaxf(a[e], b[e]));
+        }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = 0; j < iters; ++j) {
+        const int g = lane + j * 64;
+        if (g < ng) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(r + g * 8), b = *reinterpret_cast<const f32x4*>(r + g * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += __expf(a[e] - mx) + __expf(b[e] - mx);
+        }
+    }
+    const float inv = 1.0f / wave_sum(sum);
+    _Float16* rh = reinterpret_cast<_Float16*>(r);
+    for (int j = 0; j < iters; ++j) {
+        const int g = lane + j * 64;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+        if (g < ng) {
+            a = *reinterpret_cast<const f32x4*>(r + g * 8);
+            b = *reinterpret_cast<const f32x4*>(r + g * 8 + 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[e] = __expf(a[e] - mx) * inv;
+            b[e] = __expf(b[e] - mx) * inv;
+        }
+        h8 hi, lo;
+        split8(a, b, 65504.0f, 65504.0f, hi, lo);
+        __builtin_amdgcn_sched_barrier(0);                      // every load of this iteration is above, every store below
+        if (g < ng) {
+            _Float16* rec = rh + (g >> 1) * DM3D_REC;
+            *reinterpret_cast<h8*>(rec + (g & 1) * 8) = hi;
+            *reinterpret_cast<h8*>(rec + 16 + (g & 1) * 8) = lo;
+        }
+    }
+}
+
 // ---- y = act(x*scale[c] + shift[c]) ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, float* __restrict__ y, long n4,
                                                          int c4, const float* scale, const float* shift, int act) {
@@ -588,8 +641,13 @@ extern "C" int dm3d_layernorm3_h2(const float* x, int64_t rows, int32_t c, float
 
 extern "C" int dm3d_softmax_rows_h2(float* s, int64_t rows, int32_t cols, int64_t ld, void* stream) {
     DM3D_REQUIRE(s && rows > 0 && cols > 0 && ld >= cols, "softmax_h2: bad arguments");
-    DM3D_REQUIRE(cols % 16 == 0 && cols <= 1024 && ld % 16 == 0 && dm3d_aligned16(s),
-                 "softmax_h2: cols=%d must be a multiple of 16 and <= 1024, ld %% 16 == 0, s 16-byte aligned", cols);
+    DM3D_REQUIRE(cols % 16 == 0 && ld % 16 == 0 && dm3d_aligned16(s),
+                 "softmax_h2: cols=%d must be a multiple of 16, ld %% 16 == 0, s 16-byte aligned", cols);
+    if (cols > 1024) {
+        hipLaunchKernelGGL(softmax_rows_h2_stream_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           s, (long)rows, cols, (long)ld);
+        return dm3d_launch_check("softmax_rows_h2_stream_kernel");
+    }
     hipLaunchKernelGGL(softmax_rows_h2_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        s, (long)rows, cols, (long)ld);
     return dm3d_launch_check("softmax_rows_h2_kernel");

@@ -562,12 +562,19 @@ class Plan:
         self._gemm(a=scores, lda=L, stride_a=L * L, b=v_t, b_off=v_off, ldb=v_ld, stride_b=v_stride, out=out, ldo=u,
                    stride_o=L * u, m=L, n=u, k=L, batch=B, res=res, ldr=u, stride_r=L * u, h3=h2, a_h2=h2, b_h2=h2)
 
+    @staticmethod
+    def _check_tokens(L: int):
+        if L % 4:
+            raise ValueError(f"attention over {L} tokens: the P.V contraction runs on the MFMA GEMM, which needs D*H*W % 4 == 0 at "
+                             "attention levels (edge 3 or 5 are not supported; the reference's latents give 4^3, 8^3, 16^3)")
+
     def _cross_block(self, blk, x, edge):
         """CrossAttentionBlock (conditional_dm3d.py:186-195).  With precision "h3" every intermediate that only feeds
         Dense layers (LayerNorm outputs, q|k, v^T, probabilities, MLP hidden, a3) lives in DM3D_FMT_H2."""
         P, B, n, u = self.net.P, self.B, blk.name, blk.cout
         L = edge ** 3
         M = B * L
+        self._check_tokens(L)
         h2 = self.net._attn_h2(u, L)
         if h2:
             return self._cross_block_h2(blk, x, edge)
@@ -679,6 +686,7 @@ class Plan:
         P, B, n, u = self.net.P, self.B, blk.name, blk.cout
         L = edge ** 3
         M = B * L
+        self._check_tokens(L)
         h2 = self.net._attn_h2(u, L)
         W = (lambda w: w.h2) if h2 else (lambda w: w.wpk)
         qk, val, proj = P[f"{n}.qk"], P[f"{n}.value"], P[f"{n}.proj"]

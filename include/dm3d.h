@@ -230,12 +230,13 @@ int dm3d_affine_act_batched(const float* x, float* y, int32_t batch, int64_t row
 
 /* ---- tf.nn.softmax(scores, -1) in place, one wavefront per row (shuffle reductions) (:178; U:56) ------------ */
 int dm3d_softmax_rows(float* s, int64_t rows, int32_t cols, int64_t ld, void* stream);
-/* same, result left in place in DM3D_FMT_H2 (cols % 16 == 0, ld % 16 == 0, cols <= 1024): it only feeds the P.V contraction */
+/* same, result left in place in DM3D_FMT_H2 (cols % 16 == 0, ld % 16 == 0; rows longer than 1024 take a three-pass streaming
+ * form): it only feeds the P.V contraction */
 int dm3d_softmax_rows_h2(float* s, int64_t rows, int32_t cols, int64_t ld, void* stream);
 
 /* ---- single-head attention  out = softmax(q k^T * scale) v (+ res)  per sample (:163-184; U:47-61) in one call: the score
  * product, the row softmax and the P.V product that a host otherwise issues itself, on caller-provided scratch.  L = D*H*W
- * flattened tokens (<= 1024 per row for the H2 softmax), single head (the reference never uses num_heads > 1).
+ * flattened tokens, single head (the reference never uses num_heads > 1).
  *   q   [batch, lq, c]       row stride ldq
  *   k   [batch | 1, lk, c]   row stride ldk; stride_k = 0 broadcasts one context's keys to the whole batch
  *   vt  [batch | 1, c, lk]   the value tensor TRANSPOSED (it is the K-contiguous operand of P.V); row stride ldv, stride_vt

@@ -387,7 +387,7 @@ def test_h2_format_roundtrip_and_norm_kernels(dev):
             ref = torch.nn.functional.layer_norm(y.double(), (c,), ga.double(), be.double(), 1e-3)
             assert _rel(ops.h2_to_f32(o, c), ref) < 3e-6
     # softmax left in place in H2
-    for rows, cols in ((9, 512), (130, 64), (2, 1024), (5, 16)):
+    for rows, cols in ((9, 512), (130, 64), (2, 1024), (5, 16), (7, 4096), (3, 1040), (2, 8208)):     # > 1024: streaming form
         sc = torch.randn(rows, cols, generator=g) * 4
         out = ops.softmax_rows_h2_(sc.to(dev).clone())
         torch.cuda.synchronize()

@@ -104,6 +104,30 @@ def test_unet_other_build_model_arguments(dev, kw, prec):
     assert _rel(eps, ref) < TOL
 
 
+@pytest.mark.parametrize("size,kw", [
+    (24, dict(widths=(16, 32, 48), num_res_blocks=1, first_conv_channels=16)),      # 6^3 = 216 tokens: not a multiple of 16
+    (20, dict(widths=(16, 32), has_attention=(False, True), num_res_blocks=1, first_conv_channels=16)),   # 10^3 tokens, ragged bricks
+    (64, dict(widths=(16, 32, 64), num_res_blocks=1, first_conv_channels=16)),      # 16^3 = 4096 tokens: the streaming softmax
+], ids=["24cube_216tok", "20cube_1000tok", "64cube_4096tok"])
+def test_unet_other_latent_sizes(dev, size, kw):
+    import dm3d_amd
+    from dm3d_amd.unet import UNet
+    from oracle import ref_torch as rt
+    cfg = dm3d_amd.UNetConfig(img_size=size, img_channels=4, **kw)
+    W = dm3d_amd.synthetic_weights(cfg, seed=1)
+    x = torch.randn(1, size, size, size, 4, generator=torch.Generator().manual_seed(0))
+    t, ctx = torch.tensor([900]), torch.tensor([[[1]]])
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    ref = rt.unet_forward({k: torch.from_numpy(v) for k, v in W.items()}, rt.UNetConfig(img_size=size, img_channels=4, **kw), x, t, ctx)
+    for prec in ("h3", "fp32"):
+        eps = UNet(cfg, weights=W, precision=prec)([x.to(dev), t, ctx])
+        torch.cuda.synchronize()
+        assert _rel(eps, ref) < TOL, prec
+    bad = dm3d_amd.UNetConfig(img_size=12, img_channels=4, widths=(16, 32, 48), num_res_blocks=1, first_conv_channels=16)
+    with pytest.raises(ValueError, match="tokens"):        # 3^3 = 27 tokens at the attention level
+        UNet(bad, weights=None)([torch.zeros(1, 12, 12, 12, 4, device=dev), t, ctx])
+
+
 def test_generate_matches_golden_trajectory(dev):
     import dm3d_amd
     from dm3d_amd.networks import conditional_dm3d as cdm
