@@ -192,11 +192,18 @@ class DiffusionModel:
         return mean, var.reshape(B, 1, 1, 1, 1)
 
     # -- a14: generate ----------------------------------------------------------------------------------------------
-    def _context_ids(self, context_value):
+    def _context_ids(self, context_value, batch=None):
+        """The reference takes one scalar id and broadcasts it (conditional_dm3d.py:552); an array of shape [B], [B,1] or [B,1,1]
+        gives every volume of the batch its own context."""
         if context_value is None:
             # the reference builds tf.constant([[None]]) here and fails (conditional_dm3d.py:552, 586-589)
             raise ValueError("context_value is required for the conditional model")
-        return np.asarray([int(context_value)], dtype=np.int32)
+        ids = np.asarray(context_value.detach().cpu() if torch.is_tensor(context_value) else context_value).astype(np.int64).reshape(-1)
+        if ids.size != 1 and batch is not None and ids.size != batch:
+            raise ValueError(f"context_value must hold one id or one per volume ({batch}), got {ids.size}")
+        if ids.min() < 0 or ids.max() > self.network.cfg.context_dim:
+            raise ValueError(f"context ids must lie in [0, {self.network.cfg.context_dim}]")
+        return ids.astype(np.int32)
 
     def sampler(self, shape, context_value=None, *, seed=0, use_graph=True) -> "Sampler":
         """The state of one generate() call: plan, tables, context rows and the captured step graph."""
@@ -205,7 +212,7 @@ class DiffusionModel:
         shape = tuple(int(s) for s in shape)
         if len(shape) != 5 or shape[1:] != (cfg.img_size,) * 3 + (cfg.img_channels,):
             raise ValueError(f"shape must be (B,{cfg.img_size},{cfg.img_size},{cfg.img_size},{cfg.img_channels})")
-        return Sampler(self, shape, self._context_ids(context_value) if self.conditional else None, seed, use_graph)
+        return Sampler(self, shape, self._context_ids(context_value, shape[0]) if self.conditional else None, seed, use_graph)
 
     def generate(self, shape=(1, 16, 16, 16, 16), last_step=0, context_value=None, *, x_T=None, noise=None, seed=0,
                  use_graph=True, steps=None):
@@ -287,7 +294,7 @@ class Sampler:
     def __init__(self, model: DiffusionModel, shape, ctx_ids, seed, use_graph):
         self.model, self.shape, self.seed, self.use_graph = model, shape, int(seed) & (2 ** 64 - 1), use_graph
         net, T = model.network, model.timesteps
-        self.plan = net.plan(shape[0], T, False)
+        self.plan = net.plan(shape[0], T, ctx_ids is not None and len(ctx_ids) > 1)       # one context row per volume, or one broadcast
         if getattr(self.plan, "_time_filled", None) is not net.P:
             net.fill_time_table(np.arange(T), self.plan.vec)
             self.plan._time_filled = net.P

@@ -161,6 +161,13 @@ def test_generate_graph_equals_eager_and_is_deterministic(dev):
         m.generate((2, 8, 8, 8, 4), context_value=None)
     with pytest.raises(ValueError):
         m.generate((2, 8, 8, 4, 4), context_value=0)
+    # one context id per volume (extension of the reference's single broadcast id): each chain equals its single-context twin
+    mixed = m.generate((2, 8, 8, 8, 4), context_value=torch.tensor([[[0]], [[1]]]), seed=5)
+    assert torch.equal(mixed[0], a[0]) and torch.equal(mixed[1], e[1])
+    with pytest.raises(ValueError):
+        m.generate((2, 8, 8, 8, 4), context_value=[0, 1, 1])
+    with pytest.raises(ValueError):
+        m.generate((2, 8, 8, 8, 4), context_value=7)
 
 
 def test_unconditional_config1_generate(dev):
