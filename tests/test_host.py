@@ -39,6 +39,34 @@ def test_struct_layouts_match_the_header(built_library, tmp_path):
                      ctypes.sizeof(_lib.AttentionDesc)]
 
 
+def test_plain_c_program_links_against_the_abi(built_library, tmp_path):
+    """The boundary is a C ABI: a C99 translation unit including only include/dm3d.h compiles with gcc, links against the shared
+    library and calls the entries that need no device (version, size queries, layout query, argument validation)."""
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "dm3d.h"
+int main(void) {
+    dm3d_conv_desc d;
+    memset(&d, 0, sizeof d);
+    int rc = dm3d_conv3d_ndhwc(&d, NULL);                 /* all-null descriptor: refused before any device call */
+    printf("%d %d %lld %lld %d %s\n", dm3d_version() > 0, dm3d_conv_weight_layout(3, 2, 0, 0, 64),
+           (long long)dm3d_packed_weight_h3_bytes(27, 64, 64), (long long)dm3d_attention_workspace_bytes(2, 64, 48), rc != 0,
+           dm3d_last_error());
+    return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(built_library)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-ldm3d_hip", f"-Wl,-rpath,{libdir}"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    f = out.split(None, 5)
+    assert f[0] == "1" and f[1] == "0" and int(f[2]) == 27 * 64 * 4 * 64 * 2 // 2 * 1 and int(f[3]) == 2 * 64 * 48 * 4 and f[4] == "1"
+    assert "conv" in f[5]
+
+
 def test_argument_validation_needs_no_gpu(built_library):
     """Bad descriptors are rejected before any launch, with a readable message."""
     from dm3d_amd import _lib
