@@ -187,6 +187,8 @@ def main():
                 if row and row[0] == want:
                     roofline["traffic"] = float(row[4]) * 1e6
                     roofline["traffic_unit"] = "bytes/launch (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc, " + os.path.basename(path) + ")"
+                    roofline["hbm_GBps_of_kernel"] = round(roofline["traffic"] / (roofline["avg_launch_ms"] * 1e-3) / 1e9, 1)
+                    roofline["hbm_frac_of_8TBps"] = round(roofline["hbm_GBps_of_kernel"] / 8000.0, 4)
         except Exception:
             pass
 
