@@ -12,6 +12,7 @@
 //     so rows {0-3,12-15} take the patch columns dx in {0,1} and rows {4-11} take dx in {2,3} (record mod 4 = dx): conflict-free
 //     for every tap.  Weight rows get the same treatment by permuting their LDS position inside each group of 16 (PI below).
 //   * A wave owns one 8 x 8 z-slice = 2 x 2 patches x 64 output channels = 16 tiles of 16 x 16 (64 accumulator registers).
+#include <cstdlib>
 #include "dm3d_conv_args.h"
 #include "dm3d_h3.h"
 
@@ -446,6 +447,15 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const float* __r
     }
 }
 
+// Zero fill as a kernel of our own: a hipMemsetAsync captured into the per-step HIP graph becomes a memset node, and replays of
+// that graph were observed to race it against the atomic adds of the following conv (two full T = 1000 chains diverged after
+// ~90 steps; eager launches and graphs without memset nodes did not).  A kernel node is ordered like every other launch.
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, long n4, long n) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) reinterpret_cast<f32x4*>(p)[i] = z;
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[n4 * 4 + threadIdx.x] = 0.f;
+}
+
 template <int KS, bool PRO>
 int launch_v2(ConvArgs& a, hipStream_t st) {
     constexpr int HREC = (3 + KS) * (7 + KS) * 12;
@@ -469,10 +479,15 @@ int launch_v2(ConvArgs& a, hipStream_t st) {
     a.split_stride = 0;
     ConvArgs k = a;
     const bool linear = !a.relu && !a.prelu && !a.relu_out && a.res != a.out && a.x1 != a.out && a.x2 != a.out;
-    const bool atomic2 = a.ksplit == 2 && linear && a.nchunks >= 8;       // cheaper than a reduce launch when two parts suffice
+    static const bool no_atomic = [] { const char* e = getenv("DM3D_CONV_NO_ATOMIC"); return e && e[0] == '1'; }();
+    const bool atomic2 = a.ksplit == 2 && linear && a.nchunks >= 8 && !(no_atomic && with_scratch);       // cheaper than a reduce launch when two parts suffice
     if (a.ksplit > 1 && (!with_scratch || atomic2)) {         // two halves, order-independent atomic add into the zeroed output
         k.split_atomic = 1;
-        DM3D_HIP(hipMemsetAsync(a.out, 0, out_elems * sizeof(float), st));
+        long zg = ((long)(out_elems / 4) + 255) / 256;
+        if (zg > 4096) zg = 4096;
+        if (zg < 1) zg = 1;
+        hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)zg), dim3(256), 0, st, a.out, (long)(out_elems / 4), (long)out_elems);
+        if (int zrc = dm3d_launch_check("zero_f32_kernel")) return zrc;
     } else if (a.ksplit > 1) {                                // raw partial sums -> scratch; epilogue in the reduce launch
         DM3D_REQUIRE((size_t)a.scratch_bytes >= out_elems * sizeof(float) * a.ksplit, "conv: scratch of %ld bytes is too small", a.scratch_bytes);
         DM3D_REQUIRE(out_elems < (1ull << 31), "conv: split-K output of %zu elements overflows the reduce kernel's 32-bit index", out_elems);
@@ -574,6 +589,8 @@ int dm3d_pack_skip_h3v2(const float* keras_kernel, int cin, int cout, int w_exp,
 // Workgroups per brick along Cin.  Goal: at least ~2 workgroups per CU (512) while every part keeps >= 2 chunks.  Without scratch
 // only the two-way atomic form exists, and only behind a linear epilogue.
 int dm3d_conv_h3v2_ksplit(const ConvArgs& a, bool with_scratch) {
+    static const int mode = [] { const char* e = getenv("DM3D_CONV_KSPLIT"); return e ? atoi(e) : -1; }();   // 0: never split (A/B, debugging)
+    if (mode == 0) return 1;
     const long bd = (a.od + 3) / 4, bh = (a.oh + 7) / 8, bw = (a.ow + 7) / 8;
     const long wgs = (long)a.batch * bd * bh * bw * (a.coutpad / 64) * (a.parity ? 8 : 1);
     if (wgs > 256 || a.nchunks < 4) return 1;
