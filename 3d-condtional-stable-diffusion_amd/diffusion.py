@@ -137,7 +137,7 @@ class DiffusionModel:
 
     def _drop_graphs(self):
         for g in self._graphs.values():
-            lib().dm3d_graph_destroy(g)
+            lib().dm3d_graph_destroy(g[0])
         self._graphs = {}
 
     def __del__(self):
@@ -236,22 +236,29 @@ class DiffusionModel:
                 smp.step()
         return smp.plan.x.clone()
 
+    MAX_GRAPHS = 8      # captured step graphs kept per model (one per (plan, seed)); the least recently used one is destroyed
+
     def _capture(self, smp: "Sampler"):
         """Capture one step of ``smp`` into a HIP graph (cached per plan and seed; the seed is a kernel argument)."""
         key = (id(smp.plan), smp.seed)
-        if key not in self._graphs:
+        if key in self._graphs:
+            self._graphs[key] = self._graphs.pop(key)                  # most recently used last
+            return self._graphs[key][0]
+        torch.cuda.synchronize()
+        cap = torch.cuda.Stream()
+        g = C.c_void_p()
+        check(lib().dm3d_graph_begin(cap.cuda_stream), "graph_begin")
+        try:
+            smp._enqueue(cap.cuda_stream, smp.desc)
+        finally:
+            rc = lib().dm3d_graph_end(cap.cuda_stream, C.byref(g))
+        check(rc, "graph_end")
+        self._graphs[key] = (g, smp.desc, cap, smp.plan)               # the graph references the descriptor's and plan's memory
+        while len(self._graphs) > self.MAX_GRAPHS:
+            old = next(iter(self._graphs))
             torch.cuda.synchronize()
-            cap = torch.cuda.Stream()
-            g = C.c_void_p()
-            check(lib().dm3d_graph_begin(cap.cuda_stream), "graph_begin")
-            try:
-                smp._enqueue(cap.cuda_stream, smp.desc)
-            finally:
-                rc = lib().dm3d_graph_end(cap.cuda_stream, C.byref(g))
-            check(rc, "graph_end")
-            self._graphs[key] = g
-            self._graph_keep = getattr(self, "_graph_keep", []) + [smp.desc, cap, smp.plan]
-        return self._graphs[key]
+            lib().dm3d_graph_destroy(self._graphs.pop(old)[0])
+        return g
 
     def test(self, test_prefix, context=None):
         """conditional_dm3d.py:577-594: generate 10 latents, decode them, np.save the images.  The reference hard-codes the

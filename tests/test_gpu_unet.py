@@ -161,6 +161,12 @@ def test_generate_graph_equals_eager_and_is_deterministic(dev):
         m.generate((2, 8, 8, 8, 4), context_value=None)
     with pytest.raises(ValueError):
         m.generate((2, 8, 8, 4, 4), context_value=0)
+    # many seeds: the per-(plan, seed) graph cache stays bounded and an evicted seed is simply captured again
+    first = m.generate((2, 8, 8, 8, 4), context_value=0, seed=100)
+    for sd in range(101, 101 + 2 * m.MAX_GRAPHS):
+        m.generate((2, 8, 8, 8, 4), context_value=0, seed=sd)
+    assert len(m._graphs) <= m.MAX_GRAPHS
+    assert torch.equal(first, m.generate((2, 8, 8, 8, 4), context_value=0, seed=100))
     # one context id per volume (extension of the reference's single broadcast id): each chain equals its single-context twin
     mixed = m.generate((2, 8, 8, 8, 4), context_value=torch.tensor([[[0]], [[1]]]), seed=5)
     assert torch.equal(mixed[0], a[0]) and torch.equal(mixed[1], e[1])
