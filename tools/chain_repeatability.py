@@ -5,9 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from types import SimpleNamespace
 import torch, dm3d_amd
 from dm3d_amd.networks import conditional_dm3d as cdm
-cfg = dm3d_amd.UNetConfig(img_size=32, img_channels=8)
+NORM = os.environ.get("DM3D_NORM", "batch")
+cfg = dm3d_amd.UNetConfig(img_size=32, img_channels=8, norm=NORM)
 m = cdm.DiffusionModel(32, 1024, 8, None, SimpleNamespace(timesteps=1000, num_gpus=1, kernel_resize=False, bs=32),
-                       weights=dm3d_amd.synthetic_weights(cfg, seed=0))
+                       weights=dm3d_amd.synthetic_weights(cfg, seed=0), norm=NORM,
+                       precision=os.environ.get("DM3D_PRECISION", "h3"))
 B = 32
 use_graph = (sys.argv[1] == "graph") if len(sys.argv) > 1 else True
 every = 10
