@@ -3,7 +3,7 @@ single float16 weights (h2) and bfloat16 (bf) in the oracle and prints the relat
 CPU only (imports oracle/: a measurement tool, not product code).  Measured: h1 1.2-1.6e-3, h2 0.8-1.2e-3, bf 1e-2 -> all
 miss the 1e-3 parity bar that the three-pass split meets with 5e-6."""
 import sys, torch, numpy as np
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
 from oracle import ref_torch as rt
 torch.set_num_threads(8)
 orig = rt._conv3d
