@@ -593,7 +593,8 @@ int dm3d_conv_h3v2_ksplit(const ConvArgs& a, bool with_scratch) {
     if (mode == 0) return 1;
     const long bd = (a.od + 3) / 4, bh = (a.oh + 7) / 8, bw = (a.ow + 7) / 8;
     const long wgs = (long)a.batch * bd * bh * bw * (a.coutpad / 64) * (a.parity ? 8 : 1);
-    if (wgs > 256 || a.nchunks < 4) return 1;
+    static const long wg_limit = [] { const char* e = getenv("DM3D_CONV_SPLIT_WGS"); return e ? atol(e) : 256L; }();   // A/B knob
+    if (wgs > wg_limit || a.nchunks < 4) return 1;
     if (!with_scratch) {
         const bool linear = !a.relu && !a.prelu && !a.relu_out && a.res != a.out && a.x1 != a.out && a.x2 != a.out;
         return (linear && a.nchunks >= 8 && a.nchunks % 2 == 0) ? 2 : 1;
