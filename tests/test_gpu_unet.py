@@ -128,6 +128,55 @@ def test_unet_other_latent_sizes(dev, size, kw):
         UNet(bad, weights=None)([torch.zeros(1, 12, 12, 12, 4, device=dev), t, ctx])
 
 
+def _random_unet_configs(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        levels = int(rng.integers(1, 4))
+        widths = tuple(int(rng.choice([16, 32, 48, 64, 80, 96, 128])) for _ in range(levels))
+        if len(set(widths)) != len(widths):
+            continue                                   # equal widths break the reference's own skip bookkeeping (:379 vs :391)
+        size = int(rng.choice([4, 8])) << (levels - 1)
+        att = tuple(bool(rng.random() < 0.5) for _ in range(levels))
+        if any(a and ((size >> i) ** 3) % 4 for i, a in enumerate(att)) or ((size >> (levels - 1)) ** 3) % 4:
+            continue
+        kw = dict(widths=widths, has_attention=att, num_res_blocks=int(rng.integers(1, 3)), conditional=bool(rng.random() < 0.7),
+                  first_conv_channels=int(rng.choice([16, 32, 64])), norm=str(rng.choice(["batch", "batch", "group"])))
+        if kw["norm"] == "group" and any(w % 8 for w in widths + (kw["first_conv_channels"],)):
+            continue
+        out.append((size, int(rng.choice([4, 8])), int(rng.integers(1, 4)), str(rng.choice(["h3", "h3", "fp32"])), kw))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_unet_configs(8, 20260103), ids=lambda c: f"s{c[0]}c{c[1]}b{c[2]}{c[3]}_" + "x".join(map(str, c[4]["widths"])))
+def test_unet_random_build_model_arguments(dev, case):
+    """Seeded sweep over build_model arguments against the float64 oracle.  Random weights can make attention ill-conditioned
+    (saturated softmax: the float32 and float64 oracles themselves then differ by 1e-3 and more), so the bar is relative to that
+    conditioning: error <= max(2e-5, 8 x |oracle32 - oracle64|)."""
+    import dm3d_amd
+    from dm3d_amd.unet import UNet
+    from oracle import ref_torch as rt
+    size, ch, B, prec, kw = case
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    cfg = dm3d_amd.UNetConfig(img_size=size, img_channels=ch, **kw)
+    W = dm3d_amd.synthetic_weights(cfg, seed=size + ch)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, size, size, size, ch, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    ctx = torch.randint(0, 2, (B, 1, 1), generator=g)
+    ocfg = rt.UNetConfig(img_size=size, img_channels=ch, **kw)
+    Wt = {k: torch.from_numpy(v) for k, v in W.items()}
+    c = ctx if cfg.conditional else None
+    ref32 = rt.unet_forward(Wt, ocfg, x, t, c)
+    ref64 = rt.unet_forward({k: v.double() for k, v in Wt.items()}, ocfg, x.double(), t, c)
+    eps = UNet(cfg, weights=W, precision=prec)([x.to(dev), t, ctx] if cfg.conditional else [x.to(dev), t])
+    torch.cuda.synchronize()
+    cond = _rel(ref32, ref64)
+    err = _rel(eps, ref64)
+    print(f"err {err:.2e}  conditioning (oracle32 vs oracle64) {cond:.2e}")
+    assert err <= max(2e-5, 8 * cond)
+
+
 def test_generate_matches_golden_trajectory(dev):
     import dm3d_amd
     from dm3d_amd.networks import conditional_dm3d as cdm
