@@ -11,9 +11,11 @@ Contract (one JSON line from rank 0):  python bench.py --gpus N --steps K --warm
     collective ("weak" scaling: B per GPU fixed).
   * roofline: the dominant kernel is the k3/stride-1 Conv3d implicit GEMM (34 launches/step of the main instantiation —
     conv_in/conv_out and the two UpSample convs run other instantiations and are listed under per_kernel_kind);
-    achieved = algorithmic FLOPs (2*27*Cin*Cout*B*Dout^3 per launch) / HIP-event time of those launches,
-    measured live on the launch stream; peak = fp32 MFMA 157.3 TFLOP/s (MI355X_MICROARCH.md) since the kernel uses
-    v_mfma_f32_32x32x2_f32.
+    achieved = algorithmic FLOPs (2*27*Cin*Cout*B*Dout^3 per launch, plus those of a fused 1x1 skip conv) /
+    HIP-event time of those launches, measured live on the launch stream; peak = the dense MFMA peak of the datatype the
+    kernel multiplies in (MI355X_MICROARCH.md): float16 2500 TFLOP/s in the default h3 mode (three v_mfma_f32_16x16x32_f16
+    passes per algorithmic product: executed_mfma_tflops = 3 x achieved is reported beside it), float32 157.3 TFLOP/s with
+    --precision fp32 (v_mfma_f32_32x32x2_f32).  traffic = HBM bytes per launch from the committed rocprofv3 --pmc summary.
   * cpu_baseline: the CPU oracle (PyTorch-CPU restatement of the reference path; TensorFlow is not installed) on the
     host cores, a bounded sample of the same workload (rank 0, N=1 only).
 """
