@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DM3D_LIB") or os.path.join(_HERE, "csrc", "libdm3d_hip.so")     # DM3D_LIB: A/B builds (tools)
 
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
+ABI_VERSION = 104                   # DM3D_VERSION of include/dm3d.h these ctypes mirrors were written against
 PREC_F32, PREC_H3 = 0, 1
 WL_TAP, WL_PAIR = 0, 1
 FMT_F32, FMT_H2 = 0, 1
@@ -136,6 +137,9 @@ def lib() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError if the ABI lost a symbol
             fn.restype, fn.argtypes = res, args
+        if handle.dm3d_version() != ABI_VERSION:
+            raise Dm3dError(f"{LIB_PATH} reports ABI version {handle.dm3d_version()}, these bindings expect {ABI_VERSION}: "
+                            "rebuild the library (descriptor layouts differ between versions)")
         _lib = handle
     return _lib
 

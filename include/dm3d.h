@@ -21,7 +21,8 @@
 extern "C" {
 #endif
 
-#define DM3D_VERSION 100          /* major*100 + minor */
+#define DM3D_VERSION 104          /* major*100 + minor; the descriptor structs grew in 101 (w_layout), 102 (scratch), 103 (skip_*),
+                                     104 (dm3d_attention): a host built against an older header must be rebuilt */
 
 #define DM3D_OK            0
 #define DM3D_EINVAL       -1      /* bad argument (shape, alignment, null pointer) */
