@@ -133,6 +133,11 @@ def lib() -> C.CDLL:
             raise Dm3dError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built. There is no CPU or PyTorch fallback; "
                 "run `python -c 'import __graft_entry__ as g; g.build()'` at the repo root.")
+        # PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64 (same sonames as /opt/rocm's).  Whichever is mapped first
+        # serves the whole process, and if /opt/rocm's came first — this library loaded and initialised HIP before torch was
+        # imported — torch's remaining bundled libraries no longer match it and torch reports "No HIP GPUs are available".
+        # Importing torch here pins the order: one runtime, torch's, for both.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError if the ABI lost a symbol
