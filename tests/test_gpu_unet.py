@@ -177,6 +177,17 @@ def test_unet_random_build_model_arguments(dev, case):
     assert err <= max(2e-5, 8 * cond)
 
 
+def test_graft_entry_build_then_smoke_in_one_process(dev):
+    """The driver's two entry points in a fresh interpreter, in that order.  (With the library loaded — and HIP initialised —
+    before torch was imported, /opt/rocm's runtime shadowed torch's bundled one and torch saw no GPU.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=root, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "smoke: ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_generate_matches_golden_trajectory(dev):
     import dm3d_amd
     from dm3d_amd.networks import conditional_dm3d as cdm
