@@ -324,6 +324,12 @@ class Sampler:
         check(lib().dm3d_ddpm_update(C.byref(desc), st), "ddpm_update")
         check(lib().dm3d_add_i32(self.plan.t_idx.data_ptr(), self.plan.B, -1, st), "add_i32")
 
+    def prepare(self):
+        """Capture the step graph now (setup cost: the first step() otherwise pays for it)."""
+        if self.use_graph and self.graph is None:
+            self.graph = self.model._capture(self)
+        return self
+
     def step(self, noise=None):
         st = torch.cuda.current_stream().cuda_stream
         if noise is not None:

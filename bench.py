@@ -106,6 +106,7 @@ def main():
     model = cdm.DiffusionModel(S, 1024, Cc, None, margs, device=dev, weights=W, precision=args.precision, norm=args.norm)
     smp = model.sampler((B, S, S, S, Cc), context_value=1, seed=parallel.rank_seed(1234, rank),
                         use_graph=not args.no_graph)
+    smp.prepare()                          # graph capture is setup, not a step: --warmup 0 then times replays only
     smp.reset()
     torch.cuda.synchronize()
     log("model prepared; warm-up")
