@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DM3D_LIB") or os.path.join(_HERE, "csrc", "libdm3d_hip.so")     # DM3D_LIB: A/B builds (tools)
 
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
-ABI_VERSION = 104                   # DM3D_VERSION of include/dm3d.h these ctypes mirrors were written against
+ABI_VERSION = 105                   # DM3D_VERSION of include/dm3d.h these ctypes mirrors were written against
 PREC_F32, PREC_H3 = 0, 1
 WL_TAP, WL_PAIR = 0, 1
 FMT_F32, FMT_H2 = 0, 1
@@ -33,6 +33,7 @@ class ConvDesc(C.Structure):
         ("prelu_alpha", _f32p), ("relu_out", C.c_int32), ("transpose", C.c_int32),
         ("pro_batch_stride", C.c_int64), ("w_layout", C.c_int32),
         ("skip_x1", _f32p), ("skip_x2", _f32p), ("skip_c1", C.c_int32), ("skip_c2", C.c_int32), ("skip_wpk", C.c_void_p),
+        ("x1_fmt", C.c_int32), ("out_fmt", C.c_int32), ("post_scale", _f32p), ("post_shift", _f32p),
         ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64),
     ]
 

@@ -277,6 +277,23 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
     a.relu = d->relu; a.res = d->res; a.out = d->out; a.cout = d->cout;
     a.prelu = d->prelu_alpha; a.relu_out = d->relu_out;
     a.scratch = d->scratch; a.scratch_bytes = d->scratch_bytes;
+    DM3D_REQUIRE((d->x1_fmt == DM3D_FMT_F32 || d->x1_fmt == DM3D_FMT_H2) && (d->out_fmt == DM3D_FMT_F32 || d->out_fmt == DM3D_FMT_H2),
+                 "conv: unknown x1_fmt / out_fmt");
+    DM3D_REQUIRE((d->post_scale == nullptr) == (d->post_shift == nullptr), "conv: post_scale and post_shift go together");
+    if (d->x1_fmt == DM3D_FMT_H2 || d->out_fmt == DM3D_FMT_H2 || d->post_scale) {
+        DM3D_REQUIRE(d->precision == DM3D_PREC_H3 && d->ksize == 3 && d->stride == 1 && !d->upsample && !d->transpose && d->cout > 32,
+                     "conv: x1_fmt / out_fmt / post_* need precision H3, ksize 3, stride 1, no upsample / transpose, cout > 32");
+        DM3D_REQUIRE(d->x1_fmt != DM3D_FMT_H2 || (d->c2 == 0 && d->c1 % 16 == 0 && !d->pro_scale),
+                     "conv: an H2 input needs c1 %% 16 == 0, no second input and no prologue");
+        DM3D_REQUIRE(d->out_fmt != DM3D_FMT_H2 || (d->in_d % 4 == 0 && d->in_h % 8 == 0 && d->in_w % 8 == 0 && d->cout % 64 == 0 &&
+                                                  !d->prelu_alpha),
+                     "conv: an H2 output needs extents of whole 4x8x8 bricks and cout %% 64 == 0");
+        DM3D_REQUIRE(!d->post_scale || (d->in_d % 4 == 0 && d->in_h % 8 == 0 && d->in_w % 8 == 0 && d->cout % 64 == 0),
+                     "conv: post_scale needs extents of whole 4x8x8 bricks and cout %% 64 == 0");
+        DM3D_REQUIRE(dm3d_aligned16(d->post_scale) && dm3d_aligned16(d->post_shift), "conv: post_* must be 16-byte aligned");
+        a.x_h2 = d->x1_fmt == DM3D_FMT_H2; a.out_h2 = d->out_fmt == DM3D_FMT_H2;
+        a.post_scale = d->post_scale; a.post_shift = d->post_shift;
+    }
     if (d->skip_wpk) {
         DM3D_REQUIRE(d->precision == DM3D_PREC_H3 && d->ksize == 3 && d->stride == 1 && !d->upsample && !d->transpose && d->cout > 32,
                      "conv: the fused skip conv needs precision H3, ksize 3, stride 1, no upsample / transpose, cout > 32");

@@ -27,6 +27,9 @@ struct ConvArgs {
     int split_atomic;         // ksplit == 2 without scratch: both halves add into the zeroed output (order-independent for two)
     long split_stride;        // ksplit > 1 with scratch: elements between the partial-sum images; out points at image 0
     void* scratch; long scratch_bytes;
+    const float* post_scale; const float* post_shift;   // h3v2: out = silu(out*post_scale[c] + post_shift[c]) after everything else
+    int out_h2;               // h3v2: store the output in DM3D_FMT_H2 (full bricks, cout % 64 == 0 only)
+    int x_h2;                 // h3v2: x1 arrives in DM3D_FMT_H2 (c1 % 16 == 0, no x2, no prologue)
     // h3v2 only: a 1x1 conv over a second (raw, un-normalised) input accumulated into the same tile (ResidualBlock skip path)
     const float* sx1; const float* sx2; int sc1, sc2; const void* swpk; int s_npairs;   // s_npairs = round_up(sc1+sc2, 32) / 32
 };

@@ -28,7 +28,9 @@ __host__ __device__ constexpr int pi_pos(int c) {
 // patch column of MFMA row i (rows 0-3 -> 0, 4-7 -> 2, 8-11 -> 3, 12-15 -> 1); patch row is i & 3
 __device__ __forceinline__ int dx_of_row(int i) { return (0x1320 >> ((i >> 2) * 4)) & 3; }
 
-template <int KS, bool PRO>
+// MODE 0: float32 input as is; 1: float32 input through the fused norm + SiLU prologue; 2: x1 already activated and split
+// (DM3D_FMT_H2, written by the producing conv's epilogue): staging is two 16-byte copies per voxel and no arithmetic
+template <int KS, int MODE>
 __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
     constexpr int TD = 4, TH = 8, TW = 8, CK = 16, NT = 64;
     constexpr int HD = TD - 1 + KS, HH = TH - 1 + KS, HW = TW - 1 + KS, HWP = 12;
@@ -113,11 +115,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
     };
     fetch_w(c_lo * NG);
 
-    constexpr bool pro = PRO;
+    constexpr bool pro = MODE == 1, xh2 = MODE == 2;
     f32x4 raw0[NSLOT], raw1[NSLOT];
     f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
     bool ok0 = false, ok1 = false;
     auto load_halo = [&](int ch) {
+        if (xh2) {                       // record ch of each voxel: hi piece at slot `piece`, lo piece at slot 2 + piece
+            const char* base = reinterpret_cast<const char*>(p.x1) + (size_t)ch * 64 + piece * 16;
+#pragma unroll
+            for (int j = 0; j < NSLOT; ++j) {
+                const char* qp = base + (size_t)(gvox[j] >= 0 ? gvox[j] : 0) * ((size_t)p.c1 * 4);
+                raw0[j] = *reinterpret_cast<const f32x4*>(qp);
+                raw1[j] = *reinterpret_cast<const f32x4*>(qp + 32);
+            }
+            return;
+        }
         const int c0 = ch * CK;
         const float* src;
         int ldc, cb;
@@ -158,7 +170,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
                     v1[e] = dm3d_silu(fmaf(v1[e], sc1[e], sh1[e]));
                 }
             }
-            split8(v0, v1, (in && ok0) ? 65504.0f : 0.0f, (in && ok1) ? 65504.0f : 0.0f, shi[j], slo[j]);
+            if (xh2) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                shi[j] = __builtin_bit_cast(h8, in ? v0 : z);
+                slo[j] = __builtin_bit_cast(h8, in ? v1 : z);
+            } else {
+                split8(v0, v1, (in && ok0) ? 65504.0f : 0.0f, (in && ok1) ? 65504.0f : 0.0f, shi[j], slo[j]);
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -363,6 +381,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
             float add = p.bias ? p.bias[n] : 0.0f;
             if (p.vec) add += p.vec[(size_t)vrow * p.vec_ld + n];
             if (!lead) add = 0.0f;
+            const float ps = p.post_scale ? p.post_scale[n] : 1.0f, pt = p.post_scale ? p.post_shift[n] : 0.0f;
+            // DM3D_FMT_H2 position of channel n inside its voxel's row (see dm3d_gemm_h3.hip): lanes n and n^1 exchange halves
+            const int h2col = (n >> 4) * 64 + ((n >> 3) & 1) * 16 + ((n & 7) >> 1) * 4 + (n & 1) * 32 - n * 4;
 #pragma unroll
             for (int pi = 0; pi < 4; ++pi) {
                 const int base = (((oy0 + 4 * (pi >> 1)) * p.os + ooy) * p.fw + (ox0 + 4 * (pi & 1) + dxl) * p.os + oox) * p.cout + n;
@@ -374,7 +395,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
                     if (prz) { const float al = prz[o]; v = v > 0.0f ? v : al * v; }
                     if (resz) v += rv[ni][pi][r];
                     if (p.relu_out) v = fmaxf(v, 0.0f);
-                    if (split) unsafeAtomicAdd(outz + o, v); else outz[o] = v;
+                    if (p.post_scale) v = dm3d_silu(fmaf(v, ps, pt));                 // the consumer's norm + SiLU, applied once here
+                    if (p.out_h2) {
+                        const unsigned int mine = split1_bits(v);
+                        const unsigned int oth = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, false);   // lane ^ 1
+                        const unsigned int word = (n & 1) ? ((oth >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (oth << 16));
+                        *reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(outz) + (size_t)o * 4 + h2col) = word;
+                    } else if (split) {
+                        unsafeAtomicAdd(outz + o, v);
+                    } else {
+                        outz[o] = v;
+                    }
                 }
             }
         }
@@ -456,7 +487,7 @@ __global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, lo
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[n4 * 4 + threadIdx.x] = 0.f;
 }
 
-template <int KS, bool PRO>
+template <int KS, int MODE>
 int launch_v2(ConvArgs& a, hipStream_t st) {
     constexpr int HREC = (3 + KS) * (7 + KS) * 12;
     constexpr size_t lds = (size_t)(HREC * REC + 2 * 4 * 64 * REC) * sizeof(_Float16);
@@ -466,14 +497,14 @@ int launch_v2(ConvArgs& a, hipStream_t st) {
     a.bw = (a.ow + 7) / 8;
     static bool attr_set = false;
     if (!attr_set) {
-        DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3v2<KS, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3v2<KS, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     // Small grids (the 8^3 level at B = 32 has 64 bricks x 4 channel tiles = one workgroup per CU, i.e. one wave per SIMD with
     // nothing to hide its barriers and LDS latency behind: in-kernel stamps showed 58 % MFMA occupancy inside the tap loop there;
     // at B = 1 that level has 8 workgroups for 256 CUs) split the Cin chunks over several workgroups per brick.
     const bool with_scratch = a.scratch != nullptr;
-    a.ksplit = dm3d_conv_h3v2_ksplit(a, with_scratch);
+    a.ksplit = (a.out_h2 || a.post_scale) ? 1 : dm3d_conv_h3v2_ksplit(a, with_scratch);     // the fused output forms live in the plain epilogue
     const size_t out_elems = (size_t)a.batch * a.fd * a.fh * a.fw * a.cout;
     a.split_atomic = 0;
     a.split_stride = 0;
@@ -496,7 +527,7 @@ int launch_v2(ConvArgs& a, hipStream_t st) {
         k.bias = nullptr; k.vec = nullptr; k.res = nullptr; k.relu = 0; k.prelu = nullptr; k.relu_out = 0;
     }
     dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64 * a.ksplit), a.parity ? 8u : 1u);
-    hipLaunchKernelGGL((conv3d_igemm_h3v2<KS, PRO>), grid, dim3(256), lds, st, k);
+    hipLaunchKernelGGL((conv3d_igemm_h3v2<KS, MODE>), grid, dim3(256), lds, st, k);
     int rc = dm3d_launch_check("conv3d_igemm_h3v2");
     if (rc || !(a.ksplit > 1 && with_scratch && !atomic2)) return rc;
     const long n4 = (long)(out_elems / 4);                    // cout % 4 == 0 is not required of cout: fall back to scalar lanes
@@ -609,8 +640,9 @@ int dm3d_conv_h3v2_ksplit(const ConvArgs& a, bool with_scratch) {
 }
 
 int dm3d_conv_launch_h3v2(ConvArgs& a, int which, hipStream_t st) {
-    if (which == DM3D_CONV_UP) return a.pscale ? launch_v2<2, true>(a, st) : launch_v2<2, false>(a, st);
-    return a.pscale ? launch_v2<3, true>(a, st) : launch_v2<3, false>(a, st);
+    if (which == DM3D_CONV_UP) return a.pscale ? launch_v2<2, 1>(a, st) : launch_v2<2, 0>(a, st);
+    if (a.x_h2) return launch_v2<3, 2>(a, st);
+    return a.pscale ? launch_v2<3, 1>(a, st) : launch_v2<3, 0>(a, st);
 }
 
 int64_t dm3d_h3v2_image_bytes(int taps, int cin, int cout) {

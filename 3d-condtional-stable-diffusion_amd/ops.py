@@ -120,9 +120,11 @@ def pack_weights_convt(kernel: torch.Tensor, h3: bool = False):
 
 def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False, pro_scale=None, pro_shift=None,
            vec=None, vec_idx=None, relu=False, res=None, precision=_lib.PREC_F32, w_exp=0, prelu_alpha=None,
-           relu_out=False, transpose=False, skip=None) -> torch.Tensor:
+           relu_out=False, transpose=False, skip=None, x1_h2_channels=None, out_h2=False, post=None) -> torch.Tensor:
     """Conv3D(padding="same") on NDHWC with the fused prologue / concat / upsample / epilogue of dm3d_conv3d_ndhwc.
-    ``skip=(sx1, sx2_or_None, skip_wpk)``: also accumulate Conv3D(cout, 1) of the raw concat(sx1, sx2) (H3, k3, stride 1)."""
+    ``skip=(sx1, sx2_or_None, skip_wpk)``: also accumulate Conv3D(cout, 1) of the raw concat(sx1, sx2) (H3, k3, stride 1).
+    ``post=(scale, shift)``: out = silu(out*scale[c] + shift[c]) at the very end; ``out_h2``: store DM3D_FMT_H2;
+    ``x1_h2_channels=c``: x1 is a DM3D_FMT_H2 buffer of c logical channels (as written by ``out_h2``)."""
     _f32c(x1, "x1")
     if x1.dim() != 5:
         raise ValueError("x1 must be [B,D,H,W,C]")
@@ -153,6 +155,12 @@ def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False
     if prelu_alpha is not None and tuple(prelu_alpha.shape) != (od, oh, ow, cout):
         raise ValueError("prelu_alpha must be [out_d, out_h, out_w, cout]")
     d.prelu_alpha, d.relu_out, d.transpose = _p(prelu_alpha), int(bool(relu_out)), int(bool(transpose))
+    if x1_h2_channels is not None:
+        d.x1_fmt = _lib.FMT_H2
+    if out_h2:
+        d.out_fmt = _lib.FMT_H2
+    if post is not None:
+        d.post_scale, d.post_shift = post[0].data_ptr(), post[1].data_ptr()
     if skip is not None:
         sx1, sx2, swpk = skip
         _f32c(sx1, "skip x1")

@@ -71,6 +71,7 @@ class UNet:
             raise ValueError("precision must be 'fp32' or 'h3'")
         self.precision = precision
         self.fuse_skip = os.environ.get("DM3D_FUSE_SKIP", "1") != "0"      # A/B switch: ResidualBlock 1x1 skip conv inside conv2's launch
+        self.h2_handoff = os.environ.get("DM3D_H2_HANDOFF", "1") != "0"    # A/B switch: conv1 -> conv2 hand-off in DM3D_FMT_H2
         self.cfg = cfg
         self.blocks, self.spec = walk(cfg)
         self.device = torch.device(device)
@@ -427,7 +428,7 @@ class Plan:
         return (scale, shift), ct
 
     def _conv(self, w: _Conv, x1, out, edge_in, x2=None, c1=None, c2=0, upsample=0, stride=1, pro=None, vec_off=None,
-              relu=0, res=None, pro_bstride=0, skip=None):
+              relu=0, res=None, pro_bstride=0, skip=None, post=None, out_h2=False, x1_h2=False):
         d = ConvDesc()
         d.x1, d.x2 = _ptr(x1), _ptr(x2)
         d.c1, d.c2 = (c1 if c1 is not None else w.cin), c2
@@ -446,6 +447,11 @@ class Plan:
         d.relu, d.res, d.out, d.cout = relu, _ptr(res), _ptr(out), w.cout
         if d.c1 + d.c2 != w.cin:
             raise ValueError(f"conv input channels {d.c1}+{d.c2} != weight cin {w.cin}")
+        if post is not None:
+            d.post_scale, d.post_shift = _ptr(post[0]), _ptr(post[1])
+            self._keep += [post[0], post[1]]
+        d.out_fmt = _lib.FMT_H2 if out_h2 else _lib.FMT_F32
+        d.x1_fmt = _lib.FMT_H2 if x1_h2 else _lib.FMT_F32
         skip_flops = 0.0
         if skip is not None:
             sx1, sx2, sc1, sc2, simg = skip
@@ -537,8 +543,19 @@ class Plan:
             res = x1
         hmid = self._buf(B, edge, edge, edge, w)
         pro, bs = self._norm(f"{n}.norm1", x1, c1, edge, x2, c2)
-        self._conv(P[f"{n}.conv1"], x1, hmid, edge, x2=x2, c1=c1, c2=c2, pro=pro, pro_bstride=bs, vec_off=self.net.temb_off[n])
         out = self._buf(B, edge, edge, edge, w)
+        # conv1's output has one consumer: with folded BatchNormalization it leaves conv1 already normalised, activated and split
+        # (DM3D_FMT_H2) and conv2 stages plain copies.  Needs the 16x16x32 kernel, whole bricks, and a grid that would not
+        # rather split its Cin range (the fused output forms live in the unsplit epilogue).
+        handoff = (self.net.h2_handoff and self.net.cfg.norm == "batch" and self.net.precision == "h3" and edge % 8 == 0
+                   and w % 64 == 0 and B * (edge ** 3 // 256) * (w // 64) > 256
+                   and lib().dm3d_conv_weight_layout(3, 1, 0, 0, w) == _lib.WL_PAIR)
+        if handoff:
+            self._conv(P[f"{n}.conv1"], x1, hmid, edge, x2=x2, c1=c1, c2=c2, pro=pro, pro_bstride=bs, vec_off=self.net.temb_off[n],
+                       post=P[f"{n}.norm2"], out_h2=True)
+            self._conv(P[f"{n}.conv2"], hmid, out, edge, res=res, skip=skip, x1_h2=True)
+            return out
+        self._conv(P[f"{n}.conv1"], x1, hmid, edge, x2=x2, c1=c1, c2=c2, pro=pro, pro_bstride=bs, vec_off=self.net.temb_off[n])
         pro, bs = self._norm(f"{n}.norm2", hmid, w, edge)
         self._conv(P[f"{n}.conv2"], hmid, out, edge, pro=pro, pro_bstride=bs, res=res, skip=skip)
         return out

@@ -21,8 +21,8 @@
 extern "C" {
 #endif
 
-#define DM3D_VERSION 104          /* major*100 + minor; the descriptor structs grew in 101 (w_layout), 102 (scratch), 103 (skip_*),
-                                     104 (dm3d_attention): a host built against an older header must be rebuilt */
+#define DM3D_VERSION 105          /* major*100 + minor; the descriptor structs grew in 101 (w_layout), 102 (scratch), 103 (skip_*),
+                                     104 (dm3d_attention), 105 (x1_fmt / out_fmt / post_*): a host built against an older header must be rebuilt */
 
 #define DM3D_OK            0
 #define DM3D_EINVAL       -1      /* bad argument (shape, alignment, null pointer) */
@@ -158,6 +158,13 @@ typedef struct dm3d_conv_desc {
        residual read of its own.  skip_wpk from dm3d_pack_weights_skip_h3p, packed with THIS conv's w_exp; add the skip bias into
        bias.  All NULL / 0 when unused. */
     const float* skip_x1; const float* skip_x2; int32_t skip_c1, skip_c2; const void* skip_wpk;
+    /* A tensor with exactly one consumer (ResidualBlock: conv1 -> BatchNormalization -> swish -> conv2, :255-267) can skip the
+       float32 round trip: the producer applies the consumer's folded norm + swish once per element and stores DM3D_FMT_H2
+       (post_scale / post_shift per output channel, out_fmt = DM3D_FMT_H2), the consumer (x1_fmt = DM3D_FMT_H2, no x2, no
+       prologue) stages plain copies.  k3 / stride 1 / DM3D_WL_PAIR convs only; an H2 output additionally needs extents that
+       are whole 4x8x8 bricks and cout % 64 == 0.  Zero / NULL when unused. */
+    int32_t x1_fmt, out_fmt;
+    const float* post_scale; const float* post_shift;
     void* scratch;              /* optional workspace (16-byte aligned) of scratch_bytes bytes, or NULL.  With it, convs whose grid
                                    would leave most of the chip idle (small batches, the 8^3 level) split their Cin range over up
                                    to 16 workgroups per brick; the partial sums meet in a fixed order in a second launch that also

@@ -179,6 +179,42 @@ def test_conv3d_fused_skip(dev, case):
     assert err < 2e-5, f"{name}: rel err {err:.3e}"
 
 
+@pytest.mark.parametrize("dims,cm,cout", [((8, 8, 8), 64, 64), ((4, 16, 8), 32, 128)], ids=["cube", "noncubic_cout128"])
+def test_conv3d_h2_handoff_between_two_convs(dev, dims, cm, cout):
+    """ResidualBlock interior (conditional_dm3d.py:255-267): conv1 applies conv2's folded norm + swish in its epilogue and stores
+    DM3D_FMT_H2; conv2 reads that format with no prologue.  Both halves against float64, and the pair against the unfused pair."""
+    from dm3d_amd import ops, _lib
+    g = torch.Generator().manual_seed(5)
+    B, (D, H, W) = 2, dims
+    x = torch.randn(B, D, H, W, cm, generator=g)
+    k1 = torch.randn(3, 3, 3, cm, cout, generator=g) / math.sqrt(cm * 27)
+    k2 = torch.randn(3, 3, 3, cout, cout, generator=g) / math.sqrt(cout * 27)
+    b1, b2 = torch.randn(cout, generator=g), torch.randn(cout, generator=g)
+    vec = torch.randn(B, cout, generator=g)
+    s2, t2 = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(B, D, H, W, cout, generator=g)
+    from oracle import ref_torch as rt
+    h_ref = _conv_ref(x, k1, b1, vec=vec)
+    a_ref = rt._swish(h_ref * s2.double() + t2.double())
+    y_ref = _conv_ref(a_ref, k2, b2, res=res)
+    c = lambda t: t.to(dev).contiguous()
+    w1, e1 = ops.pack_weights_h3(c(k1))
+    w2, e2 = ops.pack_weights_h3(c(k2))
+    H3 = dict(precision=_lib.PREC_H3)
+    a_h2 = ops.conv3d(c(x), w1, cout, 3, bias=c(b1), vec=c(vec), w_exp=e1, post=(c(s2), c(t2)), out_h2=True, **H3)
+    a_dec = ops.h2_to_f32(a_h2.reshape(-1, cout), cout).reshape(B, D, H, W, cout)
+    assert _rel(a_dec, a_ref) < 2e-5
+    y = ops.conv3d(a_h2, w2, cout, 3, bias=c(b2), res=c(res), w_exp=e2, x1_h2_channels=cout, **H3)
+    assert _rel(y, y_ref) < 2e-5
+    # same pair the old way: float32 hand-off, norm + swish in conv2's prologue
+    h = ops.conv3d(c(x), w1, cout, 3, bias=c(b1), vec=c(vec), w_exp=e1, **H3)
+    y_old = ops.conv3d(h, w2, cout, 3, bias=c(b2), res=c(res), w_exp=e2, pro_scale=c(s2), pro_shift=c(t2), **H3)
+    torch.cuda.synchronize()
+    assert float((y - y_old).abs().max() / y_old.abs().max()) < 2e-6
+    with pytest.raises(Exception):                          # ragged extent: the H2 output form is refused, not silently wrong
+        ops.conv3d(c(x)[:, :3], w1, cout, 3, w_exp=e1, out_h2=True, **H3)
+
+
 def test_conv3d_h3_tap_layout_arm(dev):
     """DM3D_CONV_PAIR=0 (read when the library is loaded) routes every H3 conv to the 32x32x16 kernel with the DM3D_WL_TAP weight
     layout: the A/B arm of the 16x16x32 kernel must stay correct.  One child interpreter, same parity cases."""
