@@ -469,6 +469,8 @@ class Plan:
             kind = "conv_up"            # 8 parity 2x2x2 convs
         elif w.cout <= 32 and w.precision == _lib.PREC_H3:
             kind = "conv_k3s1_n32"      # conv_in / conv_out: one 32-column tile
+        elif x1_h2:
+            kind = "conv_k3s1_h2in"     # kernel MODE 2: pre-activated DM3D_FMT_H2 input (ResidualBlock conv2 behind a hand-off)
         else:
             kind = "conv_k3s1"
         self.ops.append((lib().dm3d_conv3d_ndhwc, (C.byref(d),), kind,

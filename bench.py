@@ -9,7 +9,8 @@ Contract (one JSON line from rank 0):  python bench.py --gpus N --steps K --warm
     (x_T ~ N(0,1), t = T-1, T-2, ...), nothing is skipped inside a step.
   * N>1: one process per GPU (torchrun), rank 0's weights broadcast once over RCCL, batch sharded, no per-step
     collective ("weak" scaling: B per GPU fixed).
-  * roofline: the dominant kernel is the k3/stride-1 Conv3d implicit GEMM (34 launches/step of the main instantiation —
+  * roofline: the dominant kernel is the k3/stride-1 Conv3d implicit GEMM (24 launches/step of the main instantiation, 10 more of
+    its H2-input twin —
     conv_in/conv_out and the two UpSample convs run other instantiations and are listed under per_kernel_kind);
     achieved = algorithmic FLOPs (2*27*Cin*Cout*B*Dout^3 per launch, plus those of a fused 1x1 skip conv) /
     HIP-event time of those launches, measured live on the launch stream; peak = the dense MFMA peak of the datatype the
@@ -161,8 +162,9 @@ def main():
         n, ms, fl, by, ex = acc["conv_k3s1"]
         achieved = fl / (ms * 1e-3) / 1e12
         if args.precision == "h3":
-            kname = ("conv3d_igemm_h3v2<3, true> (k3 stride-1 Conv3d with the fused norm+SiLU prologue; float16 hi+lo split, 3 x "
-                     "v_mfma_f32_16x16x32_f16 per algorithmic product, fp32 accumulate)")
+            kname = ("conv3d_igemm_h3v2<3, 1> (k3 stride-1 Conv3d with the fused norm+SiLU prologue; float16 hi+lo split, 3 x "
+                     "v_mfma_f32_16x16x32_f16 per algorithmic product, fp32 accumulate; its MODE-2 twin that reads pre-activated "
+                     "DM3D_FMT_H2 input is listed as conv_k3s1_h2in)")
             peak, passes = PEAK_F16_MFMA_TFLOPS, 3
         else:
             kname, peak, passes = "conv3d_igemm_f32<4, 8, 8, 1, 3, 4, 1> (k3 stride-1 Conv3d, v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS, 1
@@ -185,7 +187,7 @@ def main():
         try:
             import csv
             path = os.path.join(ROOT, "profiles", "r01_h3_pmc_hbm.csv" if args.precision == "h3" else "r01_fp32_pmc_hbm.csv")
-            want = "conv3d_igemm_h3v2<3, true>" if args.precision == "h3" else "conv3d_igemm_f32<4, 8, 8, 1, 3, 4, 1>"
+            want = "conv3d_igemm_h3v2<3, 1>" if args.precision == "h3" else "conv3d_igemm_f32<4, 8, 8, 1, 3, 4, 1>"
             for row in csv.reader(l for l in open(path) if not l.startswith("#")):
                 if row and row[0] == want:
                     roofline["traffic"] = float(row[4]) * 1e6
