@@ -55,12 +55,16 @@ s=must(s, """            if (!last_group) __syncthreads();""","""            if 
             if (last_group && ch - c_lo < 12) STAMP(3 + 2 * (ch - c_lo));""")
 s=must(s, """    // ---- epilogue.  Accumulator register r of tile""","""    STAMP(28);
     // ---- epilogue.  Accumulator register r of tile""")
-s=must(s, """                    if (split) unsafeAtomicAdd(outz + o, v); else outz[o] = v;
+s=must(s, """                    } else {
+                        outz[o] = v;
+                    }
                 }
             }
         }
         return;
-    }""","""                    if (split) unsafeAtomicAdd(outz + o, v); else outz[o] = v;
+    }""","""                    } else {
+                        outz[o] = v;
+                    }
                 }
             }
         }
