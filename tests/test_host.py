@@ -67,6 +67,18 @@ int main(void) {
     assert "conv" in f[5]
 
 
+def test_stamp_variant_tool_still_patches_the_kernels(built_library):
+    """tools/mk_stamp_variants.py edits the kernel sources by exact-match patches (it asserts every one): keep it in step."""
+    import shutil
+    import sys
+    vdir = os.path.join(os.path.dirname(built_library), "variants")
+    try:
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mk_stamp_variants.py")], check=True, capture_output=True, cwd=ROOT)
+        assert os.path.exists(os.path.join(vdir, "cst.so")) and os.path.exists(os.path.join(vdir, "gst.so"))
+    finally:
+        shutil.rmtree(vdir, ignore_errors=True)
+
+
 def test_argument_validation_needs_no_gpu(built_library):
     """Bad descriptors are rejected before any launch, with a readable message."""
     from dm3d_amd import _lib
