@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DM3D_LIB") or os.path.join(_HERE, "csrc", "libdm3d_hip.so")     # DM3D_LIB: A/B builds (tools)
 
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
-ABI_VERSION = 105                   # DM3D_VERSION of include/dm3d.h these ctypes mirrors were written against
+ABI_VERSION = 106                   # DM3D_VERSION of include/dm3d.h these ctypes mirrors were written against
 PREC_F32, PREC_H3 = 0, 1
 WL_TAP, WL_PAIR = 0, 1
 FMT_F32, FMT_H2 = 0, 1
@@ -35,6 +35,7 @@ class ConvDesc(C.Structure):
         ("skip_x1", _f32p), ("skip_x2", _f32p), ("skip_c1", C.c_int32), ("skip_c2", C.c_int32), ("skip_wpk", C.c_void_p),
         ("x1_fmt", C.c_int32), ("out_fmt", C.c_int32), ("post_scale", _f32p), ("post_shift", _f32p),
         ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64),
+        ("range_flag", C.c_void_p), ("range_limit", C.c_float),
     ]
 
 
@@ -47,7 +48,7 @@ class GemmDesc(C.Structure):
         ("alpha", C.c_float), ("bias", _f32p), ("bias_along_m", C.c_int32), ("act", C.c_int32),
         ("res", _f32p), ("ldr", C.c_int64), ("stride_r", C.c_int64),
         ("precision", C.c_int32), ("a_fmt", C.c_int32), ("b_fmt", C.c_int32), ("out_fmt", C.c_int32),
-        ("res2", _f32p),
+        ("res2", _f32p), ("range_flag", C.c_void_p), ("range_limit", C.c_float),
     ]
 
 
@@ -62,13 +63,21 @@ class AttentionDesc(C.Structure):
     ]
 
 
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("a", _f32p), ("g", _f32p), ("dw", _f32p),
+        ("batch", C.c_int32), ("in_d", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
+        ("ksize", C.c_int32), ("per_item_output", C.c_int32), ("stride_a", C.c_int64), ("stride_g", C.c_int64), ("stride_dw", C.c_int64),
+    ]
+
+
 class DdpmDesc(C.Structure):
     _fields_ = [
         ("x", _f32p), ("eps", _f32p), ("noise", _f32p), ("batch", C.c_int32), ("per_sample", C.c_int64),
         ("t", _i32p), ("timesteps", C.c_int32),
         ("beta", _f32p), ("sqrt_alpha", _f32p), ("alpha_bar", _f32p), ("alpha_bar_prev", _f32p),
         ("sqrt_alpha_bar", _f32p), ("sqrt_alpha_bar_prev", _f32p), ("sqrt_one_minus_alpha_bar", _f32p),
-        ("seed", C.c_uint64), ("mode", C.c_int32), ("mean_out", _f32p), ("var_out", _f32p),
+        ("seed", C.c_uint64), ("mode", C.c_int32), ("mean_out", _f32p), ("var_out", _f32p), ("seed_dev", C.c_void_p),
     ]
 
 
@@ -109,10 +118,32 @@ SIGNATURES = {
     "dm3d_softmax_rows": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]),
     "dm3d_affine_act": (C.c_int, [_f32p, _f32p, C.c_int64, C.c_int32, _f32p, _f32p, C.c_int32, C.c_void_p]),
     "dm3d_ddpm_update": (C.c_int, [C.POINTER(DdpmDesc), C.c_void_p]),
+    "dm3d_range_check": (C.c_int, [_f32p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
     "dm3d_add_i32": (C.c_int, [_i32p, C.c_int32, C.c_int32, C.c_void_p]),
     "dm3d_randn": (C.c_int, [_f32p, C.c_int64, C.c_uint64, C.c_uint32, C.c_void_p]),
     "dm3d_gather_rows": (C.c_int, [_f32p, C.c_int32, _i32p, _f32p, C.c_int32, C.c_int32, C.c_void_p]),
     "dm3d_vq_assign": (C.c_int, [_f32p, C.c_int64, C.c_int32, _f32p, C.c_int32, _f32p, _i32p, C.c_void_p]),
+    "dm3d_batchnorm_finalize": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_float] + [_f32p] * 8 + [C.c_float, C.c_int32, C.c_void_p]),
+    "dm3d_affine_act_cat": (C.c_int, [_f32p, C.c_int32, _f32p, C.c_int32, C.c_int64, _f32p, _f32p, C.c_int32, _f32p, C.c_void_p]),
+    "dm3d_bn_act_bwd": (C.c_int, [_f32p, _f32p, C.c_int32, _f32p, C.c_int32, C.c_int64, _f32p, _f32p, _f32p, _f32p, C.c_int32, C.c_void_p,
+                                   _f32p, _f32p, _f32p, _f32p, C.c_void_p]),
+    "dm3d_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
+    "dm3d_colsum": (C.c_int, [_f32p, C.c_int64, C.c_int64, C.c_int32, _f32p, C.c_int64, C.c_void_p]),
+    "dm3d_flip_transpose": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
+    "dm3d_layernorm_bwd": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_float, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_void_p]),
+    "dm3d_softmax_bwd": (C.c_int, [_f32p, _f32p, C.c_int64, C.c_int32, C.c_int64, C.c_float, C.c_void_p]),
+    "dm3d_act_bwd": (C.c_int, [_f32p, _f32p, _f32p, C.c_int64, C.c_int32, C.c_void_p]),
+    "dm3d_axpy": (C.c_int, [_f32p, _f32p, C.c_int64, C.c_float, C.c_void_p]),
+    "dm3d_fill": (C.c_int, [_f32p, C.c_int64, C.c_float, C.c_void_p]),
+    "dm3d_transpose": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _f32p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+    "dm3d_copy_cols": (C.c_int, [_f32p, C.c_int64, C.c_int32, _f32p, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "dm3d_upsample2": (C.c_int, [_f32p, _f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dm3d_sumpool2_add": (C.c_int, [_f32p, _f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dm3d_dilate2": (C.c_int, [_f32p, _f32p] + [C.c_int32] * 11 + [C.c_void_p]),
+    "dm3d_scatter_add_rows": (C.c_int, [_f32p, _i32p, C.c_int32, C.c_int32, _f32p, C.c_int32, C.c_void_p]),
+    "dm3d_q_sample": (C.c_int, [_f32p, _f32p, _i32p, _f32p, _f32p, C.c_int32, _f32p, C.c_int32, C.c_int64, C.c_void_p]),
+    "dm3d_mse_loss_grad": (C.c_int, [_f32p, _f32p, C.c_int64, C.c_double, C.c_void_p, _f32p, C.c_void_p]),
+    "dm3d_adam": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "dm3d_graph_begin": (C.c_int, [C.c_void_p]),
     "dm3d_graph_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "dm3d_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -29,6 +29,14 @@ static inline int dm3d_launch_check(const char* what) {
 static inline bool dm3d_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int64_t dm3d_round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+// H3 range guard (include/dm3d.h, range_flag): running max |value| of what an epilogue stores.  -DDM3D_NO_RANGE_GUARD builds the
+// A/B variant without it (tools/mk_variant.sh).
+#ifdef DM3D_NO_RANGE_GUARD
+#define DM3D_AMAX(a, v) ((void)(v))
+#else
+#define DM3D_AMAX(a, v) ((a) = fmaxf((a), fabsf(v)))
+#endif
+
 // ---- device helpers -----------------------------------------------------------------------------------------------
 __device__ __forceinline__ float dm3d_silu(float y) {
     // y * sigmoid(y) as mul, v_exp_f32, add, v_rcp_f32, mul (both ~1 ulp, far inside the 1e-3 parity budget).

@@ -277,6 +277,7 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
     a.relu = d->relu; a.res = d->res; a.out = d->out; a.cout = d->cout;
     a.prelu = d->prelu_alpha; a.relu_out = d->relu_out;
     a.scratch = d->scratch; a.scratch_bytes = d->scratch_bytes;
+    a.range_flag = d->range_flag; a.range_limit = d->range_limit > 0.0f ? d->range_limit : 65504.0f;
     DM3D_REQUIRE((d->x1_fmt == DM3D_FMT_F32 || d->x1_fmt == DM3D_FMT_H2) && (d->out_fmt == DM3D_FMT_F32 || d->out_fmt == DM3D_FMT_H2),
                  "conv: unknown x1_fmt / out_fmt");
     DM3D_REQUIRE((d->post_scale == nullptr) == (d->post_shift == nullptr), "conv: post_scale and post_shift go together");

@@ -32,6 +32,7 @@ struct ConvArgs {
     int x_h2;                 // h3v2: x1 arrives in DM3D_FMT_H2 (c1 % 16 == 0, no x2, no prologue)
     // h3v2 only: a 1x1 conv over a second (raw, un-normalised) input accumulated into the same tile (ResidualBlock skip path)
     const float* sx1; const float* sx2; int sc1, sc2; const void* swpk; int s_npairs;   // s_npairs = round_up(sc1+sc2, 32) / 32
+    int* range_flag; float range_limit;      // H3 range guard (include/dm3d.h): *range_flag = 1 if any |output| > range_limit
 };
 
 // which tile configuration a (ksize, stride) pair uses

@@ -281,6 +281,7 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
     const int n0 = ntile * NT;
     const bool full = oz0 + TD <= p.od && oy0 + TH <= p.oh && ox0 + TW <= p.ow && n0 + NT <= p.cout;
     const int cstep = p.os * p.cout;                            // distance between x-neighbours of the brick in the output
+    float amax = 0.0f;                                          // range guard (include/dm3d.h): largest |value| this lane stores
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
         const int r0 = wm * (TM / WM) + mr * 32;
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
                     if (prz) { const float al = prz[o]; v = v > 0.0f ? v : al * v; }
                     if (resz) v += rv[r];
                     if (p.relu_out) v = fmaxf(v, 0.0f);
+                    DM3D_AMAX(amax, v);
                     outz[o] = v;
                 }
             } else {
@@ -334,11 +336,12 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
                     if (prz) { const float al = prz[o]; v = v > 0.0f ? v : al * v; }
                     if (resz) v += resz[o];
                     if (p.relu_out) v = fmaxf(v, 0.0f);
-                    if (ok) outz[o] = v;
+                    if (ok) { DM3D_AMAX(amax, v); outz[o] = v; }
                 }
             }
         }
     }
+    if (p.range_flag && amax > p.range_limit) *p.range_flag = 1;
 }
 
 template <int TD, int TH, int TW, int S, int KS, int WM, int WN, int MINW, int NRA = 0>

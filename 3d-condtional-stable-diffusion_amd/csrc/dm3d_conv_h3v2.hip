@@ -361,6 +361,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
     const float* prz = p.prelu ? p.prelu + (zbase - (size_t)b * p.fd * p.fh * p.fw * p.cout) : nullptr;
     const int dxl = dx_of_row(4 * g4);
     const int ystep = p.os * p.fw * p.cout;                              // one brick row further in the output
+    float amax = 0.0f;                                                   // range guard: largest |value| this lane stores
+    const float rlim = split ? 0.5f * p.range_limit : p.range_limit;     // two atomic halves: either may carry half the sum
     if (full) {
         // full brick (the common case): all 64 residual values of this lane are requested before the first one is used, so the
         // epilogue pays one memory latency instead of sixteen
@@ -396,6 +398,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
                     if (resz) v += rv[ni][pi][r];
                     if (p.relu_out) v = fmaxf(v, 0.0f);
                     if (p.post_scale) v = dm3d_silu(fmaf(v, ps, pt));                 // the consumer's norm + SiLU, applied once here
+                    DM3D_AMAX(amax, v);
                     if (p.out_h2) {
                         const unsigned int mine = split1_bits(v);
                         const unsigned int oth = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, false);   // lane ^ 1
@@ -409,6 +412,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
                 }
             }
         }
+        if (p.range_flag && amax > rlim) *p.range_flag = 1;
         return;
     }
 #pragma unroll
@@ -432,10 +436,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
                 if (prz) { const float al = prz[o]; v = v > 0.0f ? v : al * v; }
                 if (resz) v += resz[o];
                 if (p.relu_out) v = fmaxf(v, 0.0f);
-                if (ok) { if (split) unsafeAtomicAdd(outz + o, v); else outz[o] = v; }
+                if (ok) { DM3D_AMAX(amax, v); if (split) unsafeAtomicAdd(outz + o, v); else outz[o] = v; }
             }
         }
     }
+    if (p.range_flag && amax > rlim) *p.range_flag = 1;
 }
 
 // out = epilogue(sum of the ksplit partial-sum images, added in image order): + bias[c] + vec[row(b)][c] -> ReLU -> PReLU -> + res ->
@@ -444,9 +449,10 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const float* __r
                                                                 int cout, long per_sample, const float* __restrict__ bias,
                                                                 const float* __restrict__ vec, const int* __restrict__ vec_idx, int vec_ld,
                                                                 int relu, const float* __restrict__ prelu, const float* __restrict__ res,
-                                                                int relu_out, int vec4) {
+                                                                int relu_out, int vec4, int* range_flag, float range_limit) {
     const int w = vec4 ? 4 : 1;
     const long total = stride / w;
+    float amax = 0.0f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long e0 = i * w;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -473,9 +479,11 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const float* __r
             if (prelu) { const float al = prelu[e32 % (unsigned)per_sample + j]; x = x > 0.0f ? x : al * x; }
             if (res) x += res[e0 + j];
             if (relu_out) x = fmaxf(x, 0.0f);
+            DM3D_AMAX(amax, x);
             out[e0 + j] = x;
         }
     }
+    if (range_flag && amax > range_limit) *range_flag = 1;
 }
 
 // Zero fill as a kernel of our own: a hipMemsetAsync captured into the per-step HIP graph becomes a memset node, and replays of
@@ -525,6 +533,7 @@ int launch_v2(ConvArgs& a, hipStream_t st) {
         k.out = static_cast<float*>(a.scratch);
         k.split_stride = (long)out_elems;
         k.bias = nullptr; k.vec = nullptr; k.res = nullptr; k.relu = 0; k.prelu = nullptr; k.relu_out = 0;
+        k.range_flag = nullptr;                               // the reduce launch checks the finished values
     }
     dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64 * a.ksplit), a.parity ? 8u : 1u);
     hipLaunchKernelGGL((conv3d_igemm_h3v2<KS, MODE>), grid, dim3(256), lds, st, k);
@@ -537,7 +546,7 @@ int launch_v2(ConvArgs& a, hipStream_t st) {
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(conv_split_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, static_cast<const float*>(a.scratch), a.ksplit,
                        (long)out_elems, a.out, a.cout, (long)a.fd * a.fh * a.fw * a.cout, a.bias, a.vec, a.vec_idx, a.vec_ld, a.relu, a.prelu,
-                       a.res, a.relu_out, vec4 ? 1 : 0);
+                       a.res, a.relu_out, vec4 ? 1 : 0, a.range_flag, a.range_limit);
     return dm3d_launch_check("conv_split_reduce_kernel");
 }
 

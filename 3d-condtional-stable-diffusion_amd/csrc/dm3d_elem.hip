@@ -405,11 +405,13 @@ struct DdpmArgs {
     const float *beta, *sqa, *ab, *abp, *sqab, *sqabp, *sq1ab;
     uint64_t seed; int mode;
     float* mean_out; float* var_out;
+    const uint64_t* seed_dev; int timesteps;
 };
 
 __global__ __launch_bounds__(256) void ddpm_kernel(const DdpmArgs p) {
     const int b = blockIdx.y;
-    const int t = p.t[b];
+    const int t = min(max(p.t[b], 0), p.timesteps - 1);
+    const uint64_t seed = p.seed_dev ? *p.seed_dev : p.seed;
     const float be = p.beta[t], sqa = p.sqa[t], ab = p.ab[t], abp = p.abp[t];
     const float sqab = p.sqab[t], sqabp = p.sqabp[t], sq1ab = p.sq1ab[t];
     const float one_m_ab = __fsub_rn(1.0f, ab), one_m_abp = __fsub_rn(1.0f, abp);
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(256) void ddpm_kernel(const DdpmArgs p) {
         }
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
         if (t > 0) z = p.noise ? reinterpret_cast<const f32x4*>(p.noise)[base + i]
-                               : philox_normal4((uint64_t)(base + i), (uint32_t)t, 0xd1f0u, p.seed);
+                               : philox_normal4((uint64_t)(base + i), (uint32_t)t, 0xd1f0u, seed);
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = __fadd_rn(fminf(fmaxf(mean[k], -1.0f), 1.0f), __fmul_rn(sigma, z[k]));
@@ -442,9 +444,18 @@ __global__ __launch_bounds__(256) void ddpm_kernel(const DdpmArgs p) {
     }
 }
 
+__global__ __launch_bounds__(256) void range_check_kernel(const float* __restrict__ x, long n4, float limit, int* __restrict__ flag) {
+    float amax = 0.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    if (amax > limit) *flag = 1;
+}
+
 __global__ void add_i32_kernel(int* p, int n, int delta) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] += delta;
+    if (i < n) p[i] = max(p[i] + delta, 0);
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, int table_rows,
@@ -574,6 +585,7 @@ extern "C" int dm3d_ddpm_update(const dm3d_ddpm_desc* d, void* stream) {
     DM3D_REQUIRE(d->beta && d->sqrt_alpha && d->alpha_bar && d->alpha_bar_prev && d->sqrt_alpha_bar &&
                  d->sqrt_alpha_bar_prev && d->sqrt_one_minus_alpha_bar, "ddpm: a Betas table is null");
     DM3D_REQUIRE(d->mode == 0 || d->mode == 1, "ddpm: mode %d not in {0,1}", d->mode);
+    DM3D_REQUIRE(d->timesteps > 0, "ddpm: timesteps=%d", d->timesteps);
     DM3D_REQUIRE(d->mode == 1 || d->mean_out, "ddpm: mode 0 needs mean_out");
     DM3D_REQUIRE(dm3d_aligned16(d->x) && dm3d_aligned16(d->eps) && dm3d_aligned16(d->noise) && dm3d_aligned16(d->mean_out),
                  "ddpm: pointers must be 16-byte aligned");
@@ -582,9 +594,16 @@ extern "C" int dm3d_ddpm_update(const dm3d_ddpm_desc* d, void* stream) {
     a.beta = d->beta; a.sqa = d->sqrt_alpha; a.ab = d->alpha_bar; a.abp = d->alpha_bar_prev; a.sqab = d->sqrt_alpha_bar;
     a.sqabp = d->sqrt_alpha_bar_prev; a.sq1ab = d->sqrt_one_minus_alpha_bar;
     a.seed = d->seed; a.mode = d->mode; a.mean_out = d->mean_out; a.var_out = d->var_out;
+    a.seed_dev = d->seed_dev; a.timesteps = d->timesteps;
     dim3 grid(grid_for(a.per4, 256), (unsigned)d->batch);
     hipLaunchKernelGGL(ddpm_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return dm3d_launch_check("ddpm_kernel");
+}
+
+extern "C" int dm3d_range_check(const float* x, int64_t n, float limit, int32_t* flag, void* stream) {
+    DM3D_REQUIRE(x && flag && n > 0 && n % 4 == 0 && dm3d_aligned16(x), "range_check: x/flag null, x unaligned or n=%lld not a positive multiple of 4", (long long)n);
+    hipLaunchKernelGGL(range_check_kernel, dim3(grid_for(n / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, (long)(n / 4), limit, flag);
+    return dm3d_launch_check("range_check_kernel");
 }
 
 extern "C" int dm3d_add_i32(int32_t* p, int32_t n, int32_t delta, void* stream) {

@@ -30,6 +30,7 @@ struct GemmH3Args {
     const float* res2;                  // optional second float32 residual with res's layout
     int out_h2;
     int batch;
+    int* range_flag; float range_limit;     // H3 range guard (include/dm3d.h)
 };
 
 constexpr int MAX_GROUP = 4;
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
     const int ldo = (int)p.ldo, ldr = (int)p.ldr;
     const float lo_bound = p.act == DM3D_ACT_RELU ? 0.0f : -3.4e38f;
     const int row_max = p.m - 1 - m0;                          // last valid row of this tile (partial tiles clamp their loads)
+    float amax = 0.0f;
     auto epilogue = [&](auto FULL_T, auto H2_T) {
         constexpr bool FULL = decltype(FULL_T)::value, H2 = decltype(H2_T)::value;
 #pragma unroll
@@ -319,6 +321,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
                     const int row = lrow + mr * 32 + (r & 3) + 8 * (r >> 2);
                     const float o = v[r];
                     const bool ok = FULL || (n_ok && m0 + row < p.m);
+                    if (FULL) DM3D_AMAX(amax, o); else DM3D_AMAX(amax, ok ? o : 0.0f);
                     if (H2) {
                         const unsigned int mine = split1_bits(o);
                         const unsigned int oth = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, false);   // lane ^ 1
@@ -338,6 +341,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
     } else {
         if (p.out_h2) epilogue(no, yes); else epilogue(no, no);
     }
+    if (p.range_flag && amax > p.range_limit) *p.range_flag = 1;
 }
 
 // float32 [rows][k] (ld_src) -> DM3D_FMT_H2 [rows][ld_dst], scaled by 2^exp2, zero filled up to round_up(k, 16)
@@ -389,6 +393,7 @@ static int fill_args(const dm3d_gemm_desc* d, GemmH3Args& a) {
     a.res = d->res; a.ldr = d->ldr; a.sr = d->stride_r; a.res2 = d->res2;
     a.out_h2 = d->out_fmt == DM3D_FMT_H2;
     a.batch = d->batch;
+    a.range_flag = d->range_flag; a.range_limit = d->range_limit > 0.0f ? d->range_limit : 65504.0f;
     return DM3D_OK;
 }
 

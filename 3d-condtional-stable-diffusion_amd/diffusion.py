@@ -66,6 +66,9 @@ class DiffusionModel:
         self.device = self.network.device
         self._graphs = {}
         self._stream = None
+        self._trainer = None
+        self._trainer_dirty = False
+        self.network._before_use = self._sync_from_trainer
 
     # -- the autoencoder bracket --------------------------------------------------------------------------------------
     @property
@@ -113,6 +116,7 @@ class DiffusionModel:
     def load_state_dict(self, sd, strict=True):
         self.network.load_state_dict(sd, strict)
         self._drop_graphs()
+        self._trainer, self._trainer_dirty = None, False          # Adam moments belong to the weights they were built for
 
     def load_weights(self, path, root=("network",)):
         """keras ``model.load_weights(ckpt)`` (main_conditional_dm.py:207-213): reads the U-Net from a TF2 checkpoint prefix
@@ -129,6 +133,7 @@ class DiffusionModel:
             self.vqvae_trainer.load_weights(path, root=("vqvae_trainer",))
 
     def save_weights(self, path, root=("network",)):
+        self._sync_from_trainer()
         if str(path).endswith(".npz"):
             np.savez(path, **self.network.state_dict())
             return
@@ -146,13 +151,77 @@ class DiffusionModel:
         except Exception:
             pass
 
-    def train_step(self, inputs):
-        """conditional_dm3d.py:471-510.  The forward half that precedes the network call exists (``q_sample`` below, on the
-        frozen encoder + quantizer); the network in training mode and the weight update need batch-statistics
-        BatchNormalization and the backward kernels."""
-        raise NotImplementedError(
-            "train_step is not built in this round: it needs batch-statistics BatchNormalization and the backward kernels "
-            "(SURVEY.md §8(f) next-2). There is deliberately no PyTorch-autograd fallback.")
+    # -- a15: train_step --------------------------------------------------------------------------------------------------
+    def _learning_rate(self) -> float:
+        """``compile(optimizer=keras.optimizers.Adam(learning_rate=args.lr))`` (main_conditional_dm.py:153): a float, an object with
+        ``learning_rate`` / ``lr``, or nothing (the reference's default --lr 1e-4, main_conditional_dm.py:228)."""
+        opt = getattr(self, "optimizer", None)
+        if isinstance(opt, (int, float)):
+            return float(opt)
+        for attr in ("learning_rate", "lr"):
+            if opt is not None and hasattr(opt, attr):
+                return float(getattr(opt, attr))
+        return 1e-4
+
+    @property
+    def trainer(self):
+        """The training engine (train.py), built on first use from the network's current weights."""
+        if self._trainer is None:
+            from .train import Trainer
+            self._trainer = Trainer(self.network.cfg, self.network.state_dict(), self.device, lr=self._learning_rate())
+        return self._trainer
+
+    def _sync_from_trainer(self):
+        """Weights changed by train_step flow back into the sampling network (folded norms, packed images, tables) before it runs."""
+        if self._trainer is not None and self._trainer_dirty:
+            self._trainer_dirty = False
+            self.network.load_state_dict(self._trainer.state_dict())
+            self._drop_graphs()
+
+    def train_step(self, inputs, *, t=None, noise=None, latents=None):
+        """conditional_dm3d.py:471-510: ``inputs = (images, mask, context)`` ((images, _) for the unconditional model, dm3d.py:431-433).
+        images [b, 16S, 16S, 16S, 1] go through the frozen encoder + quantizer (:478); t ~ U{0..T-1} (:474-476), noise ~ N(0,1) (:481),
+        q_sample (:484-490), the network with training=True (:493), loss = MSE_SUM / (global_bs * lc^4) (:496-499), Adam (:501-504),
+        loss tracker (:507-510).  Keyword-only extensions: ``t`` / ``noise`` inject the random draws (parity tests), ``latents`` skips the
+        autoencoder (pre-encoded latents [b, S, S, S, lc])."""
+        if self.conditional:
+            images, _, context = inputs
+        else:
+            images, _ = inputs
+            context = None
+        dev, cfg, T = self.device, self.network.cfg, self.timesteps
+        if latents is None and images is None:
+            raise ValueError("train_step needs images (inputs[0]) or pre-encoded latents=")
+        _lib.require_device()
+        if latents is None:
+            latents = self.encode_latents(torch.as_tensor(images, dtype=torch.float32).to(dev))
+        latents = torch.as_tensor(latents, dtype=torch.float32).to(dev).contiguous()
+        B = latents.shape[0]
+        want = (cfg.img_size,) * 3 + (cfg.img_channels,)
+        if latents.dim() != 5 or tuple(latents.shape[1:]) != want:
+            raise ValueError(f"latents must be [b,{','.join(map(str, want))}], got {tuple(latents.shape)}")
+        if t is None:
+            t = torch.from_numpy(np.random.default_rng(self.fresh_seed()).integers(0, T, size=B))
+        t = torch.as_tensor(t).reshape(-1).to(torch.int64)
+        if t.numel() != B or int(t.min()) < 0 or int(t.max()) >= T:
+            raise ValueError("t must hold one index in [0, timesteps) per sample")
+        if noise is None:
+            noise = torch.empty_like(latents)
+            check(lib().dm3d_randn(noise.data_ptr(), noise.numel(), self.fresh_seed(), 0x7ffffffe, torch.cuda.current_stream().cuda_stream), "randn")
+        noise = torch.as_tensor(noise, dtype=torch.float32).to(dev).contiguous()
+        if noise.shape != latents.shape:
+            raise ValueError("noise must have the latents' shape")
+        ids = None
+        if self.conditional:
+            ids = self._context_ids(context, B)
+        tr = self.trainer
+        tab = self.b.device_tables(dev)
+        betas = (tab[BETAS_FIELDS.index("sqrt_alpha_bar")], tab[BETAS_FIELDS.index("sqrt_one_minus_alpha_bar")])
+        loss, _ = tr.loss_and_grad(latents, t, noise, ids, betas, T, self.global_bs, self.lc)
+        tr.adam_step()
+        self._trainer_dirty = True
+        self.loss_tracker.update_state(float(loss.item()))
+        return {"loss": self.loss_tracker.result()}
 
     def encode_latents(self, images):
         """train_step's first half (conditional_dm3d.py:478): latents, _ = quantizer(encoder(images))."""
@@ -205,8 +274,15 @@ class DiffusionModel:
             raise ValueError(f"context ids must lie in [0, {self.network.cfg.context_dim}]")
         return ids.astype(np.int32)
 
-    def sampler(self, shape, context_value=None, *, seed=0, use_graph=True) -> "Sampler":
-        """The state of one generate() call: plan, tables, context rows and the captured step graph."""
+    @staticmethod
+    def fresh_seed() -> int:
+        """A new 64-bit Philox key from the host's entropy source (the reference draws fresh tf.random.normal noise per call)."""
+        import secrets
+        return secrets.randbits(64)
+
+    def sampler(self, shape, context_value=None, *, seed=None, use_graph=True) -> "Sampler":
+        """The state of one generate() call: plan, tables, context rows and the captured step graph.  There is one live
+        Sampler per (batch, context mode): creating another one for the same plan retires the older (its step() raises)."""
         net = self.network
         cfg = net.cfg
         shape = tuple(int(s) for s in shape)
@@ -214,13 +290,16 @@ class DiffusionModel:
             raise ValueError(f"shape must be (B,{cfg.img_size},{cfg.img_size},{cfg.img_size},{cfg.img_channels})")
         return Sampler(self, shape, self._context_ids(context_value, shape[0]) if self.conditional else None, seed, use_graph)
 
-    def generate(self, shape=(1, 16, 16, 16, 16), last_step=0, context_value=None, *, x_T=None, noise=None, seed=0,
+    def generate(self, shape=(1, 16, 16, 16, 16), last_step=0, context_value=None, *, x_T=None, noise=None, seed=None,
                  use_graph=True, steps=None):
         """conditional_dm3d.py:550-575.  For shape[0] > 1 the single context row is broadcast to every sample.
+        ``seed`` (optional): Philox key of x_T and of every step's noise; None (default) draws a fresh key per call, as the
+        reference draws fresh tf.random.normal noise, an integer makes the call reproducible.
         ``noise`` (optional): tensor [timesteps, *shape]; row i is the draw of step i.  ``steps`` (optional) stops
         after that many steps (benchmarks time a prefix of the chain)."""
         if not 0 <= last_step <= self.timesteps:
             raise ValueError("last_step out of range")
+        self._sync_from_trainer()
         smp = self.sampler(shape, context_value, seed=seed, use_graph=use_graph and noise is None)
         smp.reset(x_T)
         T = self.timesteps
@@ -234,13 +313,16 @@ class DiffusionModel:
         else:
             for _ in range(n_steps):
                 smp.step()
-        return smp.plan.x.clone()
+        out = smp.plan.x.clone()
+        self.network.check_range(smp.plan)
+        return out
 
-    MAX_GRAPHS = 8      # captured step graphs kept per model (one per (plan, seed)); the least recently used one is destroyed
+    MAX_GRAPHS = 8      # captured step graphs kept per model (one per plan); the least recently used one is destroyed
 
     def _capture(self, smp: "Sampler"):
-        """Capture one step of ``smp`` into a HIP graph (cached per plan and seed; the seed is a kernel argument)."""
-        key = (id(smp.plan), smp.seed)
+        """Capture one step of ``smp`` into a HIP graph, cached per plan: the Philox key lives in a device scalar of the plan
+        (dm3d_ddpm_desc.seed_dev), so one graph serves every seed."""
+        key = id(smp.plan)
         if key in self._graphs:
             self._graphs[key] = self._graphs.pop(key)                  # most recently used last
             return self._graphs[key][0]
@@ -249,7 +331,7 @@ class DiffusionModel:
         g = C.c_void_p()
         check(lib().dm3d_graph_begin(cap.cuda_stream), "graph_begin")
         try:
-            smp._enqueue(cap.cuda_stream, smp.desc)
+            smp._enqueue(cap.cuda_stream, smp.desc)     # desc reads the key through plan.seed_buf
         finally:
             rc = lib().dm3d_graph_end(cap.cuda_stream, C.byref(g))
         check(rc, "graph_end")
@@ -296,28 +378,47 @@ class Sampler:
     """One DDPM chain over a fixed batch (the loop body of generate, conditional_dm3d.py:559-573).
 
     ``step()`` enqueues U-Net forward + posterior update + index decrement on the current stream and never synchronises;
-    with ``use_graph`` the three are one HIP-graph replay."""
+    with ``use_graph`` the three are one HIP-graph replay.  A chain has T steps: step() past its end raises until reset().
+    The plan (buffers, step index, Philox key) belongs to the newest Sampler made for it; an older one raises on use."""
 
     def __init__(self, model: DiffusionModel, shape, ctx_ids, seed, use_graph):
-        self.model, self.shape, self.seed, self.use_graph = model, shape, int(seed) & (2 ** 64 - 1), use_graph
+        self.model, self.shape, self.use_graph = model, shape, use_graph
+        self.seed = (model.fresh_seed() if seed is None else int(seed)) & (2 ** 64 - 1)
         net, T = model.network, model.timesteps
-        self.plan = net.plan(shape[0], T, ctx_ids is not None and len(ctx_ids) > 1)       # one context row per volume, or one broadcast
-        if getattr(self.plan, "_time_filled", None) is not net.P:
-            net.fill_time_table(np.arange(T), self.plan.vec)
-            self.plan._time_filled = net.P
+        # one context row per volume, or one broadcast; "sampler": never the plan UNet.__call__ fills with its own time rows
+        self.plan = net.plan(shape[0], T, ctx_ids is not None and len(ctx_ids) > 1, purpose="sampler")
+        plan = self.plan
+        if getattr(plan, "_time_filled", None) is not net.P:
+            net.fill_time_table(np.arange(T), plan.vec)
+            plan._time_filled = net.P
         if ctx_ids is not None:
-            self.plan.set_context(ctx_ids)
-        self.desc = model._ddpm_desc(self.plan.x, self.plan.eps, self.plan.t_idx, 1, seed=self.seed)
-        self.graph = None
+            plan.set_context(ctx_ids)
+        if getattr(plan, "seed_buf", None) is None:
+            plan.seed_buf = torch.zeros(1, dtype=torch.int64, device=model.device)
+        plan._owner_gen = getattr(plan, "_owner_gen", 0) + 1
+        self._gen = plan._owner_gen
+        self.desc = model._ddpm_desc(plan.x, plan.eps, plan.t_idx, 1, seed=self.seed)
+        self.desc.seed_dev = plan.seed_buf.data_ptr()
+        self._t = -1                          # host mirror of the device step index; -1: no chain in progress
+
+    def _own(self):
+        if self._gen != self.plan._owner_gen:
+            raise RuntimeError("this Sampler was retired: a newer Sampler (generate() call) took over its plan")
 
     def reset(self, x_T=None):
+        self._own()
         plan, T = self.plan, self.model.timesteps
         st = torch.cuda.current_stream().cuda_stream
+        seed_i64 = self.seed - (1 << 64) if self.seed >= (1 << 63) else self.seed
+        plan.seed_buf.fill_(seed_i64)
         if x_T is not None:
             plan.x.copy_(torch.as_tensor(x_T, dtype=torch.float32).reshape(self.shape))
         else:
             check(lib().dm3d_randn(plan.x.data_ptr(), plan.x.numel(), self.seed, 0x7fffffff, st), "randn")
         plan.t_idx.fill_(T - 1)
+        if plan.range_flag is not None:
+            plan.range_flag.zero_()
+        self._t = T - 1
 
     def _enqueue(self, st, desc):
         self.plan.run(st)
@@ -326,18 +427,21 @@ class Sampler:
 
     def prepare(self):
         """Capture the step graph now (setup cost: the first step() otherwise pays for it)."""
-        if self.use_graph and self.graph is None:
-            self.graph = self.model._capture(self)
+        if self.use_graph:
+            self.model._capture(self)
         return self
 
     def step(self, noise=None):
+        self._own()
+        if self._t < 0:
+            raise RuntimeError("the chain is finished (or was never started): call reset() before step()")
         st = torch.cuda.current_stream().cuda_stream
         if noise is not None:
             d = self.model._ddpm_desc(self.plan.x, self.plan.eps, self.plan.t_idx, 1, noise=noise)
             self._enqueue(st, d)
         elif self.use_graph:
-            if self.graph is None:
-                self.graph = self.model._capture(self)
-            check(lib().dm3d_graph_launch(self.graph, st), "graph_launch")
+            # resolved through the model's cache on every step: load_weights / LRU eviction destroy graphs, never under a live handle
+            check(lib().dm3d_graph_launch(self.model._capture(self), st), "graph_launch")
         else:
             self._enqueue(st, self.desc)
+        self._t -= 1

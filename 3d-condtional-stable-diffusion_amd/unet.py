@@ -78,6 +78,7 @@ class UNet:
         self.state: Dict[str, np.ndarray] = {}
         self._plans: Dict[tuple, "Plan"] = {}
         self._prepared = False
+        self._before_use = None         # set by DiffusionModel: brings weights changed by train_step back before the network is used
         self.load_state_dict(weights if weights is not None else keras_init_weights(cfg, seed))
 
     # ---- weights -------------------------------------------------------------------------------------------------
@@ -103,7 +104,12 @@ class UNet:
         self._prepared = False
         self._plans.clear()
 
+    def _fresh(self):
+        if self._before_use is not None:
+            self._before_use()
+
     def state_dict(self) -> Dict[str, np.ndarray]:
+        self._fresh()
         return dict(self.state)
 
     def num_params(self) -> int:
@@ -218,8 +224,37 @@ class UNet:
         P["out.conv"] = self._pack(s["out.conv.kernel"], s["out.conv.bias"], conv=True)
         self.P = P
         self._prepared = True
+        self.range_limit = self._h3_range_limit()
         if cfg.conditional:
             self._prepare_context_tables()
+
+    def _h3_range_limit(self) -> float:
+        """Bound on |activation| below which no H3 operand path can leave the float16 range (include/dm3d.h, range_flag): a raw
+        consumer clamps at 65504; a consumer behind a folded BatchNormalization sees silu(x*scale + shift), |.| <= |x| max|scale| +
+        max|shift|.  (GroupNormalization normalises per sample: |x_hat| <= sqrt(group size), no bound on x is needed.)"""
+        lim = 65504.0
+        if self.cfg.norm == "batch":
+            s = self.state
+            for name in s:
+                if name.endswith(".gamma") and name[:-6] + ".var" in s:
+                    base = name[:-6]
+                    scale = np.abs(s[f"{base}.gamma"].astype(np.float64) / np.sqrt(s[f"{base}.var"].astype(np.float64) + BN_EPS))
+                    shift = np.abs(s[f"{base}.beta"].astype(np.float64) - s[f"{base}.mean"].astype(np.float64) * scale)
+                    smax = float(scale.max())
+                    if smax > 0:
+                        lim = min(lim, (65504.0 - float(shift.max())) / smax)
+        return max(lim, 1.0)
+
+    def check_range(self, plan: "Plan"):
+        """Raises if any launch of ``plan`` since the last check produced a value an H3 consumer would have clamped (one 4-byte
+        device read: the only host synchronisation of a generate() call, at its end)."""
+        if plan.range_flag is None:
+            return
+        if int(plan.range_flag.item()) != 0:
+            plan.range_flag.zero_()
+            raise _lib.Dm3dError(
+                f"an activation exceeded the range the split-float16 (precision='h3') kernels represent exactly (|x| > {self.range_limit:.4g}); "
+                "the result would differ from float32 arithmetic. Rebuild the model with precision='fp32'.")
 
     def _prepare_attn(self, P, blk):
         s, n, u = self.state, blk.name, blk.cout
@@ -302,19 +337,25 @@ class UNet:
                        bias=ta.bias)
 
     # ---- plans -----------------------------------------------------------------------------------------------------
-    def plan(self, batch: int, vec_rows: int, per_sample_context: bool = False) -> "Plan":
+    def plan(self, batch: int, vec_rows: int, per_sample_context: bool = False, purpose: str = "forward") -> "Plan":
+        """``purpose`` keeps the plan a Sampler drives (its ``vec`` holds the time table of the whole chain) apart from the
+        plan ``__call__`` uses (its ``vec`` holds the rows of the caller's t values), also when batch == timesteps."""
+        self._fresh()
         self.prepare()
-        key = (int(batch), int(vec_rows), bool(per_sample_context))
+        key = (int(batch), int(vec_rows), bool(per_sample_context), str(purpose))
         if key not in self._plans:
-            self._plans[key] = Plan(self, *key)
+            self._plans[key] = Plan(self, *key[:3])
         return self._plans[key]
+
+    def _call_training(self, inputs) -> torch.Tensor:
+        return _training_forward(self, inputs)
 
     def __call__(self, inputs, training: bool = False) -> torch.Tensor:
         """``network([x, t, context])`` / ``network([x, t])`` as in conditional_dm3d.py:493, 568 (dm3d.py:525)."""
-        if training:
-            raise NotImplementedError("training=True (batch-statistics BatchNormalization + backward) is not built yet; "
-                                      "SURVEY.md §8(f) next-2")
         cfg = self.cfg
+        self._fresh()
+        if training:
+            return self._call_training(inputs)
         if cfg.conditional:
             if len(inputs) != 3:
                 raise ValueError("the conditional network takes [image, time, context]")
@@ -344,13 +385,38 @@ class UNet:
                 raise ValueError(f"context ids must be in [0,{ids})")
             per_sample = ctx_host.shape[0] == B and B > 1 and len(set(ctx_host.tolist())) > 1
         plan = self.plan(B, B, per_sample)
+        if plan.range_flag is not None:
+            plan.range_flag.zero_()
         self.fill_time_table(t_host, plan.vec)
         plan.t_idx.copy_(torch.arange(B, dtype=torch.int32))
         if cfg.conditional:
             plan.set_context(ctx_host if per_sample else ctx_host[:1])
         plan.x.copy_(x.to(self.device))
         plan.run()
-        return plan.eps.clone()
+        out = plan.eps.clone()
+        self.check_range(plan)
+        return out
+
+
+def _training_forward(net: "UNet", inputs) -> torch.Tensor:
+    """``network([x, t, context], training=True)`` (conditional_dm3d.py:493) outside train_step: BatchNormalization normalises with
+    the statistics of this batch and updates its moving averages (momentum 0.99), as Keras does whenever training=True."""
+    from .train import Trainer
+    cfg = net.cfg
+    x, t = inputs[0], inputs[1]
+    ctx = inputs[2] if cfg.conditional else None
+    x = torch.as_tensor(x, dtype=torch.float32).to(net.device).contiguous()
+    tr = Trainer(cfg, net.state_dict(), net.device)
+    ids = None
+    if cfg.conditional:
+        ids = torch.as_tensor(ctx).reshape(-1).to(net.device, torch.int32)
+        if ids.numel() == 1 and x.shape[0] > 1:
+            ids = ids.repeat(x.shape[0])
+    out = tr.forward(x, torch.as_tensor(t).reshape(-1).cpu().numpy().astype(np.int64), ids, update_moving=True)
+    tr.tape = []
+    new = tr.state_dict()
+    net.load_state_dict({k: (new[k] if k.endswith((".mean", ".var")) else v) for k, v in net.state_dict().items()})
+    return out.v
 
 
 def _gemm_desc(a, lda, b, ldb, out, ldo, m, n, k, batch=1, stride_a=0, stride_b=0, stride_o=0, alpha=1.0, bias=None,
@@ -390,6 +456,8 @@ class Plan:
         self.vec = torch.empty(vec_rows, net.temb_ld, dtype=torch.float32, device=dev)
         self.ctx_bufs: Dict[str, tuple] = {}
         self._gn_acc = None
+        # H3 range guard (include/dm3d.h): every H3 launch of the plan reports into one flag; see UNet.check_range
+        self.range_flag = torch.zeros(1, dtype=torch.int32, device=dev) if net.precision == "h3" else None
         self._build()
         # one workspace for every conv that can split its Cin range (dm3d_conv_scratch_bytes): launches are stream-ordered
         need = max([lib().dm3d_conv_scratch_bytes(C.byref(d)) for d in self._keep if isinstance(d, ConvDesc)] + [0])
@@ -452,6 +520,8 @@ class Plan:
             self._keep += [post[0], post[1]]
         d.out_fmt = _lib.FMT_H2 if out_h2 else _lib.FMT_F32
         d.x1_fmt = _lib.FMT_H2 if x1_h2 else _lib.FMT_F32
+        if self.range_flag is not None and w.precision == _lib.PREC_H3:
+            d.range_flag, d.range_limit = self.range_flag.data_ptr(), self.net.range_limit
         skip_flops = 0.0
         if skip is not None:
             sx1, sx2, sc1, sc2, simg = skip
@@ -484,8 +554,13 @@ class Plan:
                           "bytes": 4.0 * self.B * (edge_in ** 3 * (w.cin + (skip[2] + skip[3] if skip is not None else 0))
                                                    + eo ** 3 * w.cout)}))
 
+    def _guard(self, d: GemmDesc) -> GemmDesc:
+        if self.range_flag is not None and d.precision == _lib.PREC_H3:
+            d.range_flag, d.range_limit = self.range_flag.data_ptr(), self.net.range_limit
+        return d
+
     def _gemm(self, **kw):
-        d = _gemm_desc(**kw)
+        d = self._guard(_gemm_desc(**kw))
         self._keep.append(d)
         kind = "gemm_h3" if d.precision == _lib.PREC_H3 else "gemm"
         self.ops.append((lib().dm3d_gemm_tn, (C.byref(d),), kind,
@@ -493,7 +568,7 @@ class Plan:
 
     def _gemm_group(self, problems):
         """Independent H3 GEMMs with identical operand formats as one launch (dm3d_gemm_tn_group)."""
-        arr = (GemmDesc * len(problems))(*[_gemm_desc(**kw) for kw in problems])
+        arr = (GemmDesc * len(problems))(*[self._guard(_gemm_desc(**kw)) for kw in problems])
         self._keep.append(arr)
         fl = sum(2.0 * d.m * d.n * d.k * d.batch for d in arr)
         desc = "gemm_h3 group[" + " | ".join(f"m={d.m} n={d.n} k={d.k} b={d.batch}" for d in arr) + "]"
@@ -504,6 +579,8 @@ class Plan:
         net, cfg, B = self.net, self.net.cfg, self.B
         P = net.P
         S = cfg.img_size
+        if self.range_flag is not None:        # the caller's x_t is the one tensor on an H3 operand path that no dm3d kernel wrote
+            self.ops.append((lib().dm3d_range_check, (self.x.data_ptr(), self.x.numel(), 65504.0, self.range_flag.data_ptr()), "range", {}))
         h = self._buf(B, S, S, S, cfg.first_conv_channels)
         self._conv(P["conv_in"], self.x, h, S)
         skips = [(h, cfg.first_conv_channels)]

@@ -7,8 +7,10 @@ Contract (one JSON line from rank 0):  python bench.py --gpus N --steps K --warm
     prediction + posterior update (+ Philox noise) — every one of the T steps of a chain does exactly this work, so
     value = volumes/sec for full T=1000 chains = N*B / (T * seconds_per_step); K steps of real chains are timed
     (x_T ~ N(0,1), t = T-1, T-2, ...), nothing is skipped inside a step.
-  * N>1: one process per GPU (torchrun), rank 0's weights broadcast once over RCCL, batch sharded, no per-step
-    collective ("weak" scaling: B per GPU fixed).
+  * N>1: one process per GPU, rank 0's weights broadcast once over RCCL, batch sharded, no per-step collective ("weak"
+    scaling: B per GPU fixed).  Under torchrun (RANK/LOCAL_RANK/WORLD_SIZE set) this process is one rank; started plainly as
+    `python bench.py --gpus N` it launches the N ranks itself as fresh child processes — before this process has touched the
+    GPU — relays rank 0's JSON line and exits non-zero if any rank fails.
   * roofline: the dominant kernel is the k3/stride-1 Conv3d implicit GEMM (24 launches/step of the main instantiation, 10 more of
     its H2-input twin —
     conv_in/conv_out and the two UpSample convs run other instantiations and are listed under per_kernel_kind);
@@ -53,6 +55,43 @@ def host_cores() -> int:
     return max(1, n)
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this parent never initialises the GPU),
+    relay rank 0's stdout (the JSON line) and every rank's stderr, return non-zero if any rank failed."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0 = procs[0].communicate()[0]
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"[bench] ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def csrc_digest() -> str:
+    """sha256 over the kernel sources: a PMC summary records the digest it was measured with (stale evidence is not attached)."""
+    import hashlib
+    d = os.path.join(ROOT, "3d-condtional-stable-diffusion_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,7 +108,17 @@ def main():
     ap.add_argument("--precision", choices=["h3", "fp32"], default="h3",
                     help="Conv3d arithmetic: h3 = float16 hi+lo split, 3 MFMA passes, fp32 accumulate (default); "
                          "fp32 = exact float32 MFMA")
+    ap.add_argument("--no-fp32-mode", action="store_true", help="skip the extra exact-float32 timing (N=1, h3 runs only)")
+    ap.add_argument("--no-full-chain", action="store_true", help="skip the wall-clock timing of one whole T=1000 generate() (N=1 only)")
+    ap.add_argument("--print-csrc-digest", action="store_true")
     args = ap.parse_args()
+    if args.print_csrc_digest:
+        print(csrc_digest())
+        return
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))              # nothing above has imported torch or touched the GPU
 
     import numpy as np
     import torch
@@ -80,8 +129,7 @@ def main():
 
     rank, local_rank, world = parallel.env_rank()
     if world != args.gpus:
-        if args.gpus != 1 and world == 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} processes (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} does not match the launcher's WORLD_SIZE={world}")
     # DM3D_BENCH_REHEARSAL=1: several ranks share GPU 0 and talk over gloo — only to rehearse the multi-process logic
     # on a one-GPU box (RCCL refuses two ranks on one device); the driver's real runs use one GPU per rank over RCCL.
     rehearsal = os.environ.get("DM3D_BENCH_REHEARSAL") == "1"
@@ -103,6 +151,14 @@ def main():
     spec = dm3d_amd.param_spec(cfg)
     W = dm3d_amd.synthetic_weights(cfg, seed=0) if rank == 0 else None
     W = parallel.broadcast_state(W, spec, src=0, device=comm_dev)              # RCCL broadcast over xGMI (no-op at N=1)
+    # every rank's identity: device, Philox seed, digest of the weights it holds after the broadcast (must all agree)
+    me = json.dumps({"rank": rank, "device": torch.cuda.get_device_name(dev_index), "device_index": dev_index,
+                     "seed": parallel.rank_seed(1234, rank), "weights_sha": parallel.state_digest(W)})
+    ranks_info = {"world_size": dist.get_world_size() if world > 1 else 1,
+                  "backend": dist.get_backend() if world > 1 else None,
+                  "per_rank": [json.loads(x) for x in parallel.gather_strings(me)]}
+    if len({r["weights_sha"] for r in ranks_info["per_rank"]}) != 1:
+        raise SystemExit("ranks hold different weights after the broadcast")
     margs = SimpleNamespace(timesteps=T_FULL, num_gpus=world, kernel_resize=False, bs=B * world)
     model = cdm.DiffusionModel(S, 1024, Cc, None, margs, device=dev, weights=W, precision=args.precision, norm=args.norm)
     smp = model.sampler((B, S, S, S, Cc), context_value=1, seed=parallel.rank_seed(1234, rank),
@@ -182,20 +238,80 @@ def main():
                     "algorithmic_mb_per_launch": round(by / n / 1e6, 2)}
 
     # HBM traffic of the dominant kernel: PMC counters need their own rocprofv3 passes (MI355X_MICROARCH.md), so the figure
-    # comes from the committed summary of those passes over this same command (profiles/summarize_pmc.py), not from this run
+    # comes from the committed summary of those passes over this same command (profiles/summarize_pmc.py), not from this run.
+    # It is attached only when the summary was measured on THIS workload with THESE kernel sources (its header records both);
+    # otherwise traffic stays null and the reason is reported.
     if roofline is not None:
-        try:
-            import csv
-            path = os.path.join(ROOT, "profiles", "r01_h3_pmc_hbm.csv" if args.precision == "h3" else "r01_fp32_pmc_hbm.csv")
-            want = "conv3d_igemm_h3v2<3, 1>" if args.precision == "h3" else "conv3d_igemm_f32<4, 8, 8, 1, 3, 4, 1>"
-            for row in csv.reader(l for l in open(path) if not l.startswith("#")):
-                if row and row[0] == want:
-                    roofline["traffic"] = float(row[4]) * 1e6
-                    roofline["traffic_unit"] = "bytes/launch (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc, " + os.path.basename(path) + ")"
-                    roofline["hbm_GBps_of_kernel"] = round(roofline["traffic"] / (roofline["avg_launch_ms"] * 1e-3) / 1e9, 1)
-                    roofline["hbm_frac_of_8TBps"] = round(roofline["hbm_GBps_of_kernel"] / 8000.0, 4)
-        except Exception:
-            pass
+        import csv
+        import glob
+        want = "conv3d_igemm_h3v2<3, 1>" if args.precision == "h3" else "conv3d_igemm_f32<4, 8, 8, 1, 3, 4, 1>"
+        sig = f"batch={B} size={S} channels={Cc} norm={args.norm} precision={args.precision} csrc={csrc_digest()}"
+        reason = "no profiles/*_pmc_hbm.csv records this workload and these kernel sources: " + sig
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv")), reverse=True):
+            lines = open(path).read().splitlines()
+            if not any(l.startswith("# workload: ") and l[len("# workload: "):].strip() == sig for l in lines):
+                continue
+            rows = [r for r in csv.reader(l for l in lines if not l.startswith("#")) if r and r[0] == want]
+            if not rows:
+                reason = f"{os.path.basename(path)} matches the workload but has no row for {want}"
+                log(reason)
+                continue
+            roofline["traffic"] = float(rows[0][4]) * 1e6
+            roofline["traffic_unit"] = "bytes/launch (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc, " + os.path.basename(path) + ")"
+            roofline["hbm_GBps_of_kernel"] = round(roofline["traffic"] / (roofline["avg_launch_ms"] * 1e-3) / 1e9, 1)
+            roofline["hbm_frac_of_8TBps"] = round(roofline["hbm_GBps_of_kernel"] / 8000.0, 4)
+            reason = None
+            break
+        if reason:
+            roofline["traffic_note"] = reason
+            log("roofline.traffic = null: " + reason)
+
+    # ---- the same K steps in exact-float32 arithmetic (v_mfma_f32_32x32x2_f32), so that number is timed in this run too ------
+    fp32_mode = None
+    if rank == 0 and world == 1 and args.precision == "h3" and not args.no_fp32_mode:
+        log("fp32 mode: building the exact-float32 model")
+        m32 = cdm.DiffusionModel(S, 1024, Cc, None, margs, device=dev, weights=W, precision="fp32", norm=args.norm)
+        s32 = m32.sampler((B, S, S, S, Cc), context_value=1, seed=parallel.rank_seed(1234, rank), use_graph=not args.no_graph)
+        s32.prepare()
+        s32.reset()
+        for _ in range(max(1, Wm)):
+            s32.step()
+        torch.cuda.synchronize()
+        t32 = time.perf_counter()
+        for _ in range(K):
+            s32.step()
+        torch.cuda.synchronize()
+        sp32 = (time.perf_counter() - t32) / K
+        acc32 = [0, 0.0, 0.0]
+        s32.plan.run_timed()
+        for kind, meta, ms in s32.plan.run_timed():
+            if kind == "conv_k3s1":
+                acc32[0] += 1
+                acc32[1] += ms
+                acc32[2] += meta.get("flops", 0.0)
+        a32 = acc32[2] / (acc32[1] * 1e-3) / 1e12
+        fp32_mode = {"ms_per_step": sp32 * 1e3, "value": B / (T_FULL * sp32), "unit": "volumes/s", "steps": K,
+                     "roofline": {"bound": "mfma", "kernel": "conv3d_igemm_f32<4, 8, 8, 1, 3, 4, 1> (v_mfma_f32_32x32x2_f32)",
+                                  "achieved": round(a32, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(a32 / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(acc32[1] / acc32[0], 4),
+                                  "launches_per_step": acc32[0]}}
+        log(f"fp32 mode: {sp32 * 1e3:.2f} ms/step")
+        del s32, m32
+        torch.cuda.empty_cache()
+
+    # ---- one whole chain, wall clock: generate() of B volumes through all T steps (the K-step figure extrapolates to this) ------
+    full_chain = None
+    if rank == 0 and world == 1 and not args.no_full_chain:
+        torch.cuda.synchronize()
+        f0 = time.perf_counter()
+        out = model.generate((B, S, S, S, Cc), context_value=1, seed=parallel.rank_seed(1234, rank), use_graph=not args.no_graph)
+        torch.cuda.synchronize()
+        fs = time.perf_counter() - f0
+        full_chain = {"full_chain_s": fs, "volumes": B, "timesteps": T_FULL, "volumes_per_s": B / fs,
+                      "finite": bool(torch.isfinite(out).all().item()),
+                      "ratio_to_extrapolated": fs / (T_FULL * s_per_step)}
+        log(f"full T={T_FULL} chain of B={B}: {fs:.2f} s ({B / fs:.3f} volumes/s; {T_FULL}*ms_per_step = {T_FULL * s_per_step:.2f} s)")
+        del out
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only) ----------------------------
     cpu = None
@@ -236,7 +352,11 @@ def main():
                                    f"value = n_gpus*B/(T*s_per_step)",
                        "batch_per_gpu": B, "global_batch": B * world, "timesteps": T_FULL,
                        "weights": "seeded synthetic (seed 0), rank-0 broadcast", "parallelism": f"batch-shard x{world}" + (" (REHEARSAL: ranks share one GPU, gloo)" if rehearsal else "")},
-            "roofline": roofline, "cpu_baseline": cpu, "per_kernel_kind": per_kind,
+            "roofline": roofline, "cpu_baseline": cpu, "fp32_mode": fp32_mode, "full_chain": full_chain,
+            "per_kernel_kind": per_kind,
+            "per_kernel_kind_note": "eager launches with a HIP-event pair around each (event overhead included; the timed step is "
+                                    "a HIP-graph replay, so these rows sum to slightly more than ms_per_step)",
+            "ranks": ranks_info,
             "conv_mfma_util_pct": None if roofline is None else round(100 * roofline["executed_mfma_frac_of_peak"], 2),
             "precision": args.precision, "norm": args.norm,
         }

@@ -21,8 +21,9 @@
 extern "C" {
 #endif
 
-#define DM3D_VERSION 105          /* major*100 + minor; the descriptor structs grew in 101 (w_layout), 102 (scratch), 103 (skip_*),
-                                     104 (dm3d_attention), 105 (x1_fmt / out_fmt / post_*): a host built against an older header must be rebuilt */
+#define DM3D_VERSION 106          /* major*100 + minor; the descriptor structs grew in 101 (w_layout), 102 (scratch), 103 (skip_*),
+                                     104 (dm3d_attention), 105 (x1_fmt / out_fmt / post_*), 106 (ddpm seed_dev; conv/gemm range_flag; the
+                                     training entries): a host built against an older header must be rebuilt */
 
 #define DM3D_OK            0
 #define DM3D_EINVAL       -1      /* bad argument (shape, alignment, null pointer) */
@@ -171,6 +172,13 @@ typedef struct dm3d_conv_desc {
                                    applies the epilogue, so results do not depend on timing.  dm3d_conv_scratch_bytes(d) says how
                                    much a descriptor can use (0: none).  Without it such convs split at most two ways. */
     int64_t scratch_bytes;
+    /* DM3D_PREC_H3 range guard.  An H3 consumer clamps float32 operands to the float16 range (+-65504) before the hi/lo split — a
+       silent difference from the reference's float32 arithmetic if a value ever got there.  With range_flag set, this launch
+       writes 1 to *range_flag when any |output value| exceeds range_limit (0 = 65504; hosts pass the smaller bound that also
+       covers a consumer's folded norm: (65504 - max|shift|) / max|scale|; a two-way atomic split compares its partial sums with
+       range_limit / 2).  The host reads the flag once per generate() / forward and raises instead of returning clamped results
+       (rerun with DM3D_PREC_F32).  NULL: no check. */
+    int32_t* range_flag; float range_limit;
 } dm3d_conv_desc;
 
 int     dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream);
@@ -194,6 +202,7 @@ typedef struct dm3d_gemm_desc {
     int32_t a_fmt, b_fmt;       /* H3: DM3D_FMT_F32 (split while staging) or DM3D_FMT_H2 (pre-split); k % 16 == 0 */
     int32_t out_fmt;            /* H3: DM3D_FMT_F32 or DM3D_FMT_H2 (n % 16 == 0, ldo % 16 == 0); res is always float32 */
     const float* res2;          /* optional second float32 residual, same ldr / stride_r as res (needs res) */
+    int32_t* range_flag; float range_limit;     /* H3 only: as in dm3d_conv_desc */
 } dm3d_gemm_desc;
 
 int dm3d_gemm_tn(const dm3d_gemm_desc* d, void* stream);
@@ -269,6 +278,9 @@ int     dm3d_attention(const dm3d_attention_desc* d, void* scratch, void* stream
 int dm3d_affine_act(const float* x, float* y, int64_t rows, int32_t c, const float* scale, const float* shift,
                     int32_t act, void* stream);
 
+/* *flag = 1 if any |x[i]| > limit (the H3 range guard for a tensor no dm3d kernel produced, e.g. the caller's x_t). n % 4 == 0. */
+int dm3d_range_check(const float* x, int64_t n, float limit, int32_t* flag, void* stream);
+
 /* ---- DDPM posterior step: DiffusionModel.sample + the loop body of generate (:517-548, 571-573) --------------
  * Coefficients are gathered at t[b] and combined in float32 in the reference's order.
  *   mode 0 (sample):   mean_out = posterior mean, var_out[b] = posterior variance (no clip, no noise).
@@ -286,11 +298,15 @@ typedef struct dm3d_ddpm_desc {
     uint64_t seed;
     int32_t mode;
     float* mean_out; float* var_out;
+    const uint64_t* seed_dev;   /* optional: the Philox key is read from device memory instead of `seed`, so one captured step graph
+                                   serves every seed (the host rewrites the scalar between chains).  t[b] is clamped to
+                                   [0, timesteps) before any table is indexed. */
 } dm3d_ddpm_desc;
 
 int dm3d_ddpm_update(const dm3d_ddpm_desc* d, void* stream);
 
-/* p[i] += delta (the loop counter of generate kept on the device so a captured step replays unchanged). */
+/* p[i] = max(p[i] + delta, 0) (the loop counter of generate kept on the device so a captured step replays unchanged; it
+ * saturates at 0, so a step issued past the end of a chain never indexes row -1 of a table). */
 int dm3d_add_i32(int32_t* p, int32_t n, int32_t delta, void* stream);
 /* x ~ N(0,1) from Philox keyed by (seed, stream_id): the x_T draw of generate (:555). n % 4 == 0. */
 int dm3d_randn(float* x, int64_t n, uint64_t seed, uint32_t stream_id, void* stream);
@@ -303,6 +319,88 @@ int dm3d_gather_rows(const float* table, int32_t table_rows, const int32_t* idx,
  * then dm3d_gather_rows(E^T, idx). */
 int dm3d_vq_assign(const float* z, int64_t rows, int32_t d, const float* sim, int32_t k, const float* esq, int32_t* idx,
                    void* stream);
+
+/* ================= training (DiffusionModel.train_step, conditional_dm3d.py:471-510; compile() at main_conditional_dm.py:149-154) ==========
+ * The forward pass of training reuses the entries above in DM3D_PREC_F32 (gradients span too many octaves for the float16 split);
+ * data gradients of Conv3D / Dense are those same entries on flipped / transposed weights (dm3d_flip_transpose + dm3d_pack_weights).
+ * What follows is what training needs in addition.  All tensors float32; "+=" outputs are accumulated into (the caller zeroes
+ * gradient buffers once per step: a weight used twice, or a tensor with two consumers, collects both contributions). */
+
+/* BatchNormalization(training=True) (network(..., training=True), :493): per-channel batch statistics over (B,D,H,W).
+ * dm3d_groupnorm_stats (above) accumulates per-(sample, channel) sums into acc [batch][c][2] (float64, zero on entry; call it once per
+ * concatenated input with its channel offset); this finishes them: mean, biased variance -> scale = gamma*rstd, shift = beta - mean*scale
+ * (the vectors the conv prologue / dm3d_affine_act_cat apply), mean_out / rstd_out kept for the backward pass, and — when
+ * moving_mean / moving_var are given — the Keras moving averages moving = moving*momentum + batch*(1 - momentum) (momentum 0.99;
+ * unbiased_moving = 1 feeds the variance with Bessel's correction n/(n-1), as tf.nn.fused_batch_norm — what Keras runs for rank-5
+ * inputs — does).  acc is zeroed again. */
+int dm3d_batchnorm_finalize(double* acc, int32_t batch, int64_t voxels, int32_t c, float eps, const float* gamma, const float* beta,
+                            float* scale, float* shift, float* mean_out, float* rstd_out, float* moving_mean, float* moving_var,
+                            float momentum, int32_t unbiased_moving, void* stream);
+/* y[row][:] = act(concat(x1[row], x2[row]) * scale + shift)  (x2 NULL / c2 0: one input; scale NULL: plain concatenation).
+ * y is [rows][c1+c2]: the normalised, activated, concatenated tensor a training step keeps for the weight gradient. */
+int dm3d_affine_act_cat(const float* x1, int32_t c1, const float* x2, int32_t c2, int64_t rows, const float* scale, const float* shift,
+                        int32_t act, float* y, void* stream);
+/* Backward of y = act(BatchNorm_train(concat(x1, x2))) given g = dL/dy [rows][c1+c2]: du = g*act'(x*scale+shift);
+ * red[c][2] (float64, zero on entry) receives (sum du, sum du*xhat);  dx (+=) = scale*(du - mean(du) - xhat*mean(du*xhat)) written
+ * to dx1 / dx2 (either NULL: no gradient wanted);  dgamma (+=) = sum du*xhat, dbeta (+=) = sum du (both or neither). */
+int dm3d_bn_act_bwd(const float* g, const float* x1, int32_t c1, const float* x2, int32_t c2, int64_t rows, const float* scale,
+                    const float* shift, const float* mean, const float* rstd, int32_t act, double* red, float* dx1, float* dx2,
+                    float* dgamma, float* dbeta, void* stream);
+
+/* Weight gradient of Conv3D(k in {1,3}, stride 1, "same") / Dense in the Keras layout:  dw[tap][ci][co] += sum over samples and voxels
+ * of a[voxel + tap - 1][ci] * g[voxel][co]  (a: the layer's input [batch, in_d, in_h, in_w, cin]; g: dL/d output, same extent, cout
+ * channels).  A contraction over voxels on v_mfma_f32_32x32x2_f32; partial sums meet through float atomics (dw must hold the running
+ * gradient, zero at the start of a step).  ksize 1 covers Dense (rows = batch*in_d*in_h*in_w).  per_item_output = 1 (ksize 1): `batch`
+ * independent products with their own output each (strides in elements) — the attention gradients dV = P^T dO, dK = dS^T Q per sample.
+ * A stride-2 conv's gradient is this on the dilated output gradient (dm3d_dilate2); an UpSample conv's on the upsampled input. */
+typedef struct dm3d_wgrad_desc {
+    const float* a; const float* g; float* dw;
+    int32_t batch, in_d, in_h, in_w, cin, cout, ksize;
+    int32_t per_item_output; int64_t stride_a, stride_g, stride_dw;
+} dm3d_wgrad_desc;
+int dm3d_wgrad(const dm3d_wgrad_desc* d, void* stream);
+/* out[group][:c] += column sums of x over the group's rows (x [groups*rows_per_group][c]): bias gradients (one group) and the gradient
+ * of the per-sample time-embedding vector a conv epilogue adds (one group per sample, ld_out = row stride of the vector table). */
+int dm3d_colsum(const float* x, int64_t groups, int64_t rows_per_group, int32_t c, float* out, int64_t ld_out, void* stream);
+/* Keras kernel [taps][cin][cout] -> [taps][cout][cin] with the taps reversed: the kernel whose stride-1 "same" convolution of dL/dy is
+ * dL/dx of the original layer (taps 1: the transpose). */
+int dm3d_flip_transpose(const float* keras_kernel, int32_t taps, int32_t cin, int32_t cout, float* out, void* stream);
+
+/* LayerNormalization backward (eps as in the forward): dx += rstd*(dy*gamma - mean(dy*gamma) - xhat*mean(dy*gamma*xhat)),
+ * dgamma += sum dy*xhat, dbeta += sum dy.  c % 4 == 0, c <= 1024. */
+int dm3d_layernorm_bwd(const float* x, int64_t rows, int32_t c, float eps, const float* gamma, const float* dy, float* dx, float* dgamma,
+                       float* dbeta, void* stream);
+/* softmax backward in place: dp <- scale * p * (dp - sum_j p_j dp_j) per row; scale = the factor the logits carried (units^-0.5). */
+int dm3d_softmax_bwd(const float* p, float* dp, int64_t rows, int32_t cols, int64_t ld, float scale, void* stream);
+/* dx = dy * act'(ref): ref = pre-activation (swish) or pre/post alike (ReLU).  dx may alias dy.  n % 4 == 0. */
+int dm3d_act_bwd(const float* ref, const float* dy, float* dx, int64_t n, int32_t act, void* stream);
+int dm3d_axpy(float* dst, const float* src, int64_t n, float alpha, void* stream);          /* dst += alpha*src */
+int dm3d_fill(float* dst, int64_t n, float value, void* stream);
+/* dst[b][j][i] = src[b][i][j]: the K-contiguous copies the TN contraction needs of K / V in the attention backward */
+int dm3d_transpose(const float* src, int32_t rows, int32_t cols, int64_t ld_src, int64_t stride_src, float* dst, int64_t ld_dst,
+                   int64_t stride_dst, int32_t batch, void* stream);
+/* dst[r][dst_off + j] = (accumulate ? dst : 0) + src[r][src_off + j] for j < c: a column window of one row-major matrix into another
+ * (Concatenate, and the split of its gradient).  c, offsets, leading dimensions % 4 == 0. */
+int dm3d_copy_cols(const float* src, int64_t ld_src, int32_t src_off, float* dst, int64_t ld_dst, int32_t dst_off, int64_t rows, int32_t c,
+                   int32_t accumulate, void* stream);
+/* UpSampling3D(2) materialised (its conv then needs a weight gradient over the upsampled tensor), and its backward (8 children summed, +=) */
+int dm3d_upsample2(const float* src, float* dst, int32_t batch, int32_t d, int32_t h, int32_t w, int32_t c, void* stream);
+int dm3d_sumpool2_add(const float* src, float* dst, int32_t batch, int32_t d, int32_t h, int32_t w, int32_t c, void* stream);
+/* dst [batch, id, ih, iw, c] = 0 except dst[2*o + off] = src[o]: the output gradient of a stride-2 conv spread over the input grid
+ * (off = 1 - pad_front per axis), after which data and weight gradients are those of a stride-1 conv. */
+int dm3d_dilate2(const float* src, float* dst, int32_t batch, int32_t od, int32_t oh, int32_t ow, int32_t id, int32_t ih, int32_t iw,
+                 int32_t offz, int32_t offy, int32_t offx, int32_t c, void* stream);
+/* table[idx[r]][:] += src[r][:]  (Embedding gradient, :358) */
+int dm3d_scatter_add_rows(const float* src, const int32_t* idx, int32_t rows, int32_t c, float* table, int32_t table_rows, void* stream);
+/* noisy = sqrt_alpha_bar[t[b]]*latents + sqrt_one_minus_alpha_bar[t[b]]*noise  (:484-490) */
+int dm3d_q_sample(const float* latents, const float* noise, const int32_t* t, const float* sqrt_alpha_bar,
+                  const float* sqrt_one_minus_alpha_bar, int32_t timesteps, float* out, int32_t batch, int64_t per_sample, void* stream);
+/* *loss += sum((noise - pred)^2) * inv_divisor (float64);  dpred = 2*(pred - noise)*inv_divisor (or NULL).  With
+ * inv_divisor = 1/(channels * global_bs * lc^4) this is keras MeanSquaredError(reduction=SUM) / loss_reduction_factor (:496-499). */
+int dm3d_mse_loss_grad(const float* pred, const float* noise, int64_t n, double inv_divisor, double* loss, float* dpred, void* stream);
+/* keras.optimizers.Adam step over a flat parameter buffer: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; w -= lr_t*m/(sqrt(v)+eps),
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (the host supplies it; Keras defaults b1 0.9, b2 0.999, eps 1e-7). */
+int dm3d_adam(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2, float eps, void* stream);
 
 /* ---- HIP graph capture of one denoising step (replaces the eager per-op Python loop of generate, :559-573) -- */
 int dm3d_graph_begin(void* stream);

@@ -1,5 +1,7 @@
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into per-kernel average HBM bytes per launch.
-usage: python profiles/summarize_pmc.py <fetch_dir> <write_dir> <out.csv> "<header comment>"
+usage: python profiles/summarize_pmc.py <fetch_dir> <write_dir> <out.csv> "<header comment>" ["<workload signature>"]
+The workload signature (bench.py: "batch=.. size=.. channels=.. norm=.. precision=.. csrc=<digest of the kernel sources>") is
+written as a "# workload: ..." line; bench.py attaches roofline.traffic only from a summary whose signature matches its run.
 gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE counts half of the bytes of 16-B/lane coalesced reads, so
 hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024."""
 import collections
@@ -14,14 +16,14 @@ def short(name: str) -> str:
     return (m.group(1) + (m.group(2) or "")) if m else name[:60]
 
 
-def main(fetch_dir, write_dir, out_path, comment):
+def main(fetch_dir, write_dir, out_path, comment, workload=None):
     agg = collections.defaultdict(lambda: {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]})
     for d in (fetch_dir, write_dir):
         for r in csv.DictReader(open(f"{d}/pmc_counter_collection.csv")):
             a = agg[short(r["Kernel_Name"])][r["Counter_Name"]]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
-    lines = ["# " + comment, "kernel,launches,avg_FETCH_SIZE_KB,avg_WRITE_SIZE_KB,avg_hbm_MB_per_launch_corrected"]
+    lines = ["# " + comment] + (["# workload: " + workload] if workload else []) + ["kernel,launches,avg_FETCH_SIZE_KB,avg_WRITE_SIZE_KB,avg_hbm_MB_per_launch_corrected"]
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["FETCH_SIZE"][1]):
         f = v["FETCH_SIZE"][1] / max(v["FETCH_SIZE"][0], 1)
         w = v["WRITE_SIZE"][1] / max(v["WRITE_SIZE"][0], 1)
@@ -31,4 +33,4 @@ def main(fetch_dir, write_dir, out_path, comment):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol(built_library):
         assert hasattr(handle, name), f"{name} declared in include/dm3d.h but not exported"
     from dm3d_amd import _lib
     assert set(_lib.SIGNATURES) == declared
-    assert _lib.lib().dm3d_version() == _lib.ABI_VERSION == 105
+    assert _lib.lib().dm3d_version() == _lib.ABI_VERSION == 106
     assert _lib.lib().dm3d_packed_weight_elems(27, 96, 64) == 27 * 64 * 96
     assert _lib.lib().dm3d_packed_weight_elems(1, 8, 8) == 64 * 16
 
@@ -160,7 +160,9 @@ def test_drop_in_signatures():
     assert list(g)[1:4] == ["shape", "last_step", "context_value"] and g["shape"].default == (1, 16, 16, 16, 16)
     assert list(inspect.signature(conditional_dm3d.DiffusionModel.sample).parameters)[1:] == \
         ["x_t", "pred_noise", "curr_time_step", "shape"]
-    assert list(inspect.signature(conditional_dm3d.DiffusionModel.train_step).parameters)[1:] == ["inputs"]
+    ts = inspect.signature(conditional_dm3d.DiffusionModel.train_step).parameters
+    assert [n for n, q in ts.items() if q.kind == q.POSITIONAL_OR_KEYWORD][1:] == ["inputs"]
+    assert {n for n, q in ts.items() if q.kind == q.KEYWORD_ONLY} == {"t", "noise", "latents"}          # extensions are keyword-only
     assert conditional_dm3d.first_conv_channels == 32 and dm3d.first_conv_channels == 64
     with pytest.raises(ValueError):
         conditional_dm3d.build_model(8, 4, [64, 128, 256], [False, False, True], has_cross_attention=[True], context_dim=0)
@@ -168,8 +170,11 @@ def test_drop_in_signatures():
                                         device="cpu")
     assert m.timesteps == 7 and m.lc == 4 and m.global_bs == 3 and m.b.beta.shape == (7,) and m.metrics[0].name == "loss"
     assert m.network.cfg.widths == (64, 128, 256) and m._vqvae is None      # the VQ-VAE bracket is built lazily
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="images"):
         m.train_step((None, None, None))
+    from dm3d_amd import _lib
+    with pytest.raises(_lib.Dm3dError):                       # no device here: the training path has no CPU fallback either
+        m.train_step((None, None, [[[1]]]), latents=np.zeros((1, 8, 8, 8, 4), np.float32), t=[0], noise=np.zeros((1, 8, 8, 8, 4), np.float32))
 
 
 def test_walk_block_order_and_plan_shapes():
@@ -213,12 +218,39 @@ assert parallel.env_rank() == (rank, rank, 2)
 lo, hi = parallel.shard_range(7, rank, world)
 assert (lo, hi) == ((0, 4) if rank == 0 else (4, 7))
 assert parallel.max_over_ranks(1.0 + rank) == 2.0
+assert parallel.gather_strings(f"r{rank}") == ["r0", "r1"]
+assert parallel.state_digest(got) == parallel.state_digest(ref) != parallel.state_digest({**ref, "x": np.ones(1, np.float32)})
+
+class FakeModel:                       # records what generate_sharded asks of DiffusionModel.generate (no GPU here)
+    device = torch.device("cpu")
+    def generate(self, shape, last_step=0, context_value=None, *, seed=None, **kw):
+        self.call = (tuple(shape), last_step, None if context_value is None else np.asarray(context_value).reshape(-1).tolist(), seed, kw)
+        out = torch.empty(shape, dtype=torch.float32)
+        for i in range(shape[0]):
+            out[i] = 1000 * seed + i + 0.5 * float(np.asarray(context_value).reshape(-1)[i if np.asarray(context_value).size > 1 else 0])
+        return out
+
+m = FakeModel()
+full = parallel.generate_sharded(m, (5, 2, 2, 2, 4), 0, [0, 1, 0, 1, 1], seed=7, use_graph=False)
+lo, hi = parallel.shard_range(5, rank, world)
+assert m.call == ((hi - lo, 2, 2, 2, 4), 0, [0, 1, 0, 1, 1][lo:hi], 7 + rank, {"use_graph": False})
+want = torch.tensor([7000.0, 7001.5, 7002.0, 8000.5, 8001.5])          # rank 0: volumes 0-2 (key 7), rank 1: volumes 3-4 (key 8)
+assert full.shape == (5, 2, 2, 2, 4) and torch.equal(full[:, 0, 0, 0, 0], want)
+local = parallel.generate_sharded(m, (5, 2, 2, 2, 4), 0, 1, seed=7, gather=False)
+assert local.shape[0] == hi - lo and m.call[2] == [1]
+one = parallel.generate_sharded(m, (1, 2, 2, 2, 4), 0, 0, seed=3)               # fewer volumes than ranks: rank 1's shard is empty
+assert one.shape[0] == 1 and float(one[0, 0, 0, 0, 0]) == 3000.0
+try:
+    parallel.generate_sharded(m, (5, 2, 2, 2, 4), 0, [0, 1], seed=7)
+    raise SystemExit("a context list of the wrong length was accepted")
+except ValueError:
+    pass
 dist.barrier(); dist.destroy_process_group()
 print("ok", rank)
 """
 
 
-def test_weight_broadcast_world_size_2_gloo(tmp_path):
+def test_weight_broadcast_and_sharded_generate_world_size_2_gloo(tmp_path):
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
     port = str(29500 + os.getpid() % 2000)

@@ -61,6 +61,7 @@ s=must(s, """                    } else {
                 }
             }
         }
+        if (p.range_flag && amax > rlim) *p.range_flag = 1;
         return;
     }""","""                    } else {
                         outz[o] = v;
@@ -68,6 +69,7 @@ s=must(s, """                    } else {
                 }
             }
         }
+        if (p.range_flag && amax > rlim) *p.range_flag = 1;
         STAMP(29);
         return;
     }""")
@@ -107,9 +109,11 @@ s=must(s, """    const bool full = m0 + TM <= p.m && n0 + NT <= p.n;
 s=must(s, """    } else {
         if (p.out_h2) epilogue(no, yes); else epilogue(no, no);
     }
+    if (p.range_flag && amax > p.range_limit) *p.range_flag = 1;
 }""","""    } else {
         if (p.out_h2) epilogue(no, yes); else epilogue(no, no);
     }
+    if (p.range_flag && amax > p.range_limit) *p.range_flag = 1;
     STAMP(11);
 }""")
 build(s, '_gst.hip', 'dm3d_gemm_h3.o', 'variants/gst.so')
