@@ -316,12 +316,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) v[r] += rv2[r];
                 }
+                {   // range guard: a tree (depth 4) instead of a 16-long dependent chain; rows / columns past the edge of a partial
+                    // tile hold bias + residual of clamped addresses — ordinary magnitudes, so they are not masked
+                    float t8[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) { t8[r] = 0.0f; DM3D_AMAX(t8[r], v[r]); DM3D_AMAX(t8[r], v[r + 8]); }
+                    const float t = fmaxf(fmaxf(fmaxf(t8[0], t8[1]), fmaxf(t8[2], t8[3])), fmaxf(fmaxf(t8[4], t8[5]), fmaxf(t8[6], t8[7])));
+                    amax = fmaxf(amax, t);
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = lrow + mr * 32 + (r & 3) + 8 * (r >> 2);
                     const float o = v[r];
                     const bool ok = FULL || (n_ok && m0 + row < p.m);
-                    if (FULL) DM3D_AMAX(amax, o); else DM3D_AMAX(amax, ok ? o : 0.0f);
                     if (H2) {
                         const unsigned int mine = split1_bits(o);
                         const unsigned int oth = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, false);   // lane ^ 1

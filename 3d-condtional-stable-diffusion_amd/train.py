@@ -274,12 +274,12 @@ class Trainer:
         def bwd():
             if out.g is None:
                 return
+            ptr = [st[i].data_ptr() for i in range(4)]          # (keeps st — scale, shift, mean, rstd — alive until the backward pass)
             red = torch.zeros(ct * 2, dtype=torch.float64, device=dev)
             dx1 = x1.grad_buffer().data_ptr() if x1.needs_grad else None
             dx2 = x2.grad_buffer().data_ptr() if (x2 is not None and x2.needs_grad) else None
             check(lib().dm3d_bn_act_bwd(out.g.data_ptr(), x1.v.data_ptr(), c1, x2p, c2, rows, ptr[0], ptr[1], ptr[2], ptr[3], act,
                                         red.data_ptr(), dx1, dx2, pg.g.data_ptr(), pb.g.data_ptr(), _st()), "bn_act_bwd")
-            out._keep = (st, red)
 
         self.tape.append(bwd)
         return out
@@ -355,6 +355,8 @@ class Trainer:
     def attention(self, q: Var, k: Var, v: Var, B: int, L: int, Lk: int, u: int) -> Var:
         """softmax(q k^T * u^-0.5) v per sample (conditional_dm3d.py:171-180; dm3d.py:51-61).  q [B*L, u]; k, v [B*Lk, u]."""
         dev, scale = self.device, float(u) ** -0.5
+        if L % 4 or Lk % 4:
+            raise ValueError(f"attention over {L} x {Lk} tokens: the contractions run on the MFMA GEMM, which needs D*H*W % 4 == 0 at attention levels")
         P = _empty(B * L, Lk, device=dev)
         self._gemm(q.v, u, k.v, u, L, Lk, u, out=P, ldo=Lk, batch=B, stride_a=L * u, stride_b=Lk * u, stride_o=L * Lk, alpha=scale)
         check(lib().dm3d_softmax_rows(P.data_ptr(), B * L, Lk, Lk, _st()), "softmax")
