@@ -632,3 +632,87 @@ def vq_decoder(W, cfg: VQVAEConfig, z):
         if i != n - 1:
             h = torch.relu(h)
     return torch.relu(h) if cfg.output_act else h
+
+
+# ==============================================================================================================
+# BASELINE config 5 names the OTHER autoencoder, reference networks/vqgan.py (abbreviated G:): Encoder G:287-375, Decoder G:378-475,
+# VQVAEResidualUnit G:257-284, VectorQuantizer G:151-216, wired by VQGAN.call G:699-703 on x = concat[img, mask] (G:726-727) and
+# built by main_exp_vqgan.py:23-38 (one (stride 2, k 4, "same") level per channel_list entry, in/out channels 2).  It differs from
+# the monai VQ-VAE above by a BatchNormalization + PReLU after every strided conv (G:317-341), a BatchNormalization after the
+# decoder's first conv (G:415-416) and after every Conv3DTranspose (G:457), PReLU (not ReLU) between decoder levels (G:459-467).
+# ==============================================================================================================
+def vqgan_param_spec(cfg: VQVAEConfig) -> Dict[str, Tuple[int, ...]]:
+    base = vqvae_param_spec(cfg)
+    n = len(cfg.num_channels)
+    rev = list(reversed(cfg.num_channels))
+    spec: Dict[str, Tuple[int, ...]] = {}
+    for name, shape in base.items():
+        spec[name] = shape
+        for i in range(n):
+            if name == f"enc.down{i}.bias":
+                _bn(spec, f"enc.down{i}.bn", cfg.num_channels[i])
+                e = cfg.input_size >> (i + 1)
+                spec[f"enc.down{i}.prelu.alpha"] = (e, e, e, cfg.num_channels[i])
+            if name == f"dec.up{i}.bias":
+                out = cfg.out_channels if i == n - 1 else rev[i + 1]
+                _bn(spec, f"dec.up{i}.bn", out)
+                if i != n - 1:
+                    e = cfg.latent_size << (i + 1)
+                    spec[f"dec.up{i}.prelu.alpha"] = (e, e, e, out)
+        if name == "dec.in.bias":
+            _bn(spec, "dec.in.bn", rev[0])
+    return spec
+
+
+def vqgan_synthetic_weights(cfg: VQVAEConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    g = np.random.default_rng(seed)
+    out = {}
+    for name, shape in vqgan_param_spec(cfg).items():
+        if name.endswith(".kernel"):
+            rf = int(np.prod(shape[:3]))
+            lim = math.sqrt(6.0 / (shape[3] * rf + shape[4] * rf))
+            arr = g.uniform(-lim, lim, size=shape)
+        elif name.endswith(".alpha"):
+            arr = g.uniform(0.05, 0.45, size=shape)
+        elif name.endswith(".embeddings"):
+            arr = g.normal(0.0, 1.0, size=shape)
+        elif name.endswith(".gamma"):
+            arr = g.uniform(0.8, 1.2, size=shape)
+        elif name.endswith(".var"):
+            arr = g.uniform(0.5, 1.5, size=shape)
+        elif name.endswith((".beta", ".mean")):
+            arr = g.normal(0.0, 0.1, size=shape)
+        elif name.endswith(".bias"):
+            arr = g.normal(0.0, 0.05, size=shape)
+        else:
+            raise KeyError(name)
+        out[name] = torch.from_numpy(arr.astype(np.float32))
+    return out
+
+
+def vqgan_encoder(W, cfg: VQVAEConfig, x):
+    """G:317-369: per level Conv3D(k4,s2,same) -> BatchNormalization -> PReLU -> res units; then Conv3D(k3) -> PReLU."""
+    h = x
+    for i in range(len(cfg.num_channels)):
+        h = _conv3d_k4s2(h, W[f"enc.down{i}.kernel"], W[f"enc.down{i}.bias"])
+        h = _prelu(_bn_infer(h, W, f"enc.down{i}.bn"), W[f"enc.down{i}.prelu.alpha"])
+        for j in range(cfg.num_res_layers):
+            h = vq_residual_unit(W, f"enc.l{i}.res{j}", h)
+    h = _conv3d(h, W["enc.out.kernel"], W["enc.out.bias"])
+    return _prelu(h, W["enc.out_prelu.alpha"])
+
+
+def vqgan_decoder(W, cfg: VQVAEConfig, z):
+    """G:415-470: Conv3D(k3) -> BatchNormalization -> PReLU; per level res units -> Conv3DTranspose(k4,s2,same) -> BatchNormalization
+    [-> PReLU unless last]; optional output ReLU."""
+    h = _conv3d(z, W["dec.in.kernel"], W["dec.in.bias"])
+    h = _prelu(_bn_infer(h, W, "dec.in.bn"), W["dec.in_prelu.alpha"])
+    n = len(cfg.num_channels)
+    for i in range(n):
+        for j in range(cfg.num_res_layers):
+            h = vq_residual_unit(W, f"dec.l{i}.res{j}", h)
+        h = _conv3d_transpose_k4s2(h, W[f"dec.up{i}.kernel"], W[f"dec.up{i}.bias"])
+        h = _bn_infer(h, W, f"dec.up{i}.bn")
+        if i != n - 1:
+            h = _prelu(h, W[f"dec.up{i}.prelu.alpha"])
+    return torch.relu(h) if cfg.output_act else h

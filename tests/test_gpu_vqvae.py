@@ -118,3 +118,75 @@ def test_diffusion_model_owns_the_bracket(dev):
     assert tuple(img.shape) == (1, 128, 128, 128, 1) and torch.isfinite(img).all()
     assert tuple(q.shape) == (1, 8, 8, 8, 8) and m.vqvae_trainer.num_embeddings == 64
     assert m.vqvae_trainer.input_size == 128 and sum(int(np.prod(v)) for v in m.vqvae_trainer.spec.values()) > 50e6
+
+
+def _vqgan(cfg, W, prec, dev):
+    from dm3d_amd.networks.vqgan import VQGAN
+    n = len(cfg.num_channels)
+    return VQGAN(cfg.in_channels, cfg.out_channels, cfg.num_channels, cfg.num_res_layers, cfg.num_res_channels,
+                 downsample_parameters=[(2, 4, 1, "same")] * n, upsample_parameters=[(2, 4, 1, "same", 0)] * n,
+                 num_embeddings=cfg.num_embeddings, embedding_dim=cfg.embedding_dim, D=cfg.input_size,
+                 weights={k: v.numpy() for k, v in W.items()}, precision=prec)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "h3"])
+def test_vqgan_autoencoder_matches_oracle(dev, prec):
+    """networks/vqgan.py Encoder / Decoder (the autoencoder BASELINE config 5 names; vqgan.py:287-475, built as in
+    main_exp_vqgan.py:23-38: 2-channel concat[img, mask] input, one k4/s2 level per channel_list entry): BatchNormalization after
+    every strided / transposed conv folded into its weights, PReLU in the epilogue.  32^3 -> 8^3 -> 32^3."""
+    from oracle import ref_torch as rt
+    cfg = rt.VQVAEConfig(in_channels=2, out_channels=2, num_channels=(16, 32), num_res_layers=2, num_res_channels=(16, 32),
+                         num_embeddings=64, embedding_dim=8, input_size=32)
+    W = rt.vqgan_synthetic_weights(cfg, seed=2)
+    vq = _vqgan(cfg, W, prec, dev)
+    assert list(vq.spec.items()) == list(rt.vqgan_param_spec(cfg).items())
+    g = torch.Generator().manual_seed(9)
+    img, mask = torch.rand(2, 32, 32, 32, 1, generator=g), (torch.rand(2, 32, 32, 32, 1, generator=g) > 0.5).float()
+    x = torch.cat([img, mask], -1)
+    z_ref = rt.vqgan_encoder(W, cfg, x)
+    z = vq.encode_images(img.to(dev), mask.to(dev))
+    assert tuple(z.shape) == (2, 8, 8, 8, 8) and _rel(z, z_ref) < 1e-4
+    assert torch.equal(z, vq.encoder(x.to(dev)))
+    q_ref, perp_ref, idx_ref = rt.vq_quantize(W, z_ref)
+    q, perp = vq.quantizer(z_ref.to(dev))
+    assert (vq.last_indices.cpu().long() != idx_ref).sum() <= 2
+    y_ref = rt.vqgan_decoder(W, cfg, q_ref)
+    y = vq.decoder(q_ref.to(dev))
+    rec, perp2 = vq(x.to(dev))
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (2, 32, 32, 32, 2) and _rel(y, y_ref) < 1e-4
+    assert tuple(rec.shape) == (2, 32, 32, 32, 2) and torch.isfinite(rec).all() and tuple(vq.call_2(x.to(dev)).shape) == (2, 8, 8, 8, 8)
+
+
+def test_config5_end_to_end_vqgan_ddpm(dev):
+    """BASELINE config 5: vqgan.py encode 128^3 (img + mask) -> 32^3 x 8ch latent -> conditional DDPM at 32^3 x 8ch -> decode, B=8, one
+    GPU.  The reference never connects a VQGAN to its DiffusionModel: three stages, generate() from N(0,1).
+    The chain here is T=24 (the full T=1000 chain at this shape is timed by tools/e2e_config5.py and bench.py); encoder / decoder
+    outputs are checked against the oracle on the first volume."""
+    from types import SimpleNamespace
+    import dm3d_amd
+    from dm3d_amd.networks import conditional_dm3d as cdm
+    from oracle import ref_torch as rt
+    B = 8
+    cfg = rt.VQVAEConfig(in_channels=2, out_channels=2, num_channels=(32, 64), num_res_layers=2, num_res_channels=(32, 64),
+                         num_embeddings=256, embedding_dim=8, input_size=128)
+    W = rt.vqgan_synthetic_weights(cfg, seed=3)
+    vq = _vqgan(cfg, W, "h3", dev)
+    g = torch.Generator().manual_seed(10)
+    img = torch.rand(B, 128, 128, 128, 1, generator=g)
+    mask = (img > 0.3).float()
+    z = vq.encode_images(img.to(dev), mask.to(dev))
+    lat, perp = vq.quantizer(z)
+    assert tuple(lat.shape) == (B, 32, 32, 32, 8) and torch.isfinite(lat).all() and float(perp) > 1
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    z_ref = rt.vqgan_encoder(W, cfg, torch.cat([img[:1], mask[:1]], -1))
+    assert _rel(z[:1], z_ref) < 1e-4
+    ucfg = dm3d_amd.UNetConfig(img_size=32, img_channels=8)
+    m = cdm.DiffusionModel(32, 256, 8, None, SimpleNamespace(timesteps=24, num_gpus=1, kernel_resize=False, bs=B),
+                           weights=dm3d_amd.synthetic_weights(ucfg, 0))
+    gen = m.generate((B, 32, 32, 32, 8), context_value=1, seed=5)
+    out = vq.decoder(gen)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (B, 128, 128, 128, 2) and torch.isfinite(out).all()
+    y_ref = rt.vqgan_decoder(W, cfg, gen[:1].cpu())
+    assert _rel(out[:1], y_ref) < 1e-4
