@@ -190,3 +190,27 @@ def check(rc: int, what: str = "") -> None:
 def require_device() -> None:
     if not lib().dm3d_device_ok():
         raise Dm3dError("no gfx950 (MI355X) device is visible: the dm3d kernels have no CPU path")
+
+
+# ---- roctx ranges (conv / norm / attn / ddpm-update visible in rocprofv3 --marker-trace timelines) ---------------------
+# Host-side markers only: they cost two library calls per range, so they are off unless DM3D_ROCTX=1 (tools/profile_round.sh sets it for
+# the eager PMC passes; a HIP-graph replay has no host ranges to show).
+_roctx = None
+
+
+def roctx():
+    """(push, pop) callables; no-ops unless DM3D_ROCTX=1 and the roctx library loads."""
+    global _roctx
+    if _roctx is None:
+        _roctx = (lambda name: None, lambda: None)
+        if os.environ.get("DM3D_ROCTX") == "1":
+            for name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):
+                try:
+                    h = C.CDLL(name)
+                    h.roctxRangePushA.argtypes, h.roctxRangePushA.restype = [C.c_char_p], C.c_int
+                    h.roctxRangePop.argtypes, h.roctxRangePop.restype = [], C.c_int
+                    _roctx = (lambda s, h=h: h.roctxRangePushA(s.encode()), lambda h=h: h.roctxRangePop())
+                    break
+                except OSError:
+                    continue
+    return _roctx

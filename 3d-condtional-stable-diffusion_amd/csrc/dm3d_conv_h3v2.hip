@@ -30,21 +30,27 @@ __device__ __forceinline__ int dx_of_row(int i) { return (0x1320 >> ((i >> 2) * 
 
 // MODE 0: float32 input as is; 1: float32 input through the fused norm + SiLU prologue; 2: x1 already activated and split
 // (DM3D_FMT_H2, written by the producing conv's epilogue): staging is two 16-byte copies per voxel and no arithmetic
-template <int KS, int MODE>
-__global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
-    constexpr int TD = 4, TH = 8, TW = 8, CK = 16, NT = 64;
+// TD = z-slices per brick = waves per workgroup (4: 256 threads, two workgroups per CU; 8: 512 threads, one workgroup per CU with 160 KB
+// of LDS to itself).  NBUF = weight-group buffers: 2 = the next group streams in while this one is consumed (one group of lead);
+// 3 = two groups of lead — a 16 KB LDS-DMA fill takes ~1.1 us from issue to landing (MI355X_MICROARCH.md "ldsdma-fill"), longer than
+// one group's 96 MFMAs, so with two buffers every group ended waiting for its successor (in-kernel stamps: ~680 cycles per group).
+// The 8-slice brick also halves the weight bytes streamed per FLOP (eight waves share a group) and trims the halo factor 2.34 -> 1.95.
+template <int KS, int MODE, int TD, int NBUF>
+__global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
+    constexpr int TH = 8, TW = 8, CK = 16, NT = 64, NTHR = TD * 64;
     constexpr int HD = TD - 1 + KS, HH = TH - 1 + KS, HW = TW - 1 + KS, HWP = 12;
     constexpr int HVOX = HD * HH * HW;
     constexpr int TAPS = KS * KS * KS, TAPSP = (TAPS + 3) / 4 * 4;
     constexpr int G = 4, NG = TAPSP / G;                     // taps per weight group (two MFMA k-steps), groups per chunk
-    constexpr int NSLOT = (HVOX * 2 + 255) / 256;
+    constexpr int NSLOT = (HVOX * 2 + NTHR - 1) / NTHR;
     constexpr int WGRP = G * NT * REC;                       // halfs per weight group (16 KB)
-    constexpr int WSLOT = WGRP * 2 / 16 / 256;               // 16-byte pieces per thread = 4
-    static_assert(WGRP * 2 / 16 % 256 == 0, "weight group must be a whole number of pieces per thread");
+    constexpr int WSLOT = WGRP * 2 / 16 / NTHR;              // 16-byte pieces per thread: 4 (256 threads) or 2 (512)
+    static_assert(WGRP * 2 / 16 % NTHR == 0, "weight group must be a whole number of pieces per thread");
+    static_assert(NBUF == 2 || NBUF == 3, "two or three weight buffers");
 
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_v2[];
-    _Float16* lds_w = smem_v2;                  // [2][G][NT][REC]   (first: every weight read is base + a 16-bit immediate)
-    _Float16* lds_in = smem_v2 + 2 * WGRP;      // [HREC][REC]
+    _Float16* lds_w = smem_v2;                  // [NBUF][G][NT][REC]   (first: every weight read is base + a 16-bit immediate)
+    _Float16* lds_in = smem_v2 + NBUF * WGRP;   // [HREC][REC]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
     int gvox[NSLOT], st_off[NSLOT];
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
-        const int hv = (tid >> 1) + j * 128;
+        const int hv = (tid >> 1) + j * (NTHR / 2);
         int g = -1;
         if (hv < HVOX) {
             const int hz = hv / (HH * HW), hy = (hv / HW) % HH, hx = hv % HW;
@@ -103,17 +109,23 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
         for (int ni = 0; ni < 4; ++ni) acc[pi][ni] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     // weights go global -> LDS by LDS-DMA (no registers, no ds_write): the packed image IS the LDS image, so group gg is a
-    // linear 16 KB copy; wave w moves the 1 KB pieces w, w+4, w+8, w+12.  Buffer = gg & 1 (NG is odd for k3: runtime parity).
+    // linear 16 KB copy; wave w moves the 1 KB pieces w, w+TD, ...  Buffer = group index mod NBUF, counted from this workgroup's
+    // first group (NG is odd for k3, so the phase differs from chunk to chunk: a running counter).
     const char* w_img = reinterpret_cast<const char*>(wbase + (size_t)ntile * p.nchunks * NG * WGRP) + wave * 1024 + lane * 16;
-    auto fetch_w = [&](int gg) {
+    auto fetch_w = [&](int gg, int buf) {
         const char* src = w_img + (size_t)gg * (WGRP * 2);
-        char* dst = reinterpret_cast<char*>(lds_w) + (gg & 1) * (WGRP * 2) + wave * 1024;
+        char* dst = reinterpret_cast<char*>(lds_w) + buf * (WGRP * 2) + wave * 1024;
 #pragma unroll
         for (int i = 0; i < WSLOT; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 4096),
-                                             (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * (NTHR * 16)),
+                                             (__attribute__((address_space(3))) void*)(dst + i * (NTHR * 16)), 16, 0, 0);
     };
-    fetch_w(c_lo * NG);
+    const int g_first = c_lo * NG, g_end = c_hi * NG;
+    fetch_w(g_first, 0);
+    // NBUF == 3: every DMA below is issued unconditionally (past the end the last group is fetched again into a free buffer): with
+    // conditional issues hipcc cannot count what is in flight and falls back to vmcnt(0) in front of the halo registers' first use.
+    if (NBUF == 3) fetch_w(g_first + 1 < g_end ? g_first + 1 : g_end - 1, 1);
+    int wb = 0;                                  // buffer of the group about to be consumed
 
     constexpr bool pro = MODE == 1, xh2 = MODE == 2;
     f32x4 raw0[NSLOT], raw1[NSLOT];
@@ -154,6 +166,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
         }
     };
     load_halo(c_lo);
+    // (NBUF == 3) Drain here, with an instruction hipcc's wait-count pass sees: the chunk loop's header otherwise merges "first chunk: the
+    // halo loads are the newest requests" with "later chunks: 7 groups of DMAs were issued behind them" into vmcnt(0) on every iteration.
+    if (NBUF == 3) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
 
     int a_rec = a_rec0;
     for (int ch = c_lo; ch < c_hi; ++ch) {
@@ -178,7 +193,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
                 split8(v0, v1, (in && ok0) ? 65504.0f : 0.0f, (in && ok1) ? 65504.0f : 0.0f, shi[j], slo[j]);
             }
         }
-        __syncthreads();
+        // With weight groups in flight across barriers (NBUF == 3) every barrier is a raw s_barrier behind counted waits:
+        // __syncthreads() would drain the VM counter, i.e. wait for the DMAs that are meant to stay in flight (cdna_hip_programming.md,
+        // "glds with >1 tile in flight across the barrier").
+        if (NBUF == 2) {
+            __syncthreads();
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of the previous halo image are retired
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) {
             if (st_off[j] >= 0) {
@@ -186,20 +210,34 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
                 *reinterpret_cast<h8*>(lds_in + (st_off[j] ^ 16)) = slo[j];
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk's first weight group (issued a group ago)
-        __syncthreads();
+        if (NBUF == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk's first weight group (issued a group ago)
+            __syncthreads();
+        } else {
+            // outstanding, oldest first: [this chunk's first group] [its second group] (the first chunk: + its own halo loads, which the
+            // conversion above already waited for): the first group must have landed; the halo stores must be visible
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
         load_halo(ch + 1 < c_hi ? ch + 1 : ch);
         __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const bool last_group = g + 1 == NG;
-            {
+            if (NBUF == 2) {
                 const int nxt = ch * NG + g + 1;
-                if (nxt < c_hi * NG) fetch_w(nxt);
+                if (nxt < g_end) fetch_w(nxt, wb ^ 1);
+            } else {
+                // group g+2 goes into the buffer group g-1 occupied: every wave is past g-1 (the barrier that opened this iteration)
+                const int nxt = ch * NG + g + 2;
+                const int b2 = wb + 2 >= 3 ? wb - 1 : wb + 2;
+                fetch_w(nxt < g_end ? nxt : g_end - 1, b2);
             }
             __builtin_amdgcn_sched_barrier(0);
-            const _Float16* wbuf = lds_w + ((ch * NG + g) & 1) * WGRP;
+            const _Float16* wbuf = lds_w + wb * WGRP;
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {                            // two tap pairs per group
                 // taps of the pair (compile-time after unrolling); the pad tap (>= TAPS) re-reads the last real tap's voxels
@@ -240,24 +278,40 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (!last_group) __syncthreads();      // the DMA of the next group has landed (vmcnt) and every wave is done with this one
+            wb = wb + 1 == NBUF ? 0 : wb + 1;
+            if (!last_group) {
+                if (NBUF == 2) {
+                    __syncthreads();      // the DMA of the next group has landed (vmcnt) and every wave is done with this one
+                } else {
+                    // group g+1 must have landed; newer than it in the queue: group g+2's DMA and, behind the chunk's first iteration,
+                    // the next chunk's halo loads (issued between the DMAs of g+1 and g+2)
+                    if (g == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT + 2 * NSLOT) : "memory");
+                    else        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT) : "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+            }
         }
     }
+
+    if (NBUF == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the redundant tail fetches: nothing may land in LDS the skip phase reuses
 
     // ---- fused 1x1 conv over a second, raw input (ResidualBlock: out = conv2(...) + Conv3D(width, 1)(x), conditional_dm3d.py:243-248,
     // 268).  K = 32 per MFMA = two 16-channel chunks of the SAME voxel instead of two taps: chunk 2i goes to LDS region 0, chunk
     // 2i+1 to region 1 (brick voxels only, rows padded to 12 records like the halo so the patch reads stay conflict-free), the
     // lane half picks the region.  One pair of chunks = one barrier pair + 48 MFMAs per wave; the next pair's weights (8 KB by
     // LDS-DMA) and voxels (registers) are in flight meanwhile.  Part 0 of a split-K launch carries it.
-    if (p.s_npairs > 0 && khalf == 0) {
+    if constexpr (KS == 3) if (p.s_npairs > 0 && khalf == 0) {     // (the launcher admits a skip conv behind k3 / stride 1 only)
         constexpr int SREC = TD * TH * HWP;                                // 384 records per region
         _Float16* lds_sa = smem_v2;                                        // [2][SREC][REC]            (0 .. 48 KB)
         _Float16* lds_sw = smem_v2 + 2 * SREC * REC;                       // [2 buffers][2][NT][REC]   (48 .. 64 KB)
-        static_assert((2 * SREC * REC + 2 * 2 * NT * REC) * 2 <= (HD * HH * HWP * REC + 2 * WGRP) * 2, "skip phase LDS carve");
+        static_assert((2 * SREC * REC + 2 * 2 * NT * REC) * 2 <= (HD * HH * HWP * REC + NBUF * WGRP) * 2, "skip phase LDS carve");
+        constexpr int SITEMS = TD * TH * TW * 2;                          // 16-byte pieces per region (= 2 * NTHR: four per thread in all)
         int sgv[4], sst[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int item = tid + j * 256, t = item >> 9, iv = (item & 511) >> 1;
+            const int item = tid + j * NTHR, t = item / SITEMS, iv = (item % SITEMS) >> 1;
             const int z = iv >> 6, y = (iv >> 3) & 7, x = iv & 7;
             const bool in = oz0 + z < p.ind && oy0 + y < p.inh && ox0 + x < p.inw;
             sgv[j] = in ? ((b * p.ind + oz0 + z) * p.inh + oy0 + y) * p.inw + ox0 + x : -1;
@@ -269,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
         auto sload = [&](int pp) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int c0 = (pp * 2 + ((tid + j * 256) >> 9)) * CK;
+                const int c0 = (pp * 2 + (tid + j * NTHR) / SITEMS) * CK;
                 const float* src;
                 int ldc, cb;
                 if (c0 < p.sc1) { src = p.sx1; ldc = p.sc1; cb = c0; } else { src = p.sx2; ldc = p.sc2; cb = c0 - p.sc1; }
@@ -283,13 +337,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
             }
         };
         const char* sw_img = reinterpret_cast<const char*>(p.swpk) + (size_t)ntile * p.s_npairs * (2 * NT * REC * 2) + wave * 1024 + lane * 16;
-        auto sdma = [&](int pp) {                                          // 8 KB per pair: two 1 KB pieces per wave
+        auto sdma = [&](int pp) {                                          // 8 KB per pair: 8 / TD pieces of 1 KB per wave
             const char* src = sw_img + (size_t)pp * (2 * NT * REC * 2);
             char* dst = reinterpret_cast<char*>(lds_sw) + (pp & 1) * (2 * NT * REC * 2) + wave * 1024;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 4096),
-                                                 (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+            for (int i = 0; i < 8 / TD; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * (TD * 1024)),
+                                                 (__attribute__((address_space(3))) void*)(dst + i * (TD * 1024)), 16, 0, 0);
         };
         const int sa_rec = (wave * TH + (row & 3)) * HWP + dx_of_row(row) + half * SREC;
         const int sb_hi = b_hi;                                            // same [2 taps][NT][REC] row layout as a main weight pair
@@ -495,24 +549,24 @@ __global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, lo
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[n4 * 4 + threadIdx.x] = 0.f;
 }
 
-template <int KS, int MODE>
+template <int KS, int MODE, int TD, int NBUF>
 int launch_v2(ConvArgs& a, hipStream_t st) {
-    constexpr int HREC = (3 + KS) * (7 + KS) * 12;
-    constexpr size_t lds = (size_t)(HREC * REC + 2 * 4 * 64 * REC) * sizeof(_Float16);
-    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-    a.bd = (a.od + 3) / 4;
+    constexpr int HREC = (TD - 1 + KS) * (7 + KS) * 12;
+    constexpr size_t lds = (size_t)(HREC * REC + NBUF * 4 * 64 * REC) * sizeof(_Float16);
+    static_assert((TD == 4 ? 2 : 1) * lds <= 160 * 1024, "workgroups per CU x LDS");
+    a.bd = (a.od + TD - 1) / TD;
     a.bh = (a.oh + 7) / 8;
     a.bw = (a.ow + 7) / 8;
     static bool attr_set = false;
     if (!attr_set) {
-        DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3v2<KS, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3v2<KS, MODE, TD, NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     // Small grids (the 8^3 level at B = 32 has 64 bricks x 4 channel tiles = one workgroup per CU, i.e. one wave per SIMD with
     // nothing to hide its barriers and LDS latency behind: in-kernel stamps showed 58 % MFMA occupancy inside the tap loop there;
     // at B = 1 that level has 8 workgroups for 256 CUs) split the Cin chunks over several workgroups per brick.
     const bool with_scratch = a.scratch != nullptr;
-    a.ksplit = (a.out_h2 || a.post_scale) ? 1 : dm3d_conv_h3v2_ksplit(a, with_scratch);     // the fused output forms live in the plain epilogue
+    a.ksplit = (TD != 4 || a.out_h2 || a.post_scale) ? 1 : dm3d_conv_h3v2_ksplit(a, with_scratch);     // the fused output forms live in the plain epilogue
     const size_t out_elems = (size_t)a.batch * a.fd * a.fh * a.fw * a.cout;
     a.split_atomic = 0;
     a.split_stride = 0;
@@ -536,7 +590,7 @@ int launch_v2(ConvArgs& a, hipStream_t st) {
         k.range_flag = nullptr;                               // the reduce launch checks the finished values
     }
     dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64 * a.ksplit), a.parity ? 8u : 1u);
-    hipLaunchKernelGGL((conv3d_igemm_h3v2<KS, MODE>), grid, dim3(256), lds, st, k);
+    hipLaunchKernelGGL((conv3d_igemm_h3v2<KS, MODE, TD, NBUF>), grid, dim3(TD * 64), lds, st, k);
     int rc = dm3d_launch_check("conv3d_igemm_h3v2");
     if (rc || !(a.ksplit > 1 && with_scratch && !atomic2)) return rc;
     const long n4 = (long)(out_elems / 4);                    // cout % 4 == 0 is not required of cout: fall back to scalar lanes
@@ -648,10 +702,31 @@ int dm3d_conv_h3v2_ksplit(const ConvArgs& a, bool with_scratch) {
     return best;
 }
 
+// The 8-slice / 512-thread / three-buffer form serves launches with enough bricks to fill the chip at one workgroup per CU; the
+// 4-slice / 256-thread / two-buffer form (two workgroups per CU, Cin splitting for tiny grids) serves the rest.  DM3D_CONV_WIDE=0 forces
+// the narrow form (A/B), DM3D_CONV_WIDE_WGS overrides the threshold.
+// Measured (B = 32, 32^3 x 8ch, per-layer HIP events, tools/layer_profile.py): the wide form is 1-4 % faster on the large-Cin k3 convs
+// (32^3 192->64: 1.627 -> 1.612 ms, 16^3 384->128: 0.808 -> 0.773), 5-9 % slower where a fused skip phase follows (its barriers span
+// eight waves) and 12 % slower on the UpSample parity convs (2 weight groups per chunk: nothing for the deeper ring to run ahead of).
+// DM3D_CONV_WIDE: 0 never, 1 (default) k3 without skip phase, 2 wherever the grid is large enough.
+static bool use_wide(const ConvArgs& a) {
+    static const int mode = [] { const char* e = getenv("DM3D_CONV_WIDE"); return e ? atoi(e) : 1; }();
+    static const long min_wgs = [] { const char* e = getenv("DM3D_CONV_WIDE_WGS"); return e ? atol(e) : 512L; }();
+    if (mode == 0) return false;
+    if (mode == 1 && (a.parity || a.s_npairs > 0)) return false;
+    const long wgs = (long)a.batch * ((a.od + 7) / 8) * ((a.oh + 7) / 8) * ((a.ow + 7) / 8) * (a.coutpad / 64) * (a.parity ? 8 : 1);
+    return wgs >= min_wgs;
+}
+
+template <int KS, int MODE>
+static int launch_any(ConvArgs& a, hipStream_t st) {
+    return use_wide(a) ? launch_v2<KS, MODE, 8, 3>(a, st) : launch_v2<KS, MODE, 4, 2>(a, st);
+}
+
 int dm3d_conv_launch_h3v2(ConvArgs& a, int which, hipStream_t st) {
-    if (which == DM3D_CONV_UP) return a.pscale ? launch_v2<2, 1>(a, st) : launch_v2<2, 0>(a, st);
-    if (a.x_h2) return launch_v2<3, 2>(a, st);
-    return a.pscale ? launch_v2<3, 1>(a, st) : launch_v2<3, 0>(a, st);
+    if (which == DM3D_CONV_UP) return a.pscale ? launch_any<2, 1>(a, st) : launch_any<2, 0>(a, st);
+    if (a.x_h2) return launch_any<3, 2>(a, st);
+    return a.pscale ? launch_any<3, 1>(a, st) : launch_any<3, 0>(a, st);
 }
 
 int64_t dm3d_h3v2_image_bytes(int taps, int cin, int cout) {

@@ -218,6 +218,7 @@ class DiffusionModel:
         tab = self.b.device_tables(dev)
         betas = (tab[BETAS_FIELDS.index("sqrt_alpha_bar")], tab[BETAS_FIELDS.index("sqrt_one_minus_alpha_bar")])
         loss, _ = tr.loss_and_grad(latents, t, noise, ids, betas, T, self.global_bs, self.lc)
+        tr.allreduce_grads()                       # data-parallel replicas (one process per GPU): one flat RCCL all-reduce; no-op alone
         tr.adam_step()
         self._trainer_dirty = True
         self.loss_tracker.update_state(float(loss.item()))
@@ -422,8 +423,11 @@ class Sampler:
 
     def _enqueue(self, st, desc):
         self.plan.run(st)
+        push, pop = _lib.roctx()
+        push("ddpm")
         check(lib().dm3d_ddpm_update(C.byref(desc), st), "ddpm_update")
         check(lib().dm3d_add_i32(self.plan.t_idx.data_ptr(), self.plan.B, -1, st), "add_i32")
+        pop()
 
     def prepare(self):
         """Capture the step graph now (setup cost: the first step() otherwise pays for it)."""

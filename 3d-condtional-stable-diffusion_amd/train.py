@@ -588,6 +588,15 @@ class Trainer:
         self._cache = {}
         return loss, pred.v
 
+    def allreduce_grads(self):
+        """Data-parallel training (what MirroredStrategy(cross_device_ops=ReductionToOneDevice()) does for the reference,
+        main_conditional_dm.py:87): SUM the gradients over the ranks — the loss is already divided by the GLOBAL batch
+        (conditional_dm3d.py:496-499), and BatchNormalization statistics stay per replica as in Keras.  The flat gradient buffer
+        is the bucket: one all-reduce (RCCL over xGMI under backend "nccl") per step.  No-op without a process group."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+
     def adam_step(self):
         """keras.optimizers.Adam.apply_gradients over the flat buffers (one launch)."""
         self.step_count += 1

@@ -820,12 +820,27 @@ class Plan:
                 check(lib().dm3d_gather_rows(tab.data_ptr(), tab.shape[0], ids.data_ptr(), buf.data_ptr(), buf.shape[0],
                                              buf.shape[1], st), "gather_rows")
 
+    _RANGE_OF = {"conv_k1": "conv", "conv_k3s2": "conv", "conv_up": "conv", "conv_k3s1_n32": "conv", "conv_k3s1_h2in": "conv", "conv_k3s1": "conv",
+                 "gemm": "attn", "gemm_h3": "attn", "softmax": "attn", "layernorm": "attn", "groupnorm": "norm", "affine": "norm",
+                 "range": "guard"}
+
     def run(self, stream: Optional[int] = None):
         st = _stream() if stream is None else stream
+        push, pop = _lib.roctx()
+        cur = None
         for fn, args, what, _ in self.ops:
+            rng = self._RANGE_OF.get(what, what)
+            if rng != cur:                              # consecutive launches of one family share a range (no-ops unless DM3D_ROCTX=1)
+                if cur is not None:
+                    pop()
+                push(rng)
+                cur = rng
             rc = fn(*args, st)
             if rc != 0:
+                pop()
                 check(rc, what)
+        if cur is not None:
+            pop()
 
     def run_timed(self):
         """Eager run on the current stream with a HIP event pair around every launch.
