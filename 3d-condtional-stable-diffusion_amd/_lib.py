@@ -98,6 +98,7 @@ SIGNATURES = {
     "dm3d_conv_weight_layout": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "dm3d_attention_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "dm3d_attention": (C.c_int, [C.POINTER(AttentionDesc), C.c_void_p, C.c_void_p]),
+    "dm3d_attention_group": (C.c_int, [C.POINTER(AttentionDesc), C.c_int32, C.c_void_p, C.c_void_p]),
     "dm3d_packed_weight_up_elems": (C.c_int64, [C.c_int32, C.c_int32]),
     "dm3d_pack_weights_up": (C.c_int, [_f32p, C.c_int32, C.c_int32, _f32p, C.c_void_p]),
     "dm3d_packed_weight_up_h3_bytes": (C.c_int64, [C.c_int32, C.c_int32]),

@@ -145,8 +145,24 @@ extern "C" int64_t dm3d_attention_workspace_bytes(int32_t batch, int32_t lq, int
     return (int64_t)batch * lq * dm3d_round_up(lk, 16) * (int64_t)sizeof(float);
 }
 
+int dm3d_attention_fused_launch(const dm3d_attention_desc* descs, int count, hipStream_t st);      // dm3d_attn_h3.hip
+
+extern "C" int dm3d_attention_group(const dm3d_attention_desc* descs, int32_t count, void* scratch, void* stream) {
+    DM3D_REQUIRE(descs != nullptr && count >= 1 && count <= 4, "attention_group: count %d not in [1,4]", count);
+    const int rc = dm3d_attention_fused_launch(descs, count, static_cast<hipStream_t>(stream));
+    if (rc != DM3D_EUNSUPPORTED) return rc;
+    for (int i = 0; i < count; ++i)                       // the three-launch form, one pass after the other on the shared scratch
+        if (int r = dm3d_attention(&descs[i], scratch, stream)) return r;
+    return DM3D_OK;
+}
+
 extern "C" int dm3d_attention(const dm3d_attention_desc* d, void* scratch, void* stream) {
-    DM3D_REQUIRE(d != nullptr && scratch != nullptr, "attention: null descriptor or scratch");
+    DM3D_REQUIRE(d != nullptr, "attention: null descriptor");
+    {
+        const int rc = dm3d_attention_fused_launch(d, 1, static_cast<hipStream_t>(stream));
+        if (rc != DM3D_EUNSUPPORTED) return rc;
+    }
+    DM3D_REQUIRE(scratch != nullptr, "attention: this shape runs as score product + softmax + P.V and needs scratch");
     DM3D_REQUIRE(d->q && d->k && d->vt && d->out, "attention: q/k/vt/out must be non-null");
     DM3D_REQUIRE(d->batch > 0 && d->lq > 0 && d->lk > 0 && d->c > 0, "attention: non-positive extent");
     DM3D_REQUIRE(d->fmt == DM3D_FMT_F32 || (d->fmt == DM3D_FMT_H2 && d->precision == DM3D_PREC_H3), "attention: H2 operands need precision H3");

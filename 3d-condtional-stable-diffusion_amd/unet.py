@@ -752,23 +752,40 @@ class Plan:
         kctx, vctx_t = self._buf(rows, L * u), self._buf(rows, u * L)
         self.ctx_bufs[n] = (kctx, vctx_t)
         ks, vs = (L * u, u * L) if self.per_sample_context else (0, 0)
-        scores = self._buf(2, B, L, L)
-        s2 = B * L * L                                                        # element offset of the cross-attention scores
-        scale = float(u) ** -0.5
-        self._gemm_group([
-            dict(a=qkb, lda=2 * u, stride_a=L * 2 * u, b=qkb, b_off=u, ldb=2 * u, stride_b=L * 2 * u, out=scores, ldo=L,
-                 stride_o=L * L, m=L, n=L, k=u, batch=B, alpha=scale, **hh),
-            dict(a=q2, lda=u, stride_a=L * u, b=kctx, ldb=u, stride_b=ks, out=scores, out_off=s2, ldo=L, stride_o=L * L,
-                 m=L, n=L, k=u, batch=B, alpha=scale, **hh),
-        ])
-        self.ops.append((lib().dm3d_softmax_rows_h2, (scores.data_ptr(), 2 * B * L, L, L), "softmax", {}))
         a1, a2 = self._buf(M, u), self._buf(M, u)
-        self._gemm_group([
-            dict(a=scores, lda=L, stride_a=L * L, b=v_t, ldb=M, stride_b=L, out=a1, ldo=u, stride_o=L * u, m=L, n=u, k=L,
-                 batch=B, res=y, ldr=u, stride_r=L * u, **hh),
-            dict(a=scores, a_off=s2, lda=L, stride_a=L * L, b=vctx_t, ldb=L, stride_b=vs, out=a2, ldo=u, stride_o=L * u,
-                 m=L, n=u, k=L, batch=B, **hh),
-        ])
+        scale = float(u) ** -0.5
+        import os
+        if os.environ.get("DM3D_ATTN_FUSED", "1") != "0" and u == 256 and L % 128 == 0:
+            # both attention passes in ONE fused launch (dm3d_attention_group -> csrc/dm3d_attn_h3.hip): scores, online softmax and
+            # P.V per 32-key tile in registers / LDS; no [B, L, L] tensor
+            descs = (_lib.AttentionDesc * 2)()
+            for d, (qt, qoff, ldq, kt, koff, ldk, sk, vt, ldv, sv, out, res) in zip(descs, (
+                    (qkb, 0, 2 * u, qkb, u, 2 * u, L * 2 * u, v_t, M, L, a1, y),
+                    (q2, 0, u, kctx, 0, u, ks, vctx_t, L, vs, a2, None))):
+                d.q, d.ldq = _ptr(qt, qoff), ldq
+                d.k, d.ldk, d.stride_k = _ptr(kt, koff), ldk, sk
+                d.vt, d.ldv, d.stride_vt = _ptr(vt), ldv, sv
+                d.out, d.ldo, d.res = _ptr(out), u, _ptr(res)
+                d.batch, d.lq, d.lk, d.c, d.scale, d.precision, d.fmt = B, L, L, u, scale, _lib.PREC_H3, _lib.FMT_H2
+            self._keep.append(descs)
+            self.ops.append((lib().dm3d_attention_group, (descs, 2, None), "attn_fused",
+                             {"desc": f"attn_fused 2 passes B={B} L={L} c={u}", "flops": 2 * 2 * 2.0 * B * L * L * u}))
+        else:
+            scores = self._buf(2, B, L, L)
+            s2 = B * L * L                                                        # element offset of the cross-attention scores
+            self._gemm_group([
+                dict(a=qkb, lda=2 * u, stride_a=L * 2 * u, b=qkb, b_off=u, ldb=2 * u, stride_b=L * 2 * u, out=scores, ldo=L,
+                     stride_o=L * L, m=L, n=L, k=u, batch=B, alpha=scale, **hh),
+                dict(a=q2, lda=u, stride_a=L * u, b=kctx, ldb=u, stride_b=ks, out=scores, out_off=s2, ldo=L, stride_o=L * L,
+                     m=L, n=L, k=u, batch=B, alpha=scale, **hh),
+            ])
+            self.ops.append((lib().dm3d_softmax_rows_h2, (scores.data_ptr(), 2 * B * L, L, L), "softmax", {}))
+            self._gemm_group([
+                dict(a=scores, lda=L, stride_a=L * L, b=v_t, ldb=M, stride_b=L, out=a1, ldo=u, stride_o=L * u, m=L, n=u, k=L,
+                     batch=B, res=y, ldr=u, stride_r=L * u, **hh),
+                dict(a=scores, a_off=s2, lda=L, stride_a=L * L, b=vctx_t, ldb=L, stride_b=vs, out=a2, ldo=u, stride_o=L * u,
+                     m=L, n=u, k=L, batch=B, **hh),
+            ])
         a3 = self._buf(M, u)
         self._gemm(a=hid, lda=4 * u, b=m1.h2, ldb=m1.cin_pad, out=a3, ldo=u, m=M, n=u, k=4 * u, bias=m1.bias, res=a1, res2=a2,
                    ldr=u, out_h2=True, **hh)
@@ -821,7 +838,7 @@ class Plan:
                                              buf.shape[1], st), "gather_rows")
 
     _RANGE_OF = {"conv_k1": "conv", "conv_k3s2": "conv", "conv_up": "conv", "conv_k3s1_n32": "conv", "conv_k3s1_h2in": "conv", "conv_k3s1": "conv",
-                 "gemm": "attn", "gemm_h3": "attn", "softmax": "attn", "layernorm": "attn", "groupnorm": "norm", "affine": "norm",
+                 "gemm": "attn", "gemm_h3": "attn", "attn_fused": "attn", "softmax": "attn", "layernorm": "attn", "groupnorm": "norm", "affine": "norm",
                  "range": "guard"}
 
     def run(self, stream: Optional[int] = None):

@@ -272,6 +272,13 @@ typedef struct dm3d_attention_desc {
 } dm3d_attention_desc;
 int64_t dm3d_attention_workspace_bytes(int32_t batch, int32_t lq, int32_t lk);
 int     dm3d_attention(const dm3d_attention_desc* d, void* scratch, void* stream);
+/* With DM3D_FMT_H2 operands, c == 256, lq % 128 == 0 and lk % 32 == 0 (the reference's 8^3 attention level: L = 512, units 256) the
+ * call above is ONE fused launch: K / V^T stream through LDS in 32-key tiles, the scores and an online softmax (row maximum and sum kept
+ * per query, accumulator rescaled when the maximum moves) live in registers, the [batch, lq, lk] probabilities never reach HBM and
+ * scratch is not touched (it may be NULL).  Other shapes run as score product + row softmax + P.V on scratch.
+ * dm3d_attention_group: up to 4 passes of identical (batch, lq, lk, scale) — the self- and the cross-attention pass of a
+ * CrossAttentionBlock — in one grid (the three-launch form, when needed, runs them one after the other on the shared scratch). */
+int     dm3d_attention_group(const dm3d_attention_desc* descs, int32_t count, void* scratch, void* stream);
 
 /* ---- y = act(x*scale[c] + shift[c]) over the last axis (inference BatchNormalization of AttentionBlock, U:45;
  * swish of the time embedding, :250); scale/shift may be NULL (identity). */

@@ -472,6 +472,47 @@ def test_attention_entry(dev, mode):
         assert _rel(out, ref) < 2e-5, (mode, kb)
 
 
+@pytest.mark.parametrize("B,Lq,Lk,kb,scale_mul", [(2, 512, 512, 2, 1.0), (3, 128, 96, 1, 1.0), (1, 256, 512, 1, 40.0)],
+                         ids=["L512_self", "q128_k96_broadcast", "peaked_softmax"])
+def test_attention_fused_kernel(dev, B, Lq, Lk, kb, scale_mul):
+    """The fused form of dm3d_attention (csrc/dm3d_attn_h3.hip: units 256, H2 operands, lq % 128 == 0, lk % 32 == 0): scores, online
+    softmax over 32-key tiles and P.V in one launch, without scratch, against the float64 oracle and against the three-launch form.
+    "peaked_softmax": a large logit scale makes the running maximum move from tile to tile (the accumulator rescaling path)."""
+    import ctypes as C
+    from dm3d_amd import ops, _lib
+    from dm3d_amd._lib import lib, check
+    from oracle import ref_torch as rt
+    u = 256
+    g = torch.Generator().manual_seed(Lq + Lk)
+    q = torch.randn(B, Lq, u, generator=g) * 0.7
+    k = torch.randn(kb, Lk, u, generator=g) * 0.7
+    v = torch.randn(kb, Lk, u, generator=g)
+    res = torch.randn(B, Lq, u, generator=g)
+    scale = scale_mul * float(u) ** -0.5
+    s = torch.einsum("blc,bLc->blL", q.double(), k.double().expand(B, -1, -1)) * scale
+    ref = torch.einsum("blL,bLc->blc", torch.softmax(s, -1), v.double().expand(B, -1, -1)) + res.double()
+    enc = lambda t: ops.split_h2(t.to(dev).contiguous()).view(*t.shape[:-1], -1)
+    qh, kh, vth = enc(q), enc(k), enc(v.transpose(1, 2).contiguous())
+    out = torch.empty(B, Lq, u, device=dev)
+    d = _lib.AttentionDesc()
+    d.q, d.ldq = qh.data_ptr(), u
+    d.k, d.ldk, d.stride_k = kh.data_ptr(), u, (Lk * u if kb == B and B > 1 else 0)
+    d.vt, d.ldv, d.stride_vt = vth.data_ptr(), Lk, (u * Lk if kb == B and B > 1 else 0)
+    d.out, d.ldo, d.res = out.data_ptr(), u, res.to(dev).data_ptr()
+    resd = res.to(dev)
+    d.res = resd.data_ptr()
+    d.batch, d.lq, d.lk, d.c, d.scale, d.precision, d.fmt = B, Lq, Lk, u, scale, _lib.PREC_H3, _lib.FMT_H2
+    check(lib().dm3d_attention(C.byref(d), None, torch.cuda.current_stream().cuda_stream), "attention")     # no scratch: must be the fused kernel
+    torch.cuda.synchronize()
+    err = _rel(out, ref)
+    print(f"fused attention rel err {err:.2e}")
+    assert err < 2e-5
+    # the three-launch form on the same operands (ops.attention picks it for F32-format operands)
+    out3 = ops.attention(q.to(dev), k.to(dev), v.transpose(1, 2).contiguous().to(dev), scale, res=resd, precision=_lib.PREC_H3, fmt=_lib.FMT_F32)
+    torch.cuda.synchronize()
+    assert _rel(out, out3.cpu()) < 2e-5
+
+
 @pytest.mark.parametrize("rows,c", [(37, 256), (5, 48), (1024, 256), (3, 1024)])
 def test_layernorm3(dev, rows, c):
     from dm3d_amd import ops

@@ -8,7 +8,7 @@ os.chdir(CSRC)
 subprocess.check_call(["make"])
 os.makedirs("variants", exist_ok=True)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I../../include", "-Wno-unused-function", "-ffp-contract=off"]
-OBJS = ["dm3d_api.o", "dm3d_conv.o", "dm3d_conv_h3.o", "dm3d_conv_h3v2.o", "dm3d_gemm.o", "dm3d_gemm_h3.o", "dm3d_elem.o"]
+OBJS = ["dm3d_api.o", "dm3d_conv.o", "dm3d_conv_h3.o", "dm3d_conv_h3v2.o", "dm3d_gemm.o", "dm3d_gemm_h3.o", "dm3d_elem.o", "dm3d_train.o", "dm3d_attn_h3.o"]
 
 
 def build(src_text, tmp_name, replaces, out):
@@ -41,18 +41,26 @@ s=must(s, """    const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;""","""    STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;""",1)
-s=must(s, """    load_halo(c_lo);
+s=must(s, """    if (NBUF == 3) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
 
-    int a_rec = a_rec0;""","""    load_halo(c_lo);
+    int a_rec = a_rec0;""","""    if (NBUF == 3) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
     STAMP(1);
 
     int a_rec = a_rec0;""")
-s=must(s, """        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk's first weight group (issued a group ago)
-        __syncthreads();""","""        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk's first weight group (issued a group ago)
-        __syncthreads();
-        if (ch - c_lo < 12) STAMP(2 + 2 * (ch - c_lo));""")
-s=must(s, """            if (!last_group) __syncthreads();""","""            if (!last_group) __syncthreads();
-            if (last_group && ch - c_lo < 12) STAMP(3 + 2 * (ch - c_lo));""")
+s=must(s, """        load_halo(ch + 1 < c_hi ? ch + 1 : ch);
+        __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {""","""        if (ch - c_lo < 12) STAMP(2 + 2 * (ch - c_lo));
+        load_halo(ch + 1 < c_hi ? ch + 1 : ch);
+        __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {""")
+s=must(s, """            wb = wb + 1 == NBUF ? 0 : wb + 1;
+            if (!last_group) {""","""            wb = wb + 1 == NBUF ? 0 : wb + 1;
+            if (last_group && ch - c_lo < 12) STAMP(3 + 2 * (ch - c_lo));
+            if (!last_group) {""")
 s=must(s, """    // ---- epilogue.  Accumulator register r of tile""","""    STAMP(28);
     // ---- epilogue.  Accumulator register r of tile""")
 s=must(s, """                    } else {
