@@ -95,6 +95,7 @@ SIGNATURES = {
     "dm3d_packed_weight_skip_h3p_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
     "dm3d_pack_weights_skip_h3p": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "dm3d_conv_scratch_bytes": (C.c_int64, [C.POINTER(ConvDesc)]),
+    "dm3d_conv_tile_form": (C.c_int32, [C.POINTER(ConvDesc)]),
     "dm3d_conv_weight_layout": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "dm3d_attention_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "dm3d_attention": (C.c_int, [C.POINTER(AttentionDesc), C.c_void_p, C.c_void_p]),

@@ -330,6 +330,18 @@ extern "C" int dm3d_pack_weights_skip_h3p(const float* keras_kernel, int32_t cin
     return dm3d_pack_skip_h3v2(keras_kernel, cin, cout, w_exp, packed, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int32_t dm3d_conv_tile_form(const dm3d_conv_desc* d) {
+    if (!d || d->precision != DM3D_PREC_H3) return 0;
+    if (dm3d_conv_weight_layout(d->ksize, d->stride, d->upsample, d->transpose, d->cout) != DM3D_WL_PAIR) return 0;
+    ConvArgs a{};
+    const bool par_mode = d->upsample || d->transpose;
+    a.batch = d->batch; a.od = d->in_d; a.oh = d->in_h; a.ow = d->in_w;      // (WL_PAIR convs are stride 1 / parity convs on the input grid)
+    a.coutpad = (int)dm3d_round_up(d->cout, DM3D_COUT_PAD);
+    a.parity = par_mode ? 1 : 0;
+    a.s_npairs = d->skip_wpk ? 1 : 0;
+    return dm3d_conv_h3v2_wide(a) ? 8 : 4;
+}
+
 extern "C" int64_t dm3d_conv_scratch_bytes(const dm3d_conv_desc* d) {
     if (!d || d->precision != DM3D_PREC_H3 || d->batch <= 0 || d->cout <= 0 || d->in_d <= 0 || d->in_h <= 0 || d->in_w <= 0) return 0;
     if (dm3d_conv_weight_layout(d->ksize, d->stride, d->upsample, d->transpose, d->cout) != DM3D_WL_PAIR) return 0;

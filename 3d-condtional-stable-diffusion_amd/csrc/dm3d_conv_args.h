@@ -42,6 +42,7 @@ int dm3d_conv_launch_f32(ConvArgs& a, int which, hipStream_t st);
 int dm3d_conv_launch_h3(ConvArgs& a, int which, hipStream_t st);
 int dm3d_conv_launch_h3v2(ConvArgs& a, int which, hipStream_t st);     // DM3D_WL_PAIR weights; which in {K3S1, UP}
 int dm3d_conv_h3v2_ksplit(const ConvArgs& a, bool with_scratch);
+bool dm3d_conv_h3v2_wide(const ConvArgs& a);            // true: the 8-slice / 512-thread / three-buffer form serves this launch
 int64_t dm3d_h3v2_skip_image_bytes(int cin, int cout);
 int dm3d_pack_skip_h3v2(const float* keras_kernel, int cin, int cout, int w_exp, void* packed, hipStream_t st);       // split factor the launch would choose
 int64_t dm3d_h3v2_image_bytes(int taps, int cin, int cout);

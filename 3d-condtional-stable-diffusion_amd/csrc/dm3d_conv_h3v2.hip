@@ -718,6 +718,8 @@ static bool use_wide(const ConvArgs& a) {
     return wgs >= min_wgs;
 }
 
+bool dm3d_conv_h3v2_wide(const ConvArgs& a) { return use_wide(a); }
+
 template <int KS, int MODE>
 static int launch_any(ConvArgs& a, hipStream_t st) {
     return use_wide(a) ? launch_v2<KS, MODE, 8, 3>(a, st) : launch_v2<KS, MODE, 4, 2>(a, st);

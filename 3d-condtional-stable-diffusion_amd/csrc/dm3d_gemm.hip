@@ -18,6 +18,7 @@ struct GemmArgs {
     const float* bias; int bias_m; int act;
     const float* res; long ldr, sr;
     const float* res2;
+    int ksplit, batch;          // ksplit > 1: grid.z = batch * ksplit, each part contracts a K range and adds into the zeroed output
 };
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_f32(const GemmArgs p) {
@@ -29,7 +30,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32(const GemmArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l32 = lane & 31;
-    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * NT, bz = blockIdx.z;
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * NT, bz = blockIdx.z % p.batch, part = blockIdx.z / p.batch;
+    const int nck = (p.k + CK - 1) / CK;
+    const int k_begin = (int)((long)nck * part / p.ksplit) * CK, k_end = part + 1 == p.ksplit ? p.k : (int)((long)nck * (part + 1) / p.ksplit) * CK;
     const float* A = p.a + (size_t)bz * p.sa;
     const float* B = p.b + (size_t)bz * p.sb;
 
@@ -39,7 +42,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32(const GemmArgs p) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     auto fetch = [&](int k0) {
-        const bool kok = k0 + piece * 4 < p.k;
+        const bool kok = k0 + piece * 4 < k_end;
 #pragma unroll
         for (int j = 0; j < A_SLOTS; ++j) {
             const int m = m0 + row0 + j * 32;
@@ -67,15 +70,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32(const GemmArgs p) {
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) b_lds[nr] = lds_b + (nr * 32 + l32) * LDV;
 
-    fetch(0);
-    for (int k0 = 0; k0 < p.k; k0 += CK) {
+    fetch(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += CK) {
         __syncthreads();                            // previous chunk's MFMAs have read the LDS tiles
 #pragma unroll
         for (int j = 0; j < A_SLOTS; ++j) *reinterpret_cast<f32x4*>(lds_a + (row0 + j * 32) * LDV + piece * 4) = ra[j];
 #pragma unroll
         for (int j = 0; j < B_SLOTS; ++j) *reinterpret_cast<f32x4*>(lds_b + (row0 + j * 32) * LDV + piece * 4) = rb[j];
         __syncthreads();
-        if (k0 + CK < p.k) fetch(k0 + CK);
+        if (k0 + CK < k_end) fetch(k0 + CK);
         dm3d_mma_step<MR, NR, CK>(acc, a_lds, b_lds, half);
     }
 
@@ -86,7 +89,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32(const GemmArgs p) {
     for (int nr = 0; nr < NR; ++nr) {
         const int n = n0 + nr * 32 + l32;
         if (n >= p.n) continue;
-        const float bn = (p.bias && !p.bias_m) ? p.bias[n] : 0.0f;
+        const bool lead = part == 0;                    // split-K: part 0 carries bias and residuals
+        const float bn = (p.bias && !p.bias_m && lead) ? p.bias[n] : 0.0f;
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
 #pragma unroll
@@ -94,11 +98,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32(const GemmArgs p) {
                 const int m = m0 + wave * 64 + mr * 32 + dm3d_acc_row(r, half);
                 if (m < p.m) {
                     float v = acc[mr][nr][r] * p.alpha + bn;
-                    if (p.bias && p.bias_m) v += p.bias[m];
+                    if (p.bias && p.bias_m && lead) v += p.bias[m];
                     v = dm3d_act(v, p.act);
-                    if (R) v += R[(size_t)m * p.ldr + n];
-                    if (R2) v += R2[(size_t)m * p.ldr + n];
-                    O[(size_t)m * p.ldo + n] = v;
+                    if (R && lead) v += R[(size_t)m * p.ldr + n];
+                    if (R2 && lead) v += R2[(size_t)m * p.ldr + n];
+                    if (p.ksplit > 1) unsafeAtomicAdd(&O[(size_t)m * p.ldo + n], v);
+                    else O[(size_t)m * p.ldo + n] = v;
                 }
             }
         }
@@ -108,6 +113,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32(const GemmArgs p) {
 }  // namespace
 
 int dm3d_gemm_h3_launch(const dm3d_gemm_desc* d, hipStream_t st);     // dm3d_gemm_h3.hip
+extern "C" int dm3d_fill(float* dst, int64_t n, float value, void* stream);    // dm3d_train.hip
 
 extern "C" int dm3d_gemm_tn(const dm3d_gemm_desc* d, void* stream) {
     DM3D_REQUIRE(d != nullptr, "gemm: null descriptor");
@@ -134,7 +140,19 @@ extern "C" int dm3d_gemm_tn(const dm3d_gemm_desc* d, void* stream) {
     a.m = d->m; a.n = d->n; a.k = d->k; a.alpha = d->alpha;
     a.bias = d->bias; a.bias_m = d->bias_along_m; a.act = d->act;
     a.res = d->res; a.ldr = d->ldr; a.sr = d->stride_r; a.res2 = d->res2;
-    dim3 grid((unsigned)((d->m + 255) / 256), (unsigned)((d->n + 63) / 64), (unsigned)d->batch);
+    // A long contraction feeding a handful of tiles (the data gradient of ContextMLP's Dense(h*w*d*c): m = batch, n = 128, k = 131072)
+    // would leave the chip idle behind a few serial K loops: split K over workgroups that add into the zeroed output (linear epilogues only)
+    a.ksplit = 1; a.batch = d->batch;
+    const long tiles = (long)((d->m + 255) / 256) * ((d->n + 63) / 64) * d->batch;
+    if (tiles < 128 && d->k >= 8192 && d->act == DM3D_ACT_NONE && d->batch == 1 && d->ldo == d->n && d->res != d->out) {
+        long ks = 512 / tiles;
+        if (ks > d->k / 1024) ks = d->k / 1024;
+        if (ks > 1) {
+            a.ksplit = (int)ks;
+            if (int rc = dm3d_fill(d->out, (int64_t)d->m * d->n, 0.0f, stream)) return rc;
+        }
+    }
+    dim3 grid((unsigned)((d->m + 255) / 256), (unsigned)((d->n + 63) / 64), (unsigned)(d->batch * a.ksplit));
     hipLaunchKernelGGL(gemm_tn_f32, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return dm3d_launch_check("gemm_tn_f32");
 }

@@ -205,7 +205,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradArgs p) {
     const int ntap = p.ksize == 3 ? 3 : 1;
     const int dz = p.ksize == 3 ? tr / 3 - 1 : 0, dy = p.ksize == 3 ? tr % 3 - 1 : 0;
     const long vox = (long)p.d * p.h * p.w;                     // voxels per sample; samples are consecutive (the K axis spans all)
-    const long kvox = p.chunks * KT;                            // padded K extent of this batch item
     const long c_lo = p.chunks * split / p.nsplit, c_hi = p.chunks * (split + 1) / p.nsplit;
 
     // staging assignment: thread -> (voxel row r = tid >> 3 [0..31], 8-channel piece = tid & 7 -> two float4 at piece*8, piece*8+4)
@@ -221,45 +220,55 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradArgs p) {
     const bool g_ok0 = co0 + sp < p.cout, g_ok1 = co0 + sp + 4 < p.cout;
     const long total_vox = p.ksize == 3 ? vox * p.batch : vox;  // k3: `batch` samples laid out consecutively form one K axis
 
-    for (long ch = c_lo; ch < c_hi; ++ch) {
+    // Loads are unconditional on clamped addresses and masked afterwards (a load under a divergent branch makes hipcc wait for it on the
+    // spot: eight serialised round trips per chunk), and the next chunk's operands travel in registers during this chunk's MFMAs.
+    const long vox_total = p.ksize == 3 ? total_vox : vox;
+    const int ca0 = a_ok0 ? ci0 + sp : 0, ca1 = a_ok1 ? ci0 + sp + 4 : 0;       // clamped channel offsets
+    const int cg0 = g_ok0 ? co0 + sp : 0, cg1 = g_ok1 ? co0 + sp + 4 : 0;
+    f32x4 ga, gb, av[3][2];
+    bool gm = false, am[3] = {false, false, false};
+    auto fetch = [&](long ch) {
         const long v = ch * KT + srow;                          // this thread's voxel (flat over samples for k3)
-        const bool v_ok = v < (p.ksize == 3 ? total_vox : vox) && v < kvox;
-        f32x4 ga = z4, gb = z4, av[3][2];
+        gm = v < vox_total;
+        const long vc = gm ? v : vox_total - 1;
+        ga = *reinterpret_cast<const f32x4*>(G + vc * p.cout + cg0);
+        gb = *reinterpret_cast<const f32x4*>(G + vc * p.cout + cg1);
+        if (p.ksize == 3) {
+            const long s = vc / vox, rem = vc - s * vox;
+            const int zz = (int)(rem / ((long)p.h * p.w)), yy = (int)((rem / p.w) % p.h), xx = (int)(rem % p.w);
+            const int iz = zz + dz, iy = yy + dy;
+            const bool zy_ok = gm && iz >= 0 && iz < p.d && iy >= 0 && iy < p.h;
+            const int izc = min(max(iz, 0), p.d - 1), iyc = min(max(iy, 0), p.h - 1);
+            const long base = ((s * p.d + izc) * p.h + iyc) * (long)p.w;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) { av[t][0] = z4; av[t][1] = z4; }
-        if (v_ok) {
-            if (g_ok0) ga = *reinterpret_cast<const f32x4*>(G + v * p.cout + co0 + sp);
-            if (g_ok1) gb = *reinterpret_cast<const f32x4*>(G + v * p.cout + co0 + sp + 4);
-            if (p.ksize == 3) {
-                const long s = v / vox, rem = v - s * vox;
-                const int zz = (int)(rem / ((long)p.h * p.w)), yy = (int)((rem / p.w) % p.h), xx = (int)(rem % p.w);
-                const int iz = zz + dz, iy = yy + dy;
-                if (iz >= 0 && iz < p.d && iy >= 0 && iy < p.h) {
-                    const long base = ((s * p.d + iz) * p.h + iy) * (long)p.w;
+            for (int t = 0; t < 3; ++t) {
+                const int ix = xx + t - 1;
+                am[t] = zy_ok && ix >= 0 && ix < p.w;
+                const float* q = A + (base + min(max(ix, 0), p.w - 1)) * p.cin;
+                av[t][0] = *reinterpret_cast<const f32x4*>(q + ca0);
+                av[t][1] = *reinterpret_cast<const f32x4*>(q + ca1);
+            }
+        } else {
+            am[0] = gm;
+            const float* q = A + vc * p.cin;
+            av[0][0] = *reinterpret_cast<const f32x4*>(q + ca0);
+            av[0][1] = *reinterpret_cast<const f32x4*>(q + ca1);
+        }
+    };
+    if (c_lo < c_hi) fetch(c_lo);
+    for (long ch = c_lo; ch < c_hi; ++ch) {
+        __syncthreads();                                        // previous chunk's MFMAs are done with the tiles
+        *reinterpret_cast<f32x4*>(lds_g + srow * LDA + sp) = (gm && g_ok0) ? ga : z4;
+        *reinterpret_cast<f32x4*>(lds_g + srow * LDA + sp + 4) = (gm && g_ok1) ? gb : z4;
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        const int ix = xx + t - 1;
-                        if (ix >= 0 && ix < p.w) {
-                            const float* q = A + (base + ix) * p.cin + ci0 + sp;
-                            if (a_ok0) av[t][0] = *reinterpret_cast<const f32x4*>(q);
-                            if (a_ok1) av[t][1] = *reinterpret_cast<const f32x4*>(q + 4);
-                        }
-                    }
-                }
-            } else {
-                const float* q = A + v * p.cin + ci0 + sp;
-                if (a_ok0) av[0][0] = *reinterpret_cast<const f32x4*>(q);
-                if (a_ok1) av[0][1] = *reinterpret_cast<const f32x4*>(q + 4);
+        for (int t = 0; t < 3; ++t) {                           // (static indices: a runtime-indexed register array lives in scratch memory)
+            if (t < ntap) {
+                *reinterpret_cast<f32x4*>(lds_a[t] + srow * LDA + sp) = (am[t] && a_ok0) ? av[t][0] : z4;
+                *reinterpret_cast<f32x4*>(lds_a[t] + srow * LDA + sp + 4) = (am[t] && a_ok1) ? av[t][1] : z4;
             }
         }
-        __syncthreads();                                        // previous chunk's MFMAs are done with the tiles
-        *reinterpret_cast<f32x4*>(lds_g + srow * LDA + sp) = ga;
-        *reinterpret_cast<f32x4*>(lds_g + srow * LDA + sp + 4) = gb;
-        for (int t = 0; t < ntap; ++t) {
-            *reinterpret_cast<f32x4*>(lds_a[t] + srow * LDA + sp) = av[t][0];
-            *reinterpret_cast<f32x4*>(lds_a[t] + srow * LDA + sp + 4) = av[t][1];
-        }
         __syncthreads();
+        fetch(ch + 1 < c_hi ? ch + 1 : ch);
 #pragma unroll
         for (int k = 0; k < KT; k += 2) {
             const float bv = lds_g[(k + half) * LDA + wn * 32 + l32];
@@ -276,7 +285,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradArgs p) {
     const int co = co0 + wn * 32 + l32;
     if (co >= p.cout) return;
     float* DW = p.dw + (size_t)bi * p.dw_bs;
-    for (int t = 0; t < ntap; ++t) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        if (t >= ntap) continue;
         const int tap = p.ksize == 3 ? tr * 3 + t : 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

@@ -541,8 +541,10 @@ class Plan:
             kind = "conv_k3s1_n32"      # conv_in / conv_out: one 32-column tile
         elif x1_h2:
             kind = "conv_k3s1_h2in"     # kernel MODE 2: pre-activated DM3D_FMT_H2 input (ResidualBlock conv2 behind a hand-off)
+        elif w.precision == _lib.PREC_H3 and pro is not None and lib().dm3d_conv_tile_form(C.byref(d)) == 4:
+            kind = "conv_k3s1_td4"      # conv3d_igemm_h3v2<3, 1, 4, 2>: the 4-slice form (small grids, fused skip phase)
         else:
-            kind = "conv_k3s1"
+            kind = "conv_k3s1"          # h3: conv3d_igemm_h3v2<3, 1, 8, 3> (prologue, 8-slice bricks); fp32: conv3d_igemm_f32
         self.ops.append((lib().dm3d_conv3d_ndhwc, (C.byref(d),), kind,
                          {"desc": f"{kind} {edge_in}^3{'x2up' if upsample else ''} cin={w.cin} cout={w.cout}"
                                   + (f" +k1 skip cin={skip[2] + skip[3]}" if skip is not None else ""),
@@ -837,7 +839,7 @@ class Plan:
                 check(lib().dm3d_gather_rows(tab.data_ptr(), tab.shape[0], ids.data_ptr(), buf.data_ptr(), buf.shape[0],
                                              buf.shape[1], st), "gather_rows")
 
-    _RANGE_OF = {"conv_k1": "conv", "conv_k3s2": "conv", "conv_up": "conv", "conv_k3s1_n32": "conv", "conv_k3s1_h2in": "conv", "conv_k3s1": "conv",
+    _RANGE_OF = {"conv_k3s1_td4": "conv", "conv_k1": "conv", "conv_k3s2": "conv", "conv_up": "conv", "conv_k3s1_n32": "conv", "conv_k3s1_h2in": "conv", "conv_k3s1": "conv",
                  "gemm": "attn", "gemm_h3": "attn", "attn_fused": "attn", "softmax": "attn", "layernorm": "attn", "groupnorm": "norm", "affine": "norm",
                  "range": "guard"}
 

@@ -11,9 +11,9 @@ Contract (one JSON line from rank 0):  python bench.py --gpus N --steps K --warm
     scaling: B per GPU fixed).  Under torchrun (RANK/LOCAL_RANK/WORLD_SIZE set) this process is one rank; started plainly as
     `python bench.py --gpus N` it launches the N ranks itself as fresh child processes — before this process has touched the
     GPU — relays rank 0's JSON line and exits non-zero if any rank fails.
-  * roofline: the dominant kernel is the k3/stride-1 Conv3d implicit GEMM (24 launches/step of the main instantiation, 10 more of
-    its H2-input twin —
-    conv_in/conv_out and the two UpSample convs run other instantiations and are listed under per_kernel_kind);
+  * roofline: the dominant kernel is the k3/stride-1 Conv3d implicit GEMM with the norm+SiLU prologue in its 8-slice form,
+    conv3d_igemm_h3v2<3, 1, 8, 3> (10 launches/step: the large-Cin convs of the 32^3 and 16^3 levels, ~39 % of the step; the 4-slice
+    form, the H2-input twin, conv_in/conv_out and the two UpSample convs are other instantiations, listed under per_kernel_kind);
     achieved = algorithmic FLOPs (2*27*Cin*Cout*B*Dout^3 per launch, plus those of a fused 1x1 skip conv) /
     HIP-event time of those launches, measured live on the launch stream; peak = the dense MFMA peak of the datatype the
     kernel multiplies in (MI355X_MICROARCH.md): float16 2500 TFLOP/s in the default h3 mode (three v_mfma_f32_16x16x32_f16
@@ -218,9 +218,10 @@ def main():
         n, ms, fl, by, ex = acc["conv_k3s1"]
         achieved = fl / (ms * 1e-3) / 1e12
         if args.precision == "h3":
-            kname = ("conv3d_igemm_h3v2<3, 1> (k3 stride-1 Conv3d with the fused norm+SiLU prologue; float16 hi+lo split, 3 x "
-                     "v_mfma_f32_16x16x32_f16 per algorithmic product, fp32 accumulate; its MODE-2 twin that reads pre-activated "
-                     "DM3D_FMT_H2 input is listed as conv_k3s1_h2in)")
+            kname = ("conv3d_igemm_h3v2<3, 1, 8, 3> (k3 stride-1 Conv3d with the fused norm+SiLU prologue, 8-slice bricks, three weight "
+                     "buffers; float16 hi+lo split, 3 x v_mfma_f32_16x16x32_f16 per algorithmic product, fp32 accumulate; its 4-slice "
+                     "form <3, 1, 4, 2> is listed as conv_k3s1_td4, the MODE-2 twin that reads pre-activated DM3D_FMT_H2 input as "
+                     "conv_k3s1_h2in)")
             peak, passes = PEAK_F16_MFMA_TFLOPS, 3
         else:
             kname, peak, passes = "conv3d_igemm_f32<4, 8, 8, 1, 3, 4, 1> (k3 stride-1 Conv3d, v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS, 1
@@ -244,7 +245,7 @@ def main():
     if roofline is not None:
         import csv
         import glob
-        want = "conv3d_igemm_h3v2<3, 1>" if args.precision == "h3" else "conv3d_igemm_f32<4, 8, 8, 1, 3, 4, 1>"
+        want = "conv3d_igemm_h3v2<3, 1, 8, 3>" if args.precision == "h3" else "conv3d_igemm_f32<4, 8, 8, 1, 3, 4, 1>"
         sig = f"batch={B} size={S} channels={Cc} norm={args.norm} precision={args.precision} csrc={csrc_digest()}"
         reason = "no profiles/*_pmc_hbm.csv records this workload and these kernel sources: " + sig
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv")), reverse=True):

@@ -183,6 +183,10 @@ typedef struct dm3d_conv_desc {
 
 int     dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream);
 int64_t dm3d_conv_scratch_bytes(const dm3d_conv_desc* d);
+/* Which tile form of the 16x16x32 conv kernel serves this descriptor: 8 (8 z-slices per brick, 512 threads, three weight buffers — launches
+ * with enough bricks to fill the chip at one workgroup per CU), 4 (4 slices, 256 threads, two buffers), 0 (another kernel).  Profiling
+ * harnesses use it to name the instantiation a launch runs (rocprofv3 lists conv3d_igemm_h3v2<KS, MODE, 8, 3> and <KS, MODE, 4, 2>). */
+int32_t dm3d_conv_tile_form(const dm3d_conv_desc* d);
 
 /* ---- Dense / einsum contractions: out[b][m][n] = act(alpha * sum_k A[b][m][k]*B[b][n][k] + bias) + res -------
  * Both operands K-contiguous ("TN").  Replaces layers.Dense on the last axis (:131-137, 164-169, 251, 301-304, 313),
