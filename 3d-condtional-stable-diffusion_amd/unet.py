@@ -757,7 +757,9 @@ class Plan:
         a1, a2 = self._buf(M, u), self._buf(M, u)
         scale = float(u) ** -0.5
         import os
-        if os.environ.get("DM3D_ATTN_FUSED", "1") != "0" and u == 256 and L % 128 == 0:
+        # (the fused kernel runs one 4-wave workgroup per 128 queries: it needs >= ~128 workgroups to beat the GEMM form, i.e. B >= 16 at L = 512;
+        # measured B = 1 / 4 / 8: 2.80 / 3.85 / 5.74 ms per step fused against 2.5 / 3.5 / 5.3 with the three launches)
+        if os.environ.get("DM3D_ATTN_FUSED", "1") != "0" and u == 256 and L % 128 == 0 and 2 * B * (L // 128) >= 128:
             # both attention passes in ONE fused launch (dm3d_attention_group -> csrc/dm3d_attn_h3.hip): scores, online softmax and
             # P.V per 32-key tile in registers / LDS; no [B, L, L] tensor
             descs = (_lib.AttentionDesc * 2)()
