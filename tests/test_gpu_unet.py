@@ -552,3 +552,36 @@ def test_generate_sharded_single_process(dev):
     m = cdm.DiffusionModel(8, 1024, 4, None, _args(3, 2), weights=dm3d_amd.synthetic_weights(cfg, seed=0))
     a = parallel.generate_sharded(m, (2, 8, 8, 8, 4), 0, 1, seed=9)
     assert torch.equal(a, m.generate((2, 8, 8, 8, 4), 0, 1, seed=parallel.rank_seed(9, 0)))
+
+
+def test_generate_full_size_steps_match_oracle(dev):
+    """Configs 2-3 through the sampling loop itself: three DDPM steps at 32^3 (C=4, B=2, both context ids mixed per volume) with injected
+    x_T / noise against the oracle's ddpm_step(unet_forward(...)) on this box's CPU — the posterior update, the clip and the per-step
+    timestep table at full latent size, not only eps."""
+    import dm3d_amd
+    from dm3d_amd.networks import conditional_dm3d as cdm
+    from oracle import ref_torch as rt
+    T, B, C = 1000, 2, 4
+    cfg = dm3d_amd.UNetConfig(img_size=32, img_channels=C)
+    W = dm3d_amd.synthetic_weights(cfg, seed=0)
+    m = cdm.DiffusionModel(32, 1024, C, None, _args(T, B), weights=W)
+    g = torch.Generator().manual_seed(12)
+    shape = (B, 32, 32, 32, C)
+    x_T = torch.randn(shape, generator=g)
+    steps = 3
+    noises = torch.zeros((T,) + shape)
+    for i in range(T - steps, T):
+        noises[i] = torch.randn(shape, generator=g)
+    ids = torch.tensor([[[1]], [[0]]])
+    got = m.generate(shape, context_value=ids, x_T=x_T, noise=noises, steps=steps)
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    ocfg, b = rt.UNetConfig(img_size=32, img_channels=C), rt.Betas(T)
+    Wt = {k: torch.from_numpy(v) for k, v in W.items()}
+    x = x_T
+    for i in range(T - 1, T - 1 - steps, -1):
+        tt = torch.full((B,), i, dtype=torch.int64)
+        x = rt.ddpm_step(b, x, rt.unet_forward(Wt, ocfg, x, tt, ids), tt, noises[i])
+    torch.cuda.synchronize()
+    err = float((got.cpu() - x).abs().max())
+    print(f"3 full-size DDPM steps: max abs difference {err:.2e} (values in [-1, 1] + noise)")
+    assert err < 1e-4
