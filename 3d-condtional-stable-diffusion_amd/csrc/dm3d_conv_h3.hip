@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
                     bh[nr] = *reinterpret_cast<const h8*>(wbuf + t * (NT * REC) + b_hi[nr]);
                     bl[nr] = *reinterpret_cast<const h8*>(wbuf + t * (NT * REC) + b_lo[nr]);
                 }
+#ifndef DM3D_MFMA_PASS_MAJOR
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
@@ -264,6 +265,21 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
                         acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mr], bl[nr], acc[mr][nr], 0, 0, 0);
                         acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mr], bh[nr], acc[mr][nr], 0, 0, 0);
                     }
+#else
+                // pass-major: the three MFMAs into one accumulator are MR*NR issue slots apart (see dm3d_conv_h3v2.hip)
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mr], bh[nr], acc[mr][nr], 0, 0, 0);
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mr], bl[nr], acc[mr][nr], 0, 0, 0);
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mr], bh[nr], acc[mr][nr], 0, 0, 0);
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             if (!last_group) {

@@ -28,6 +28,35 @@ __host__ __device__ constexpr int pi_pos(int c) {
 // patch column of MFMA row i (rows 0-3 -> 0, 4-7 -> 2, 8-11 -> 3, 12-15 -> 1); patch row is i & 3
 __device__ __forceinline__ int dx_of_row(int i) { return (0x1320 >> ((i >> 2) * 4)) & 3; }
 
+// The three passes (al.bh, ah.bl, ah.bh) of the 4 x 2 accumulator tiles one weight batch feeds.  Default: tile-major, the three MFMAs of an
+// accumulator back to back.  -DDM3D_MFMA_PASS_MAJOR (tools/mk_variant.sh) issues them pass-major instead, 8 slots apart, so that no MFMA
+// waits for its predecessor's result: measured neutral on the conv, GEMM and 32x32x16 kernels alike (interleaved A/B, profiles/
+// r02_ab_mfma_order.log: 17.59 vs 17.59 ms/step) — with two waves per SIMD the other wave fills those slots.  (In the fused attention
+// kernel, one wave per SIMD, the same reordering was worth 2x.)
+#ifndef DM3D_MFMA_PASS_MAJOR
+#define DM3D_MFMA3_TILES(acc, nb, al, ah, bl, bh)                                                        \
+    _Pragma("unroll") for (int pi_ = 0; pi_ < 4; ++pi_)                                                  \
+        _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_) {                                               \
+            f32x4v& c_ = acc[pi_][(nb) * 2 + k_];                                                        \
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[pi_], bh[k_], c_, 0, 0, 0);                   \
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi_], bl[k_], c_, 0, 0, 0);                   \
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi_], bh[k_], c_, 0, 0, 0);                   \
+        }
+#else
+#define DM3D_MFMA3_TILES(acc, nb, al, ah, bl, bh)                                                        \
+    do {                                                                                                 \
+        _Pragma("unroll") for (int pi_ = 0; pi_ < 4; ++pi_)                                              \
+            _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_)                                             \
+                acc[pi_][(nb) * 2 + k_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[pi_], bh[k_], acc[pi_][(nb) * 2 + k_], 0, 0, 0); \
+        _Pragma("unroll") for (int pi_ = 0; pi_ < 4; ++pi_)                                              \
+            _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_)                                             \
+                acc[pi_][(nb) * 2 + k_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi_], bl[k_], acc[pi_][(nb) * 2 + k_], 0, 0, 0); \
+        _Pragma("unroll") for (int pi_ = 0; pi_ < 4; ++pi_)                                              \
+            _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_)                                             \
+                acc[pi_][(nb) * 2 + k_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi_], bh[k_], acc[pi_][(nb) * 2 + k_], 0, 0, 0); \
+    } while (0)
+#endif
+
 // MODE 0: float32 input as is; 1: float32 input through the fused norm + SiLU prologue; 2: x1 already activated and split
 // (DM3D_FMT_H2, written by the producing conv's epilogue): staging is two 16-byte copies per voxel and no arithmetic
 // TD = z-slices per brick = waves per workgroup (4: 256 threads, two workgroups per CU; 8: 512 threads, one workgroup per CU with 160 KB
@@ -266,15 +295,7 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
                         bh[k] = *reinterpret_cast<const h8*>(wbuf + (pr * 2 * NT + ni * 16) * REC + b_hi);
                         bl[k] = *reinterpret_cast<const h8*>(wbuf + (pr * 2 * NT + ni * 16) * REC + (b_hi ^ 16));
                     }
-#pragma unroll
-                    for (int pi = 0; pi < 4; ++pi)
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            f32x4v& c = acc[pi][nb * 2 + k];
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[pi], bh[k], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi], bl[k], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi], bh[k], c, 0, 0, 0);
-                        }
+                    DM3D_MFMA3_TILES(acc, nb, al, ah, bl, bh);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -385,15 +406,7 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
                     bh[k] = *reinterpret_cast<const h8*>(wbuf + ((nb * 2 + k) * 16) * REC + sb_hi);
                     bl[k] = *reinterpret_cast<const h8*>(wbuf + ((nb * 2 + k) * 16) * REC + (sb_hi ^ 16));
                 }
-#pragma unroll
-                for (int pi = 0; pi < 4; ++pi)
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        f32x4v& c = acc[pi][nb * 2 + k];
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[pi], bh[k], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi], bl[k], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi], bh[k], c, 0, 0, 0);
-                    }
+                DM3D_MFMA3_TILES(acc, nb, al, ah, bl, bh);
             }
             __builtin_amdgcn_sched_barrier(0);
         }

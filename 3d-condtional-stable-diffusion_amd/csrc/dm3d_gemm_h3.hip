@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
                 bh[nr] = *reinterpret_cast<const h8*>(lb + b_hi + (kk * NT + nr * 32) * REC);
                 bl[nr] = *reinterpret_cast<const h8*>(lb + (b_hi ^ 16) + (kk * NT + nr * 32) * REC);
             }
+#ifndef DM3D_MFMA_PASS_MAJOR
 #pragma unroll
             for (int mr = 0; mr < 2; ++mr)
 #pragma unroll
@@ -212,6 +213,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
                     acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mr], bl[nr], acc[mr][nr], 0, 0, 0);
                     acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mr], bh[nr], acc[mr][nr], 0, 0, 0);
                 }
+#else
+            // pass-major over the 2 x 2 tiles: the three MFMAs into one accumulator are four issue slots (128 cycles) apart, more than a
+            // 32x32x16's result latency; back to back, the second and third wait for their predecessor (see dm3d_conv_h3v2.hip)
+#pragma unroll
+            for (int mr = 0; mr < 2; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < 2; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mr], bh[nr], acc[mr][nr], 0, 0, 0);
+#pragma unroll
+            for (int mr = 0; mr < 2; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < 2; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mr], bl[nr], acc[mr][nr], 0, 0, 0);
+#pragma unroll
+            for (int mr = 0; mr < 2; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < 2; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mr], bh[nr], acc[mr][nr], 0, 0, 0);
+#endif
         }
     };
 
