@@ -278,6 +278,10 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
     a.prelu = d->prelu_alpha; a.relu_out = d->relu_out;
     a.scratch = d->scratch; a.scratch_bytes = d->scratch_bytes;
     a.range_flag = d->range_flag; a.range_limit = d->range_limit > 0.0f ? d->range_limit : 65504.0f;
+    if (d->wpk_f8) {
+        DM3D_REQUIRE(d->precision == DM3D_PREC_H3 && dm3d_aligned16(d->wpk_f8), "conv: wpk_f8 needs precision H3 and 16-byte alignment");
+        a.wpk_f8 = d->wpk_f8;
+    }
     DM3D_REQUIRE((d->x1_fmt == DM3D_FMT_F32 || d->x1_fmt == DM3D_FMT_H2) && (d->out_fmt == DM3D_FMT_F32 || d->out_fmt == DM3D_FMT_H2),
                  "conv: unknown x1_fmt / out_fmt");
     DM3D_REQUIRE((d->post_scale == nullptr) == (d->post_shift == nullptr), "conv: post_scale and post_shift go together");
@@ -339,6 +343,8 @@ extern "C" int32_t dm3d_conv_tile_form(const dm3d_conv_desc* d) {
     a.coutpad = (int)dm3d_round_up(d->cout, DM3D_COUT_PAD);
     a.parity = par_mode ? 1 : 0;
     a.s_npairs = d->skip_wpk ? 1 : 0;
+    a.wpk_f8 = d->wpk_f8;
+    if (dm3d_conv_h3v2_f8(a)) return 9;
     return dm3d_conv_h3v2_wide(a) ? 8 : 4;
 }
 
@@ -374,7 +380,21 @@ extern "C" int dm3d_pack_weights_h3p(const float* keras_kernel, int32_t taps, in
     DM3D_REQUIRE(mode >= 0 && mode <= 2 && (mode == 0 || taps == 8), "pack_weights_h3p: mode %d with taps %d", mode, taps);
     DM3D_REQUIRE(w_exp >= -100 && w_exp <= 100, "pack_weights_h3p: w_exp %d out of range", w_exp);
     DM3D_REQUIRE(dm3d_aligned16(packed), "pack_weights_h3p: packed must be 16-byte aligned");
-    return dm3d_pack_h3v2(keras_kernel, taps, cin, cout, w_exp, in_scale, packed, mode, static_cast<hipStream_t>(stream));
+    return dm3d_pack_h3v2(keras_kernel, taps, cin, cout, w_exp, in_scale, packed, mode, 0, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int64_t dm3d_packed_weight_h3f8_bytes(int32_t taps, int32_t cin, int32_t cout) {
+    if (taps <= 0 || cin <= 0 || cout <= 0) return 0;
+    return dm3d_h3v2_image_bytes(taps, cin, cout, 1);
+}
+
+extern "C" int dm3d_pack_weights_h3f8(const float* keras_kernel, int32_t taps, int32_t cin, int32_t cout, int32_t w_exp,
+                                      const float* in_scale, void* packed, int32_t mode, void* stream) {
+    DM3D_REQUIRE(keras_kernel && packed && taps > 0 && cin > 0 && cout > 0, "pack_weights_h3f8: bad arguments");
+    DM3D_REQUIRE(mode >= 0 && mode <= 2 && (mode == 0 || taps == 8), "pack_weights_h3f8: mode %d with taps %d", mode, taps);
+    DM3D_REQUIRE(w_exp >= -100 && w_exp <= 100, "pack_weights_h3f8: w_exp %d out of range", w_exp);
+    DM3D_REQUIRE(dm3d_aligned16(packed), "pack_weights_h3f8: packed must be 16-byte aligned");
+    return dm3d_pack_h3v2(keras_kernel, taps, cin, cout, w_exp, in_scale, packed, mode, 1, static_cast<hipStream_t>(stream));
 }
 
 int dm3d_conv_launch_f32(ConvArgs& a, int which, hipStream_t st) {

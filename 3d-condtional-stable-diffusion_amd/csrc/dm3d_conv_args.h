@@ -32,6 +32,7 @@ struct ConvArgs {
     int x_h2;                 // h3v2: x1 arrives in DM3D_FMT_H2 (c1 % 16 == 0, no x2, no prologue)
     // h3v2 only: a 1x1 conv over a second (raw, un-normalised) input accumulated into the same tile (ResidualBlock skip path)
     const float* sx1; const float* sx2; int sc1, sc2; const void* swpk; int s_npairs;   // s_npairs = round_up(sc1+sc2, 32) / 32
+    const void* wpk_f8;                      // optional second weight image: the float8 cross-term form (dm3d_h3.h "H3F8")
     int* range_flag; float range_limit;      // H3 range guard (include/dm3d.h): *range_flag = 1 if any |output| > range_limit
 };
 
@@ -45,6 +46,7 @@ int dm3d_conv_h3v2_ksplit(const ConvArgs& a, bool with_scratch);
 bool dm3d_conv_h3v2_wide(const ConvArgs& a);            // true: the 8-slice / 512-thread / three-buffer form serves this launch
 int64_t dm3d_h3v2_skip_image_bytes(int cin, int cout);
 int dm3d_pack_skip_h3v2(const float* keras_kernel, int cin, int cout, int w_exp, void* packed, hipStream_t st);       // split factor the launch would choose
-int64_t dm3d_h3v2_image_bytes(int taps, int cin, int cout);
+int64_t dm3d_h3v2_image_bytes(int taps, int cin, int cout, int f8 = 0);
 int dm3d_pack_h3v2(const float* keras_kernel, int taps, int cin, int cout, int w_exp, const float* in_scale, void* packed, int mode,
-                   hipStream_t st);
+                   int f8, hipStream_t st);
+bool dm3d_conv_h3v2_f8(const ConvArgs& a);               // true: the float8 cross-term form (wpk_f8) serves this launch

@@ -64,13 +64,24 @@ __device__ __forceinline__ int dx_of_row(int i) { return (0x1320 >> ((i >> 2) * 
 // 3 = two groups of lead — a 16 KB LDS-DMA fill takes ~1.1 us from issue to landing (MI355X_MICROARCH.md "ldsdma-fill"), longer than
 // one group's 96 MFMAs, so with two buffers every group ended waiting for its successor (in-kernel stamps: ~680 cycles per group).
 // The 8-slice brick also halves the weight bytes streamed per FLOP (eight waves share a group) and trims the halo factor 2.34 -> 1.95.
-template <int KS, int MODE, int TD, int NBUF>
+// F8 = 1 (8-slice form only): the "H3F8" arithmetic of dm3d_h3.h — ah.bh on v_mfma_f32_16x16x32_f16 as before, both cross terms on
+// v_mfma_scale_f32_16x16x128_f8f6f4 (K = 128 = 4 taps x 16 channels x 2 terms = one weight group; lane k-group kg takes tap kg of the
+// group).  Per group a wave issues 32 float16 + 16 float8 MFMAs (512 + ~455 cycles) where the three-pass form issues 96 float16 MFMAs
+// (1536 cycles); pipeline (three 16 KB buffers, counted waits) as in the three-pass form.
+#ifdef DM3D_EXP_NO_F8_READ       // timing experiment: the float8 operands come from registers instead of LDS (results are wrong)
+__device__ __forceinline__ u32x4 f8read_fake(const void* p) { u32x4 v; const unsigned t = (unsigned)(size_t)p; v[0] = t; v[1] = t * 3; v[2] = t * 5; v[3] = t * 7; return v; }
+#define F8READ(p) f8read_fake(p)
+#else
+#define F8READ(p) *reinterpret_cast<const u32x4*>(p)
+#endif
+template <int KS, int MODE, int TD, int NBUF, int F8 = 0>
 __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
     constexpr int TH = 8, TW = 8, CK = 16, NT = 64, NTHR = TD * 64;
     constexpr int HD = TD - 1 + KS, HH = TH - 1 + KS, HW = TW - 1 + KS, HWP = 12;
     constexpr int HVOX = HD * HH * HW;
-    constexpr int TAPS = KS * KS * KS, TAPSP = (TAPS + 3) / 4 * 4;
-    constexpr int G = 4, NG = TAPSP / G;                     // taps per weight group (two MFMA k-steps), groups per chunk
+    constexpr int G = 4;                                     // taps per weight group (= one K = 128 step of the float8 cross terms)
+    constexpr int TAPS = KS * KS * KS, TAPSP = (TAPS + G - 1) / G * G;
+    constexpr int NG = TAPSP / G;                            // groups per chunk
     constexpr int NSLOT = (HVOX * 2 + NTHR - 1) / NTHR;
     constexpr int WGRP = G * NT * REC;                       // halfs per weight group (16 KB)
     constexpr int WSLOT = WGRP * 2 / 16 / NTHR;              // 16-byte pieces per thread: 4 (256 threads) or 2 (512)
@@ -141,9 +152,15 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
     // linear 16 KB copy; wave w moves the 1 KB pieces w, w+TD, ...  Buffer = group index mod NBUF, counted from this workgroup's
     // first group (NG is odd for k3, so the phase differs from chunk to chunk: a running counter).
     const char* w_img = reinterpret_cast<const char*>(wbase + (size_t)ntile * p.nchunks * NG * WGRP) + wave * 1024 + lane * 16;
+#ifdef DM3D_EXP_NO_DMA
+    const int g_first_dma = c_lo * NG;
+#endif
     auto fetch_w = [&](int gg, int buf) {
         const char* src = w_img + (size_t)gg * (WGRP * 2);
         char* dst = reinterpret_cast<char*>(lds_w) + buf * (WGRP * 2) + wave * 1024;
+#ifdef DM3D_EXP_NO_DMA          // timing experiment: no weight stream (results are wrong)
+        if (gg > g_first_dma + 1) return;
+#endif
 #pragma unroll
         for (int i = 0; i < WSLOT; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * (NTHR * 16)),
@@ -218,6 +235,9 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 shi[j] = __builtin_bit_cast(h8, in ? v0 : z);
                 slo[j] = __builtin_bit_cast(h8, in ? v1 : z);
+                if (F8) slo[j] = h2_to_x8(shi[j], slo[j]);              // (hi16, lo16) of the hand-off format -> [ah8 | al8]
+            } else if (F8) {
+                split8_f8(v0, v1, (in && ok0) ? DM3D_F8_LIMIT : 0.0f, (in && ok1) ? DM3D_F8_LIMIT : 0.0f, shi[j], slo[j]);
             } else {
                 split8(v0, v1, (in && ok0) ? 65504.0f : 0.0f, (in && ok1) ? 65504.0f : 0.0f, shi[j], slo[j]);
             }
@@ -253,9 +273,26 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
         load_halo(ch + 1 < c_hi ? ch + 1 : ch);
         __builtin_amdgcn_sched_barrier(0);
 
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
+        // end of a weight group: advance the ring, wait for the next group's DMA, one barrier
+        auto group_end = [&](const int g) {
+            __builtin_amdgcn_sched_barrier(0);
+            wb = wb + 1 == NBUF ? 0 : wb + 1;
             const bool last_group = g + 1 == NG;
+            if (!last_group) {
+                if (NBUF == 2) {
+                    __syncthreads();      // the DMA of the next group has landed (vmcnt) and every wave is done with this one
+                } else {
+                    // group g+1 must have landed; newer than it in the queue: group g+2's DMA and, behind the chunk's first iteration,
+                    // the next chunk's halo loads (issued between the DMAs of g+1 and g+2)
+                    if (g == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT + 2 * NSLOT) : "memory");
+                    else        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT) : "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+            }
+        };
+        auto group_body = [&](const int g) {
             if (NBUF == 2) {
                 const int nxt = ch * NG + g + 1;
                 if (nxt < g_end) fetch_w(nxt, wb ^ 1);
@@ -268,7 +305,7 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
             __builtin_amdgcn_sched_barrier(0);
             const _Float16* wbuf = lds_w + wb * WGRP;
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {                            // two tap pairs per group
+            for (int pr = 0; pr < G / 2; ++pr) {                        // tap pairs of the group
                 // taps of the pair (compile-time after unrolling); the pad tap (>= TAPS) re-reads the last real tap's voxels
                 const int ta = g * G + pr * 2, tb = ta + 1;
                 const int tac = ta < TAPS ? ta : TAPS - 1, tbc = tb < TAPS ? tb : TAPS - 1;
@@ -282,8 +319,8 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
 #pragma unroll
                 for (int py = 0; py < 2; ++py) {                         // patch rows are 4*HWP = 48 records apart: same swizzle
                     ah[py * 2 + 0] = *reinterpret_cast<const h8*>(lds_in + o0 + py * (48 * REC));
-                    al[py * 2 + 0] = *reinterpret_cast<const h8*>(lds_in + (o0 ^ 16) + py * (48 * REC));
                     ah[py * 2 + 1] = *reinterpret_cast<const h8*>(lds_in + o1 + py * (48 * REC));
+                    al[py * 2 + 0] = *reinterpret_cast<const h8*>(lds_in + (o0 ^ 16) + py * (48 * REC));
                     al[py * 2 + 1] = *reinterpret_cast<const h8*>(lds_in + (o1 ^ 16) + py * (48 * REC));
                 }
 #pragma unroll
@@ -298,21 +335,127 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
                     DM3D_MFMA3_TILES(acc, nb, al, ah, bl, bh);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            wb = wb + 1 == NBUF ? 0 : wb + 1;
-            if (!last_group) {
-                if (NBUF == 2) {
-                    __syncthreads();      // the DMA of the next group has landed (vmcnt) and every wave is done with this one
-                } else {
-                    // group g+1 must have landed; newer than it in the queue: group g+2's DMA and, behind the chunk's first iteration,
-                    // the next chunk's halo loads (issued between the DMAs of g+1 and g+2)
-                    if (g == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT + 2 * NSLOT) : "memory");
-                    else        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT) : "memory");
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                }
+            group_end(g);
+        };
+
+        // ---- the float8 cross-term form's group: 32 float16 MFMAs (ah.bh of the two tap pairs) + 16 float8 MFMAs (one K = 128 step:
+        // ah.bl + al.bh of all four taps), software-pipelined by hand: the LDS reads of a batch are issued in front of the previous batch's
+        // MFMAs (sched_barrier keeps them there), so the matrix pipe never waits for an operand that was requested a few cycles ago — left
+        // to the compiler every batch of reads sat directly in front of its own MFMAs behind an s_waitcnt, and with all eight waves of the
+        // workgroup in the same phase (one barrier per group) nothing else filled those gaps.
+        // float8 operands: lane (half, q) contributes, as its 32 K-bytes, slot 2 + q (channels 8q .. 8q+7: [ah8 x8 | al8 x8], weights
+        // [bl8 x8 | bh8 x8]) of tap `half` of the group's first pair and of its second pair — the very addresses the three-pass form reads
+        // its lo operands from, conflict-free like those (a k-group = tap mapping cost 5-7 LDS cycles per read instead of 4).
+        typedef int i32x8 __attribute__((ext_vector_type(8)));
+        h8 a_carry[4];                                                   // ah of the next group's first pair, read during this group's tail
+        auto group_body_f8 = [&](const int g) {
+            const bool last_group = g + 1 == NG;
+            if (NBUF == 2) {
+                const int nxt = ch * NG + g + 1;
+                if (nxt < g_end) fetch_w(nxt, wb ^ 1);
+            } else {
+                const int nxt = ch * NG + g + 2;
+                const int b2 = wb + 2 >= 3 ? wb - 1 : wb + 2;
+                fetch_w(nxt < g_end ? nxt : g_end - 1, b2);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            const _Float16* wbuf = lds_w + wb * WGRP;
+            // halo offset (halfs) of this lane's hi slot: tap pair pr of group gg, patch pi (pad taps re-read the last real tap: zero weights)
+            auto a_off = [&](int gg, int pr, int pi) {
+                const int ta = gg * G + pr * 2, tb = ta + 1;
+                const int tac = ta < TAPS ? ta : TAPS - 1, tbc = tb < TAPS ? tb : TAPS - 1;
+                const int rec_a = ((tac / (KS * KS)) * HH + (tac / KS) % KS) * HWP + tac % KS;
+                const int rec_b = ((tbc / (KS * KS)) * HH + (tbc / KS) % KS) * HWP + tbc % KS;
+                const int v = a_rec + (half ? rec_b : rec_a) + 4 * (pi & 1);
+                return v * REC + ((q ^ swz(v)) << 3) + (pi >> 1) * (48 * REC);
+            };
+            auto rd_a = [&](int gg, int pr, h8 (&a)[4]) {
+#pragma unroll
+                for (int pi = 0; pi < 4; ++pi) a[pi] = __builtin_bit_cast(h8, F8READ(lds_in + a_off(gg, pr, pi)));
+            };
+            auto rd_b = [&](int pr, int nb, h8 (&b)[2]) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) b[k] = __builtin_bit_cast(h8, F8READ(wbuf + (pr * 2 * NT + (nb * 2 + k) * 16) * REC + b_hi));
+            };
+            auto rd_a8 = [&](int pi) {
+                const u32x4 x0 = F8READ(lds_in + (a_off(g, 0, pi) ^ 16)), x1 = F8READ(lds_in + (a_off(g, 1, pi) ^ 16));
+                return i32x8{(int)x0[0], (int)x0[1], (int)x0[2], (int)x0[3], (int)x1[0], (int)x1[1], (int)x1[2], (int)x1[3]};
+            };
+            auto mma_hi = [&](const h8 (&a)[4], const h8 (&b)[2], int nb) {
+#ifndef DM3D_EXP_NO_HI_MFMA
+#pragma unroll
+                for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+                        acc[pi][nb * 2 + k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[pi], b[k], acc[pi][nb * 2 + k], 0, 0, 0);
+#else
+                asm volatile("" :: "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]));
+#endif
+            };
+            auto mma_f8 = [&](const i32x8& a8, const i32x8 (&b8)[4], int pi) {
+#ifndef DM3D_EXP_NO_F8_MFMA
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[pi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[ni], acc[pi][ni], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+#else
+                asm volatile("" :: "v"(a8), "v"(b8[0]), "v"(b8[1]), "v"(b8[2]), "v"(b8[3]));
+#endif
+            };
+            h8 a0[4], a1[4], b0[2], b1[2], b2[2], b3[2];
+            if (g == 0) {
+                rd_a(g, 0, a0);
+            } else {
+#pragma unroll
+                for (int pi = 0; pi < 4; ++pi) a0[pi] = a_carry[pi];
+            }
+            rd_b(0, 0, b0);
+            rd_b(0, 1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_hi(a0, b0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            rd_a(g, 1, a1);
+            rd_b(1, 0, b2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_hi(a0, b1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            rd_b(1, 1, b3);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_hi(a1, b2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            i32x8 b8[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const u32x4 w0 = F8READ(wbuf + (ni * 16) * REC + (b_hi ^ 16));
+                const u32x4 w1 = F8READ(wbuf + (2 * NT + ni * 16) * REC + (b_hi ^ 16));
+                b8[ni] = i32x8{(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+            }
+            i32x8 x0 = rd_a8(0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_hi(a1, b3, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            i32x8 x1 = rd_a8(1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_f8(x0, b8, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            x0 = rd_a8(2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_f8(x1, b8, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            x1 = rd_a8(3);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_f8(x0, b8, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!last_group) rd_a(g + 1, 0, a_carry);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_f8(x1, b8, 3);
+            group_end(g);
+        };
+        if constexpr (F8) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) group_body_f8(g);
+        } else {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) group_body(g);
         }
     }
 
@@ -562,7 +705,7 @@ __global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, lo
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[n4 * 4 + threadIdx.x] = 0.f;
 }
 
-template <int KS, int MODE, int TD, int NBUF>
+template <int KS, int MODE, int TD, int NBUF, int F8 = 0>
 int launch_v2(ConvArgs& a, hipStream_t st) {
     constexpr int HREC = (TD - 1 + KS) * (7 + KS) * 12;
     constexpr size_t lds = (size_t)(HREC * REC + NBUF * 4 * 64 * REC) * sizeof(_Float16);
@@ -572,7 +715,7 @@ int launch_v2(ConvArgs& a, hipStream_t st) {
     a.bw = (a.ow + 7) / 8;
     static bool attr_set = false;
     if (!attr_set) {
-        DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3v2<KS, MODE, TD, NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3v2<KS, MODE, TD, NBUF, F8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     // Small grids (the 8^3 level at B = 32 has 64 bricks x 4 channel tiles = one workgroup per CU, i.e. one wave per SIMD with
@@ -584,6 +727,7 @@ int launch_v2(ConvArgs& a, hipStream_t st) {
     a.split_atomic = 0;
     a.split_stride = 0;
     ConvArgs k = a;
+    if (F8) k.wpk = a.wpk_f8;
     const bool linear = !a.relu && !a.prelu && !a.relu_out && a.res != a.out && a.x1 != a.out && a.x2 != a.out;
     static const bool no_atomic = [] { const char* e = getenv("DM3D_CONV_NO_ATOMIC"); return e && e[0] == '1'; }();
     const bool atomic2 = a.ksplit == 2 && linear && a.nchunks >= 8 && !(no_atomic && with_scratch);       // cheaper than a reduce launch when two parts suffice
@@ -603,7 +747,7 @@ int launch_v2(ConvArgs& a, hipStream_t st) {
         k.range_flag = nullptr;                               // the reduce launch checks the finished values
     }
     dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64 * a.ksplit), a.parity ? 8u : 1u);
-    hipLaunchKernelGGL((conv3d_igemm_h3v2<KS, MODE, TD, NBUF>), grid, dim3(TD * 64), lds, st, k);
+    hipLaunchKernelGGL((conv3d_igemm_h3v2<KS, MODE, TD, NBUF, F8>), grid, dim3(TD * 64), lds, st, k);
     int rc = dm3d_launch_check("conv3d_igemm_h3v2");
     if (rc || !(a.ksplit > 1 && with_scratch && !atomic2)) return rc;
     const long n4 = (long)(out_elems / 4);                    // cout % 4 == 0 is not required of cout: fall back to scalar lanes
@@ -621,7 +765,7 @@ int launch_v2(ConvArgs& a, hipStream_t st) {
 // 64*ntile + 16*t16 + c; taps >= taps are zero; slots swizzled by the position.  mode: 0 plain, 1 UpSample sums, 2 Conv3DTranspose
 __global__ __launch_bounds__(256) void pack_weights_h3v2_kernel(const float* __restrict__ w, int taps, int tapsp, int cin, int cout,
                                                                 int nchunks, int ntiles, float scale, const float* in_scale,
-                                                                _Float16* __restrict__ out, int mode) {
+                                                                _Float16* __restrict__ out, int mode, int f8) {
     const long nrec = (long)ntiles * nchunks * tapsp * 64;
     const int npar = mode ? 8 : 1;
     for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < nrec * 16 * npar; i0 += (long)gridDim.x * 256) {
@@ -646,11 +790,17 @@ __global__ __launch_bounds__(256) void pack_weights_h3v2_kernel(const float* __r
             v *= scale;
         }
         const _Float16 hi = (_Float16)v;
-        const _Float16 lo = (_Float16)(v - (float)hi);
         _Float16* r = out + ((long)par * nrec + rec) * REC;
         const int sw = (pos >> 2) & 3;
         r[(((k >> 3) ^ sw) << 3) + (k & 7)] = hi;
-        r[(((2 + (k >> 3)) ^ sw) << 3) + (k & 7)] = lo;
+        if (f8) {
+            // H3F8 record (dm3d_h3.h): slot 2 + (k >> 3) = [bl8 x8 | bh8 x8] with bl8 = fp8((w - hi) * 4), bh8 = fp8(hi * 2^-11)
+            unsigned char* s8 = reinterpret_cast<unsigned char*>(r + (((2 + (k >> 3)) ^ sw) << 3));
+            s8[k & 7] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32((v - (float)hi) * 4.0f, 0.0f, 0, false) & 0xff);
+            s8[8 + (k & 7)] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32((float)hi * 0.00048828125f, 0.0f, 0, false) & 0xff);
+        } else {
+            r[(((2 + (k >> 3)) ^ sw) << 3) + (k & 7)] = (_Float16)(v - (float)hi);
+        }
     }
 }
 
@@ -733,8 +883,22 @@ static bool use_wide(const ConvArgs& a) {
 
 bool dm3d_conv_h3v2_wide(const ConvArgs& a) { return use_wide(a); }
 
+// The float8 cross-term form (F8) serves a launch when the caller supplied the second weight image (wpk_f8) and the grid is large enough
+// for 8-slice bricks.  (A fused skip phase keeps its own staging, weight image and three-pass arithmetic; the hand-off output format is
+// the epilogue's business: both are independent of the main loop's operand format.)
+bool dm3d_conv_h3v2_f8(const ConvArgs& a) {
+    static const int min_wgs = [] { const char* e = getenv("DM3D_CONV_WIDE_WGS"); return e ? atoi(e) : 512; }();
+    if (!a.wpk_f8) return false;
+    const long wgs = (long)a.batch * ((a.od + 7) / 8) * ((a.oh + 7) / 8) * ((a.ow + 7) / 8) * (a.coutpad / 64) * (a.parity ? 8 : 1);
+    return wgs >= min_wgs;
+}
+
 template <int KS, int MODE>
 static int launch_any(ConvArgs& a, hipStream_t st) {
+    if (dm3d_conv_h3v2_f8(a)) {
+        static const int f8_td = [] { const char* e = getenv("DM3D_CONV_F8_TD"); return e ? atoi(e) : 8; }();     // A/B: 4 = 4-slice bricks, two workgroups per CU
+        return f8_td == 4 ? launch_v2<KS, MODE, 4, 2, 1>(a, st) : launch_v2<KS, MODE, 8, 3, 1>(a, st);
+    }
     return use_wide(a) ? launch_v2<KS, MODE, 8, 3>(a, st) : launch_v2<KS, MODE, 4, 2>(a, st);
 }
 
@@ -744,15 +908,17 @@ int dm3d_conv_launch_h3v2(ConvArgs& a, int which, hipStream_t st) {
     return a.pscale ? launch_any<3, 1>(a, st) : launch_any<3, 0>(a, st);
 }
 
-int64_t dm3d_h3v2_image_bytes(int taps, int cin, int cout) {
-    const int tapsp = (taps + 3) / 4 * 4;
+// f8: the image of the float8 cross-term form (taps padded to a multiple of 8, records in the H3F8 layout)
+int64_t dm3d_h3v2_image_bytes(int taps, int cin, int cout, int f8) {
+    const int g = 4, tapsp = (taps + g - 1) / g * g;
     return (int64_t)tapsp * dm3d_round_up(cout, 64) * (dm3d_round_up(cin, 16) / 16) * REC * (int64_t)sizeof(_Float16);
 }
 
 int dm3d_pack_h3v2(const float* keras_kernel, int taps, int cin, int cout, int w_exp, const float* in_scale, void* packed, int mode,
-                   hipStream_t st) {
+                   int f8, hipStream_t st) {
     const int nchunks = (int)(dm3d_round_up(cin, 16) / 16), ntiles = (int)(dm3d_round_up(cout, 64) / 64);
-    hipLaunchKernelGGL(pack_weights_h3v2_kernel, dim3(4096), dim3(256), 0, st, keras_kernel, taps, (taps + 3) / 4 * 4, cin, cout,
-                       nchunks, ntiles, ldexpf(1.0f, w_exp), in_scale, static_cast<_Float16*>(packed), mode);
+    const int g = 4;
+    hipLaunchKernelGGL(pack_weights_h3v2_kernel, dim3(4096), dim3(256), 0, st, keras_kernel, taps, (taps + g - 1) / g * g, cin, cout,
+                       nchunks, ntiles, ldexpf(1.0f, w_exp), in_scale, static_cast<_Float16*>(packed), mode, f8);
     return dm3d_launch_check("pack_weights_h3v2_kernel");
 }

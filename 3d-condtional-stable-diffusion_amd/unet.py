@@ -55,6 +55,7 @@ class _Conv:
         self.precision, self.w_exp = precision, w_exp
         self.cin_pad = -(-cin // _lib.CIN_PAD) * _lib.CIN_PAD
         self.h2 = None              # DM3D_FMT_H2 copy of wpk ([cout_pad][cin_pad]) for the H3 GEMM
+        self.wpk_f8 = None          # second image for the float8 cross-term form (precision "h3f8")
 
 
 class UNet:
@@ -67,9 +68,14 @@ class UNet:
         DM3D_PRECISION environment variable, else "h3"."""
         import os
         precision = precision or os.environ.get("DM3D_PRECISION", "h3")
-        if precision not in ("fp32", "h3"):
-            raise ValueError("precision must be 'fp32' or 'h3'")
-        self.precision = precision
+        if precision not in ("fp32", "h3", "h3f8"):
+            raise ValueError("precision must be 'fp32', 'h3' or 'h3f8'")
+        # "h3f8": the H3 kernels with the two cross terms of the k3 / UpSample convs on float8 operands where the launch is large enough
+        # (dm3d_conv_desc.wpk_f8; eps error 5-9e-5 instead of 5-8e-6, activations clamped at 448 instead of 65504).  Everything else
+        # (GEMMs, attention, small grids) is plain "h3", which is what self.precision says from here on.
+        self.f8 = precision == "h3f8"
+        self.precision_name = precision
+        self.precision = "h3" if self.f8 else precision
         self.fuse_skip = os.environ.get("DM3D_FUSE_SKIP", "1") != "0"      # A/B switch: ResidualBlock 1x1 skip conv inside conv2's launch
         self.h2_handoff = os.environ.get("DM3D_H2_HANDOFF", "1") != "0"    # A/B switch: conv1 -> conv2 hand-off in DM3D_FMT_H2
         self.cfg = cfg
@@ -134,7 +140,11 @@ class UNet:
                 w_exp = 0 if wmax == 0.0 or not np.isfinite(wmax) else max(-100, min(100, int(13 - np.floor(np.log2(wmax)))))
                 wpk = torch.empty(lib().dm3d_packed_weight_up_h3_bytes(cin, cout) // 2, dtype=torch.float16, device=self.device)
                 check(lib().dm3d_pack_weights_up_h3(raw.data_ptr(), cin, cout, w_exp, wpk.data_ptr(), _stream()), "pack_weights_up_h3")
-                return _Conv(wpk, dbias, taps, cin, cout, _lib.PREC_H3, w_exp)
+                cv = _Conv(wpk, dbias, taps, cin, cout, _lib.PREC_H3, w_exp)
+                if self.f8 and lib().dm3d_conv_weight_layout(3, 1, 1, 0, cout) == _lib.WL_PAIR:
+                    cv.wpk_f8 = torch.empty(8 * lib().dm3d_packed_weight_h3f8_bytes(8, cin, cout) // 2, dtype=torch.float16, device=self.device)
+                    check(lib().dm3d_pack_weights_h3f8(raw.data_ptr(), 8, cin, cout, w_exp, None, cv.wpk_f8.data_ptr(), 1, _stream()), "pack_weights_h3f8")
+                return cv
             wpk = torch.empty(lib().dm3d_packed_weight_up_elems(cin, cout), dtype=torch.float32, device=self.device)
             check(lib().dm3d_pack_weights_up(raw.data_ptr(), cin, cout, wpk.data_ptr(), _stream()), "pack_weights_up")
             return _Conv(wpk, dbias, taps, cin, cout)
@@ -146,6 +156,13 @@ class UNet:
                 wpk = torch.empty(lib().dm3d_packed_weight_h3p_bytes(taps, cin, cout) // 2, dtype=torch.float16, device=self.device)
                 check(lib().dm3d_pack_weights_h3p(raw.data_ptr(), taps, cin, cout, w_exp, _ptr(in_scale), wpk.data_ptr(), 0,
                                                   _stream()), "pack_weights_h3p")
+                if self.f8 and taps == 27:
+                    f8img = torch.empty(lib().dm3d_packed_weight_h3f8_bytes(taps, cin, cout) // 2, dtype=torch.float16, device=self.device)
+                    check(lib().dm3d_pack_weights_h3f8(raw.data_ptr(), taps, cin, cout, w_exp, _ptr(in_scale), f8img.data_ptr(), 0,
+                                                       _stream()), "pack_weights_h3f8")
+                    cv = _Conv(wpk, self._dev(bias) if bias is not None else None, taps, cin, cout, _lib.PREC_H3, w_exp)
+                    cv.wpk_f8 = f8img
+                    return cv
             else:
                 wpk = torch.empty(lib().dm3d_packed_weight_h3_bytes(taps, cin, cout) // 2, dtype=torch.float16, device=self.device)
                 check(lib().dm3d_pack_weights_h3(raw.data_ptr(), taps, cin, cout, w_exp, _ptr(in_scale), wpk.data_ptr(),
@@ -232,7 +249,8 @@ class UNet:
         """Bound on |activation| below which no H3 operand path can leave the float16 range (include/dm3d.h, range_flag): a raw
         consumer clamps at 65504; a consumer behind a folded BatchNormalization sees silu(x*scale + shift), |.| <= |x| max|scale| +
         max|shift|.  (GroupNormalization normalises per sample: |x_hat| <= sqrt(group size), no bound on x is needed.)"""
-        lim = 65504.0
+        top = 448.0 if self.f8 else 65504.0          # the float8 cross-term form clamps activations at 448 (dm3d_h3.h)
+        lim = top
         if self.cfg.norm == "batch":
             s = self.state
             for name in s:
@@ -242,7 +260,7 @@ class UNet:
                     shift = np.abs(s[f"{base}.beta"].astype(np.float64) - s[f"{base}.mean"].astype(np.float64) * scale)
                     smax = float(scale.max())
                     if smax > 0:
-                        lim = min(lim, (65504.0 - float(shift.max())) / smax)
+                        lim = min(lim, (top - float(shift.max())) / smax)
         return max(lim, 1.0)
 
     def check_range(self, plan: "Plan"):
@@ -252,6 +270,10 @@ class UNet:
             return
         if int(plan.range_flag.item()) != 0:
             plan.range_flag.zero_()
+            if self.f8:
+                raise _lib.Dm3dError(
+                    f"an activation exceeded the range the float8 cross-term (precision='h3f8') kernels cover (|x| > {self.range_limit:.4g}); "
+                    "the result would differ from float32 arithmetic. Rebuild the model with precision='h3' (range 65504) or 'fp32'.")
             raise _lib.Dm3dError(
                 f"an activation exceeded the range the split-float16 (precision='h3') kernels represent exactly (|x| > {self.range_limit:.4g}); "
                 "the result would differ from float32 arithmetic. Rebuild the model with precision='fp32'.")
@@ -520,6 +542,8 @@ class Plan:
             self._keep += [post[0], post[1]]
         d.out_fmt = _lib.FMT_H2 if out_h2 else _lib.FMT_F32
         d.x1_fmt = _lib.FMT_H2 if x1_h2 else _lib.FMT_F32
+        if w.wpk_f8 is not None:
+            d.wpk_f8 = w.wpk_f8.data_ptr()
         if self.range_flag is not None and w.precision == _lib.PREC_H3:
             d.range_flag, d.range_limit = self.range_flag.data_ptr(), self.net.range_limit
         skip_flops = 0.0
@@ -530,18 +554,21 @@ class Plan:
         self._keep.append(d)
         up = 2 if upsample else 1
         eo = -(-edge_in * up // stride)
+        form = lib().dm3d_conv_tile_form(C.byref(d)) if w.precision == _lib.PREC_H3 else 0
         # kinds follow the kernel instantiations rocprofv3 lists, so bench.py's per-kernel averages can be checked against it
         if w.taps == 1:
             kind = "conv_k1"
         elif stride == 2:
             kind = "conv_k3s2"
+        elif form == 9:
+            kind = "conv_f8_up" if upsample else ("conv_f8_h2in" if x1_h2 else "conv_f8")    # conv3d_igemm_h3v2<KS, MODE, 8, 2, 1>: float8 cross terms
         elif upsample:
             kind = "conv_up"            # 8 parity 2x2x2 convs
         elif w.cout <= 32 and w.precision == _lib.PREC_H3:
             kind = "conv_k3s1_n32"      # conv_in / conv_out: one 32-column tile
         elif x1_h2:
             kind = "conv_k3s1_h2in"     # kernel MODE 2: pre-activated DM3D_FMT_H2 input (ResidualBlock conv2 behind a hand-off)
-        elif w.precision == _lib.PREC_H3 and pro is not None and lib().dm3d_conv_tile_form(C.byref(d)) == 4:
+        elif w.precision == _lib.PREC_H3 and pro is not None and form == 4:
             kind = "conv_k3s1_td4"      # conv3d_igemm_h3v2<3, 1, 4, 2>: the 4-slice form (small grids, fused skip phase)
         else:
             kind = "conv_k3s1"          # h3: conv3d_igemm_h3v2<3, 1, 8, 3> (prologue, 8-slice bricks); fp32: conv3d_igemm_f32
@@ -551,8 +578,9 @@ class Plan:
                           # algorithmic; a fused 1x1 skip conv counts its own FLOPs here
                           "flops": 2.0 * w.taps * w.cin * w.cout * self.B * eo ** 3 + skip_flops,
                           # MFMA work actually issued: the upsample conv runs as 8 parity convs of 8 taps on the low-res grid
+                          # (float8 form: 1 float16 + 2/2.25 float8-rate units per product, counted in float16-MFMA-equivalent FLOPs)
                           "exec_flops": (2.0 * (8 if upsample else w.taps) * w.cin * w.cout * self.B * eo ** 3 + skip_flops)
-                                        * (3 if w.precision == _lib.PREC_H3 else 1),
+                                        * ((1 + 2 / 2.25 if form == 9 else 3) if w.precision == _lib.PREC_H3 else 1),
                           "bytes": 4.0 * self.B * (edge_in ** 3 * (w.cin + (skip[2] + skip[3] if skip is not None else 0))
                                                    + eo ** 3 * w.cout)}))
 
@@ -582,7 +610,8 @@ class Plan:
         P = net.P
         S = cfg.img_size
         if self.range_flag is not None:        # the caller's x_t is the one tensor on an H3 operand path that no dm3d kernel wrote
-            self.ops.append((lib().dm3d_range_check, (self.x.data_ptr(), self.x.numel(), 65504.0, self.range_flag.data_ptr()), "range", {}))
+            self.ops.append((lib().dm3d_range_check, (self.x.data_ptr(), self.x.numel(), 448.0 if self.net.f8 else 65504.0,
+                                                       self.range_flag.data_ptr()), "range", {}))
         h = self._buf(B, S, S, S, cfg.first_conv_channels)
         self._conv(P["conv_in"], self.x, h, S)
         skips = [(h, cfg.first_conv_channels)]
@@ -841,7 +870,7 @@ class Plan:
                 check(lib().dm3d_gather_rows(tab.data_ptr(), tab.shape[0], ids.data_ptr(), buf.data_ptr(), buf.shape[0],
                                              buf.shape[1], st), "gather_rows")
 
-    _RANGE_OF = {"conv_k3s1_td4": "conv", "conv_k1": "conv", "conv_k3s2": "conv", "conv_up": "conv", "conv_k3s1_n32": "conv", "conv_k3s1_h2in": "conv", "conv_k3s1": "conv",
+    _RANGE_OF = {"conv_f8": "conv", "conv_f8_h2in": "conv", "conv_f8_up": "conv", "conv_k3s1_td4": "conv", "conv_k1": "conv", "conv_k3s2": "conv", "conv_up": "conv", "conv_k3s1_n32": "conv", "conv_k3s1_h2in": "conv", "conv_k3s1": "conv",
                  "gemm": "attn", "gemm_h3": "attn", "attn_fused": "attn", "softmax": "attn", "layernorm": "attn", "groupnorm": "norm", "affine": "norm",
                  "range": "guard"}
 

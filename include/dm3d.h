@@ -21,9 +21,9 @@
 extern "C" {
 #endif
 
-#define DM3D_VERSION 106          /* major*100 + minor; the descriptor structs grew in 101 (w_layout), 102 (scratch), 103 (skip_*),
+#define DM3D_VERSION 107          /* major*100 + minor; the descriptor structs grew in 101 (w_layout), 102 (scratch), 103 (skip_*),
                                      104 (dm3d_attention), 105 (x1_fmt / out_fmt / post_*), 106 (ddpm seed_dev; conv/gemm range_flag; the
-                                     training entries): a host built against an older header must be rebuilt */
+                                     training entries), 107 (conv wpk_f8: the float8 cross-term form): a host built against an older header must be rebuilt */
 
 #define DM3D_OK            0
 #define DM3D_EINVAL       -1      /* bad argument (shape, alignment, null pointer) */
@@ -103,6 +103,11 @@ int     dm3d_pack_weights_convt_h3(const float* keras_kernel, int32_t cin, int32
 int64_t dm3d_packed_weight_h3p_bytes(int32_t taps, int32_t cin, int32_t cout);
 int     dm3d_pack_weights_h3p(const float* keras_kernel, int32_t taps, int32_t cin, int32_t cout, int32_t w_exp,
                               const float* in_scale, void* packed, int32_t mode, void* stream);
+/* image for dm3d_conv_desc.wpk_f8: the DM3D_WL_PAIR geometry with taps padded to a multiple of 8 and records [hi16 c0-7 | hi16 c8-15 |
+ * bl8 c0-7, bh8 c0-7 | bl8 c8-15, bh8 c8-15] (float8 e4m3: bl8 = fp8(lo * 4), bh8 = fp8(hi * 2^-11)); modes as dm3d_pack_weights_h3p */
+int64_t dm3d_packed_weight_h3f8_bytes(int32_t taps, int32_t cin, int32_t cout);
+int     dm3d_pack_weights_h3f8(const float* keras_kernel, int32_t taps, int32_t cin, int32_t cout, int32_t w_exp,
+                               const float* in_scale, void* packed, int32_t mode, void* stream);
 /* the layout dm3d_conv3d_ndhwc wants in wpk for a DM3D_PREC_H3 conv of this geometry (what w_layout must say) */
 int32_t dm3d_conv_weight_layout(int32_t ksize, int32_t stride, int32_t upsample, int32_t transpose, int32_t cout);
 /* image of a 1x1 kernel [cin, cout] for dm3d_conv_desc.skip_wpk (two 16-channel chunks per MFMA k-step) */
@@ -179,12 +184,21 @@ typedef struct dm3d_conv_desc {
        range_limit / 2).  The host reads the flag once per generate() / forward and raises instead of returning clamped results
        (rerun with DM3D_PREC_F32).  NULL: no check. */
     int32_t* range_flag; float range_limit;
+    /* Optional second weight image for the "H3F8" arithmetic (DM3D_PREC_H3 k3 / stride-1 / UpSample / Conv3DTranspose convs with cout > 32):
+       a.b = ah.bh on float16 MFMA as in H3, the two cross terms ah.bl + al.bh on float8 (e4m3) operands through
+       v_mfma_scale_f32_16x16x128_f8f6f4 (2.25x the float16 rate): 1.9 instead of 3 MFMA units per product.  The cross terms are 2^-11 of
+       a product, so their float8 rounding (2^-4) costs ~2^-15 relative per product — eps of the whole U-Net 5-9e-5 against the 1e-3 contract
+       (H3: 5-8e-6) — and activations are clamped at +-448 instead of +-65504 (range_limit must be <= 448 for such a launch's producers).
+       Packed by dm3d_pack_weights_h3f8 with THIS conv's w_exp.  The kernel uses it when the launch has enough bricks for its 8-slice form
+       (dm3d_conv_tile_form() == 9) and no fused skip conv / hand-off output; otherwise wpk serves the launch as before.  NULL: never. */
+    const void* wpk_f8;
 } dm3d_conv_desc;
 
 int     dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream);
 int64_t dm3d_conv_scratch_bytes(const dm3d_conv_desc* d);
 /* Which tile form of the 16x16x32 conv kernel serves this descriptor: 8 (8 z-slices per brick, 512 threads, three weight buffers — launches
- * with enough bricks to fill the chip at one workgroup per CU), 4 (4 slices, 256 threads, two buffers), 0 (another kernel).  Profiling
+ * with enough bricks to fill the chip at one workgroup per CU), 9 (the 8-slice form in H3F8 arithmetic: wpk_f8 given and eligible),
+ * 4 (4 slices, 256 threads, two buffers), 0 (another kernel).  Profiling
  * harnesses use it to name the instantiation a launch runs (rocprofv3 lists conv3d_igemm_h3v2<KS, MODE, 8, 3> and <KS, MODE, 4, 2>). */
 int32_t dm3d_conv_tile_form(const dm3d_conv_desc* d);
 

@@ -460,6 +460,62 @@ def test_sampler_guards_and_fresh_seeds(dev):
     assert torch.equal(c, d)
 
 
+REGRESSION_F8 = 2e-4   # precision="h3f8" delivers ~4e-5 (float8 cross terms); the contract stays TOL = 1e-3
+
+
+def test_unet_eps_h3f8_full_batch_32cube(dev):
+    """precision="h3f8" at the bench shape (32^3 x 8ch, B = 32: the batch at which the float8 cross-term conv form has enough bricks to
+    run) against the oracle on this box's CPU, mixed timesteps and both context ids; and the plan really runs the float8 kernels."""
+    import dm3d_amd
+    from dm3d_amd.unet import UNet
+    from oracle import ref_torch as rt
+    B, C = 32, 8
+    cfg = dm3d_amd.UNetConfig(img_size=32, img_channels=C)
+    W = dm3d_amd.synthetic_weights(cfg, seed=0)
+    net = UNet(cfg, weights=W, precision="h3f8")
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(B, 32, 32, 32, C, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    ctx = torch.randint(0, 2, (B, 1, 1), generator=g)
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    Wt = {k: torch.from_numpy(v) for k, v in W.items()}
+    ref = torch.cat([rt.unet_forward(Wt, rt.UNetConfig(img_size=32, img_channels=C), x[i:i + 8], t[i:i + 8], ctx[i:i + 8]) for i in range(0, B, 8)])
+    eps = net([x.to(dev), t, ctx])
+    torch.cuda.synchronize()
+    kinds = net.plan(B, B, per_sample_context=True).count()
+    assert kinds.get("conv_f8", 0) >= 10 and kinds.get("conv_f8_h2in", 0) >= 10 and kinds.get("conv_f8_up", 0) == 2, kinds
+    err = _rel(eps, ref)
+    per_sample = [_rel(eps[i], ref[i]) for i in range(B)]
+    erel = _elem_rel(eps, ref)
+    print(f"[h3f8] 32^3x{C} B={B} eps rel err {err:.3e} (worst sample {max(per_sample):.1e}), element-relative {erel:.3e}; kinds {kinds}")
+    assert err < TOL and max(per_sample) < TOL                        # the contract (north_star: 1e-3 relative)
+    assert err < REGRESSION_F8 and max(per_sample) < REGRESSION_F8    # the regression bar of this arithmetic
+    h3 = UNet(cfg, weights=W, precision="h3")([x.to(dev), t, ctx])
+    assert _rel(h3, ref) < REGRESSION                                  # same inputs, three-pass form: the usual bar
+    assert not torch.equal(h3, eps)
+
+
+def test_h3f8_range_guard_is_448(dev):
+    """The float8 cross-term form clamps activations at +-448 (e4m3's largest finite value; the conversions return NaN beyond it, so the
+    staging clamps): in precision="h3f8" a larger activation raises — pointing at "h3" — where "h3" computes it."""
+    import dm3d_amd
+    from dm3d_amd import _lib
+    from dm3d_amd.unet import UNet
+    cfg = dm3d_amd.UNetConfig(img_size=8, img_channels=4)
+    W = dm3d_amd.synthetic_weights(cfg, seed=0)
+    x = torch.randn(1, 8, 8, 8, 4, generator=torch.Generator().manual_seed(3))
+    t, ctx = torch.tensor([10]), torch.tensor([[[1]]])
+    net = UNet(cfg, weights=W, precision="h3f8")
+    ok = net([x.to(dev), t, ctx])
+    assert net.range_limit <= 448.0                                  # (set by prepare())
+    big = x.clone()
+    big[0, 3, 3, 3, 1] = 1000.0
+    with pytest.raises(_lib.Dm3dError, match="h3f8"):
+        net([big.to(dev), t, ctx])
+    assert torch.equal(ok, net([x.to(dev), t, ctx]))
+    UNet(cfg, weights=W, precision="h3")([big.to(dev), t, ctx])      # inside the three-pass form's range: no error
+
+
 def test_h3_range_guard_raises_instead_of_clamping(dev):
     """The split-float16 kernels clamp operands at +-65504.  A value beyond that must surface as an error (or be computed exactly
     by the float32 kernels), never as a silently clamped result (csrc/dm3d_h3.h split8)."""

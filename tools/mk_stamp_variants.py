@@ -50,15 +50,15 @@ s=must(s, """    if (NBUF == 3) __builtin_amdgcn_s_waitcnt(0x0F70);          // 
 s=must(s, """        load_halo(ch + 1 < c_hi ? ch + 1 : ch);
         __builtin_amdgcn_sched_barrier(0);
 
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {""","""        if (ch - c_lo < 12) STAMP(2 + 2 * (ch - c_lo));
+        // end of a weight group: advance the ring, wait for the next group's DMA, one barrier""","""        if (ch - c_lo < 12) STAMP(2 + 2 * (ch - c_lo));
         load_halo(ch + 1 < c_hi ? ch + 1 : ch);
         __builtin_amdgcn_sched_barrier(0);
 
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {""")
+        // end of a weight group: advance the ring, wait for the next group's DMA, one barrier""")
 s=must(s, """            wb = wb + 1 == NBUF ? 0 : wb + 1;
+            const bool last_group = g + 1 == NG;
             if (!last_group) {""","""            wb = wb + 1 == NBUF ? 0 : wb + 1;
+            const bool last_group = g + 1 == NG;
             if (last_group && ch - c_lo < 12) STAMP(3 + 2 * (ch - c_lo));
             if (!last_group) {""")
 s=must(s, """    // ---- epilogue.  Accumulator register r of tile""","""    STAMP(28);

@@ -13,11 +13,11 @@ out=$PWD/gpurun_out
 mkdir -p $out
 python3 bench.py --precision $prec --steps 30 --warmup 5 2> $out/${tag}_bench.log | tail -1 > $out/${tag}_bench.json
 echo "bench done: $(cut -c1-160 $out/${tag}_bench.json)"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_stats -o run -- python3 bench.py --precision $prec --steps 10 --warmup 2 --no-cpu-baseline --no-fp32-mode --no-full-chain > $out/prof_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_stats -o run -- python3 bench.py --precision $prec --steps 10 --warmup 2 --no-cpu-baseline --no-fp32-mode --no-h3f8-mode --no-full-chain > $out/prof_stats.log 2>&1
 cp $(find $out/prof_stats -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats.csv
 echo "stats done: $(sed -n 2p $out/${tag}_kernel_stats.csv | cut -c1-200)"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/prof_$c -o run -- python3 bench.py --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-full-chain --no-graph > $out/prof_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/prof_$c -o run -- python3 bench.py --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-h3f8-mode --no-full-chain --no-graph > $out/prof_$c.log 2>&1
   mkdir -p $out/pmc_$c && cp $(find $out/prof_$c -name "*counter_collection.csv" | head -1) $out/pmc_$c/pmc_counter_collection.csv
 done
 python3 profiles/summarize_pmc.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/${tag}_pmc_hbm.csv \
