@@ -131,6 +131,9 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
             if (iz >= 0 && iz < p.ind && iy >= 0 && iy < p.inh && ix >= 0 && ix < p.inw)
                 g = ((b * p.ind + iz) * p.inh + iy) * p.inw + ix;
         }
+#ifdef DM3D_EXP_HALO_CACHED           // timing experiment: every halo load hits the same few cache-resident voxels (results are wrong)
+        if (g >= 0) g &= 1023;
+#endif
         gvox[j] = g;
         const int v = (hv / HW) * HWP + hv % HW;
         st_off[j] = hv < HVOX ? v * REC + ((piece ^ swz(v)) << 3) : -1;
@@ -177,15 +180,12 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
     f32x4 raw0[NSLOT], raw1[NSLOT];
     f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
     bool ok0 = false, ok1 = false;
-    auto load_halo = [&](int ch) {
+    // One slot (two 16-byte loads per thread) of chunk ch's halo; all slots of a chunk read the same channel piece.
+    auto load_halo_slot = [&](int ch, int j) {
         if (xh2) {                       // record ch of each voxel: hi piece at slot `piece`, lo piece at slot 2 + piece
-            const char* base = reinterpret_cast<const char*>(p.x1) + (size_t)ch * 64 + piece * 16;
-#pragma unroll
-            for (int j = 0; j < NSLOT; ++j) {
-                const char* qp = base + (size_t)(gvox[j] >= 0 ? gvox[j] : 0) * ((size_t)p.c1 * 4);
-                raw0[j] = *reinterpret_cast<const f32x4*>(qp);
-                raw1[j] = *reinterpret_cast<const f32x4*>(qp + 32);
-            }
+            const char* qp = reinterpret_cast<const char*>(p.x1) + (size_t)ch * 64 + piece * 16 + (size_t)(gvox[j] >= 0 ? gvox[j] : 0) * ((size_t)p.c1 * 4);
+            raw0[j] = *reinterpret_cast<const f32x4*>(qp);
+            raw1[j] = *reinterpret_cast<const f32x4*>(qp + 32);
             return;
         }
         const int c0 = ch * CK;
@@ -193,15 +193,19 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
         int ldc, cb;
         if (c0 < p.c1) { src = p.x1; ldc = p.c1; cb = c0; } else { src = p.x2; ldc = p.c2; cb = c0 - p.c1; }
         const int cpos = cb + piece * 8;
+        const int off0 = cpos < ldc ? cpos : 0, off1 = cpos + 4 < ldc ? cpos + 4 : 0;
+        const float* qp = src + (size_t)(gvox[j] >= 0 ? gvox[j] : 0) * ldc;
+        raw0[j] = *reinterpret_cast<const f32x4*>(qp + off0);
+        raw1[j] = *reinterpret_cast<const f32x4*>(qp + off1);
+    };
+    // what the conversion of chunk ch needs beside the voxels: channel validity and, behind a fused norm, the scale / shift vectors (PLOADS loads)
+    constexpr int PLOADS = pro ? 4 : 0;
+    auto load_chunk_params = [&](int ch) {
+        if (xh2) return;
+        const int c0 = ch * CK;
+        const int ldc = c0 < p.c1 ? p.c1 : p.c2, cpos = (c0 < p.c1 ? c0 : c0 - p.c1) + piece * 8;
         ok0 = cpos < ldc;
         ok1 = cpos + 4 < ldc;
-        const int off0 = ok0 ? cpos : 0, off1 = ok1 ? cpos + 4 : 0;
-#pragma unroll
-        for (int j = 0; j < NSLOT; ++j) {
-            const float* qp = src + (size_t)(gvox[j] >= 0 ? gvox[j] : 0) * ldc;
-            raw0[j] = *reinterpret_cast<const f32x4*>(qp + off0);
-            raw1[j] = *reinterpret_cast<const f32x4*>(qp + off1);
-        }
         if (pro) {
             const int s0 = ok0 ? c0 + piece * 8 : 0, s1 = ok1 ? c0 + piece * 8 + 4 : 0;
             const size_t bo = (size_t)b * p.pro_bstride;
@@ -211,18 +215,35 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
             sh1 = *reinterpret_cast<const f32x4*>(p.pshift + bo + s1);
         }
     };
+    auto load_halo = [&](int ch) {
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) load_halo_slot(ch, j);
+        load_chunk_params(ch);
+    };
+    // The next chunk's halo is requested inside this chunk's MFMA phase.  SPREAD: one slot per group (groups 0 .. NSLOT-1, behind the
+    // group's weight DMA) instead of all of them in front of group 0: requests return in order, so with everything issued up front the
+    // whole 64 KB per workgroup — 16 MB across the chip, in one burst — had to land before the wait for the DMA issued one group later
+    // could pass (two groups, ~2.8 us); measured with cache-resident halos the kernel was 8-10 % faster, i.e. that wait was exposed.
+#ifndef DM3D_HALO_SPREAD
+#define DM3D_HALO_SPREAD 1
+#endif
+    constexpr bool SPREAD = DM3D_HALO_SPREAD && NG > NSLOT;
+    // vector-memory requests issued inside group g of a chunk (beside its weight DMA)
+    auto halo_ops = [&](int g) { return SPREAD ? ((g >= 0 && g < NSLOT) ? 2 + (g == 0 ? PLOADS : 0) : 0) : 0; };
     load_halo(c_lo);
     // (NBUF == 3) Drain here, with an instruction hipcc's wait-count pass sees: the chunk loop's header otherwise merges "first chunk: the
     // halo loads are the newest requests" with "later chunks: 7 groups of DMAs were issued behind them" into vmcnt(0) on every iteration.
     if (NBUF == 3) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
 
-    int a_rec = a_rec0;
-    for (int ch = c_lo; ch < c_hi; ++ch) {
-        asm volatile("" : "+v"(a_rec));      // keeps the 14 per-pair operand addresses from being hoisted out of the chunk loop (spills)
-        h8 shi[NSLOT], slo[NSLOT];
+    // Conversion of a chunk's halo registers (prologue norm + SiLU, float16 split / float8 operands) into the pieces the LDS image takes,
+    // in place.  (Tried: converting chunk ch+1 inside chunk ch's MFMA phase, the two waves of a SIMD in different groups, so that only
+    // [barrier, LDS stores, barrier] remain between chunks — 2.5 % slower on the three-pass form, 5 % on the float8 form: the VALU work
+    // delays that wave's MFMAs more than the idle boundary costs.)
+    auto convert_halo = [&]() {
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) {
             const bool in = gvox[j] >= 0;
+            h8 shi_j, slo_j;
             f32x4 v0 = raw0[j], v1 = raw1[j];
             if (pro) {
 #pragma unroll
@@ -233,15 +254,22 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
             }
             if (xh2) {
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                shi[j] = __builtin_bit_cast(h8, in ? v0 : z);
-                slo[j] = __builtin_bit_cast(h8, in ? v1 : z);
-                if (F8) slo[j] = h2_to_x8(shi[j], slo[j]);              // (hi16, lo16) of the hand-off format -> [ah8 | al8]
+                shi_j = __builtin_bit_cast(h8, in ? v0 : z);
+                slo_j = __builtin_bit_cast(h8, in ? v1 : z);
+                if (F8) slo_j = h2_to_x8(shi_j, slo_j);                 // (hi16, lo16) of the hand-off format -> [ah8 | al8]
             } else if (F8) {
-                split8_f8(v0, v1, (in && ok0) ? DM3D_F8_LIMIT : 0.0f, (in && ok1) ? DM3D_F8_LIMIT : 0.0f, shi[j], slo[j]);
+                split8_f8(v0, v1, (in && ok0) ? DM3D_F8_LIMIT : 0.0f, (in && ok1) ? DM3D_F8_LIMIT : 0.0f, shi_j, slo_j);
             } else {
-                split8(v0, v1, (in && ok0) ? 65504.0f : 0.0f, (in && ok1) ? 65504.0f : 0.0f, shi[j], slo[j]);
+                split8(v0, v1, (in && ok0) ? 65504.0f : 0.0f, (in && ok1) ? 65504.0f : 0.0f, shi_j, slo_j);
             }
+            raw0[j] = __builtin_bit_cast(f32x4, shi_j);
+            raw1[j] = __builtin_bit_cast(f32x4, slo_j);
         }
+    };
+    int a_rec = a_rec0;
+    for (int ch = c_lo; ch < c_hi; ++ch) {
+        asm volatile("" : "+v"(a_rec));      // keeps the 14 per-pair operand addresses from being hoisted out of the chunk loop (spills)
+        convert_halo();
         // With weight groups in flight across barriers (NBUF == 3) every barrier is a raw s_barrier behind counted waits:
         // __syncthreads() would drain the VM counter, i.e. wait for the DMAs that are meant to stay in flight (cdna_hip_programming.md,
         // "glds with >1 tile in flight across the barrier").
@@ -255,8 +283,8 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) {
             if (st_off[j] >= 0) {
-                *reinterpret_cast<h8*>(lds_in + st_off[j]) = shi[j];
-                *reinterpret_cast<h8*>(lds_in + (st_off[j] ^ 16)) = slo[j];
+                *reinterpret_cast<h8*>(lds_in + st_off[j]) = __builtin_bit_cast(h8, raw0[j]);
+                *reinterpret_cast<h8*>(lds_in + (st_off[j] ^ 16)) = __builtin_bit_cast(h8, raw1[j]);
             }
         }
         if (NBUF == 2) {
@@ -270,8 +298,15 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
-        load_halo(ch + 1 < c_hi ? ch + 1 : ch);
+        const int ch_next = ch + 1 < c_hi ? ch + 1 : ch;           // (past the end: the last chunk again, unconditional like the DMAs)
+        if (!SPREAD) load_halo(ch_next);
         __builtin_amdgcn_sched_barrier(0);
+        // requests of group g behind its weight DMA
+        auto halo_in_group = [&](const int g) {
+            if (!SPREAD) return;
+            if (g < NSLOT) load_halo_slot(ch_next, g);
+            if (g == 0) load_chunk_params(ch_next);
+        };
 
         // end of a weight group: advance the ring, wait for the next group's DMA, one barrier
         auto group_end = [&](const int g) {
@@ -284,10 +319,19 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
                 } else {
                     // group g+1 must have landed; newer than it in the queue: group g+2's DMA and, behind the chunk's first iteration,
                     // the next chunk's halo loads (issued between the DMAs of g+1 and g+2)
-                    if (g == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT + 2 * NSLOT) : "memory");
-                    else        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT) : "memory");
+                    // (SPREAD: the requests issued beside the DMAs of groups g-1 and g, see halo_ops)
+                    const int extra = SPREAD ? halo_ops(g - 1) + halo_ops(g) : (g == 0 ? 2 * NSLOT : 0);
+                    if (extra == 0)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT) : "memory");
+                    else if (extra == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT + 2) : "memory");
+                    else if (extra == 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT + 4) : "memory");
+                    else if (extra == 6) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT + 6) : "memory");
+                    else if (extra == 8) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT + 8) : "memory");
+                    else if (extra == 2 * NSLOT) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT + 2 * NSLOT) : "memory");
+                    else                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT) : "memory");
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef DM3D_EXP_NO_GROUP_BARRIER      // timing experiment: results are wrong without it
                     __builtin_amdgcn_s_barrier();
+#endif
                     asm volatile("" ::: "memory");
                 }
             }
@@ -302,6 +346,7 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
                 const int b2 = wb + 2 >= 3 ? wb - 1 : wb + 2;
                 fetch_w(nxt < g_end ? nxt : g_end - 1, b2);
             }
+            halo_in_group(g);
             __builtin_amdgcn_sched_barrier(0);
             const _Float16* wbuf = lds_w + wb * WGRP;
 #pragma unroll
@@ -358,6 +403,7 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
                 const int b2 = wb + 2 >= 3 ? wb - 1 : wb + 2;
                 fetch_w(nxt < g_end ? nxt : g_end - 1, b2);
             }
+            halo_in_group(g);
             __builtin_amdgcn_sched_barrier(0);
             const _Float16* wbuf = lds_w + wb * WGRP;
             // halo offset (halfs) of this lane's hi slot: tap pair pr of group gg, patch pi (pad taps re-read the last real tap: zero weights)
