@@ -34,6 +34,7 @@ struct ConvArgs {
     const float* sx1; const float* sx2; int sc1, sc2; const void* swpk; int s_npairs;   // s_npairs = round_up(sc1+sc2, 32) / 32
     const void* wpk_f8;                      // optional second weight image: the float8 cross-term form (dm3d_h3.h "H3F8")
     int* range_flag; float range_limit;      // H3 range guard (include/dm3d.h): *range_flag = 1 if any |output| > range_limit
+    int epi_vec4;                            // h3v2: every epilogue operand is 16-byte aligned (cout, vec_ld % 4 == 0): 16-byte epilogue accesses
 };
 
 // which tile configuration a (ksize, stride) pair uses

@@ -87,6 +87,7 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
     constexpr int WSLOT = WGRP * 2 / 16 / NTHR;              // 16-byte pieces per thread: 4 (256 threads) or 2 (512)
     static_assert(WGRP * 2 / 16 % NTHR == 0, "weight group must be a whole number of pieces per thread");
     static_assert(NBUF == 2 || NBUF == 3, "two or three weight buffers");
+    static_assert(!F8 || (TD == 8 && NBUF == 3), "the float8 cross-term form exists for 8-slice bricks with three weight buffers");
 
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_v2[];
     _Float16* lds_w = smem_v2;                  // [NBUF][G][NT][REC]   (first: every weight read is base + a 16-bit immediate)
@@ -619,9 +620,85 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
     const int ystep = p.os * p.fw * p.cout;                              // one brick row further in the output
     float amax = 0.0f;                                                   // range guard: largest |value| this lane stores
     const float rlim = split ? 0.5f * p.range_limit : p.range_limit;     // two atomic halves: either may carry half the sum
+#ifndef DM3D_EPILOGUE_SCALAR
+    if (full && !split && p.epi_vec4) {
+        // Full brick, plain stores, aligned operands (the common case).  The MFMA leaves a lane with ONE channel of FOUR voxels (r = 0..3: brick rows); stored
+        // like that every access is 4 bytes per lane — 64 loads + 64 stores per lane with a residual, and the epilogue of a 64 -> 64 conv
+        // took 17-25 thousand cycles (in-kernel stamps), bound by the number of memory instructions, not by bytes.  A 4 x 4 transpose
+        // inside each quad of lanes (two DPP exchange rounds, 16 VALU per tile) gives a lane FOUR consecutive channels of ONE voxel
+        // (row k = n & 3, channels (n & ~3) .. +3): 16-byte accesses, a quarter of the instructions.  Per element the arithmetic and its
+        // order are those of the scalar path below (-DDM3D_EPILOGUE_SCALAR), so the results are bit-identical.
+        const int k = row & 3, c4 = row & ~3;
+        const bool b0 = (row & 1) != 0, b1 = (row & 2) != 0;
+        auto xor1 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)); };
+        auto xor2 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)); };
+        f32x4 rv4[4][4];
+        if (resz) {                                     // all residual pieces requested before the first one is used
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int pi = 0; pi < 4; ++pi)
+                    rv4[ni][pi] = *reinterpret_cast<const f32x4*>(resz + (((oy0 + 4 * (pi >> 1) + k) * p.os + ooy) * p.fw
+                                                                          + (ox0 + 4 * (pi & 1) + dxl) * p.os + oox) * p.cout + n0 + ni * 16 + c4);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + ni * 16 + c4;             // first of this lane's four channels
+            f32x4 add = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.vec) {
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(p.vec + (size_t)vrow * p.vec_ld + n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) add[j] += vv[j];
+            }
+            const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 ps = p.post_scale ? *reinterpret_cast<const f32x4*>(p.post_scale + n) : one;
+            const f32x4 pt = p.post_scale ? *reinterpret_cast<const f32x4*>(p.post_shift + n) : zero;
+            // DM3D_FMT_H2: the hi halves of channels n..n+3 are 8 contiguous bytes of the voxel's record, the lo halves 32 bytes further
+            const int h2off = (n >> 4) * 64 + ((n >> 3) & 1) * 16 + (n & 7) * 2 - n * 4;
+#pragma unroll
+            for (int pi = 0; pi < 4; ++pi) {
+                float a[4] = {acc[pi][ni][0], acc[pi][ni][1], acc[pi][ni][2], acc[pi][ni][3]};
+                {   // quad transpose: a[j] of lane k  <-  a[k] of lane j
+                    float s0 = b0 ? a[0] : a[1], s1 = b0 ? a[2] : a[3];
+                    float r0 = xor1(s0), r1 = xor1(s1);
+                    if (b0) { a[0] = r0; a[2] = r1; } else { a[1] = r0; a[3] = r1; }
+                    s0 = b1 ? a[0] : a[2]; s1 = b1 ? a[1] : a[3];
+                    r0 = xor2(s0); r1 = xor2(s1);
+                    if (b1) { a[0] = r0; a[1] = r1; } else { a[2] = r0; a[3] = r1; }
+                }
+                const int o = (((oy0 + 4 * (pi >> 1) + k) * p.os + ooy) * p.fw + (ox0 + 4 * (pi & 1) + dxl) * p.os + oox) * p.cout + n;
+                f32x4 al4 = zero;
+                if (prz) al4 = *reinterpret_cast<const f32x4*>(prz + o);
+                f32x4 v4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = fmaf(a[j], p.out_scale, add[j]);
+                    if (p.relu) v = fmaxf(v, 0.0f);
+                    if (prz) v = v > 0.0f ? v : al4[j] * v;
+                    if (resz) v += rv4[ni][pi][j];
+                    if (p.relu_out) v = fmaxf(v, 0.0f);
+                    if (p.post_scale) v = dm3d_silu(fmaf(v, ps[j], pt[j]));           // the consumer's norm + SiLU, applied once here
+                    DM3D_AMAX(amax, v);
+                    v4[j] = v;
+                }
+                if (p.out_h2) {
+                    const unsigned int w0 = split1_bits(v4[0]), w1 = split1_bits(v4[1]), w2 = split1_bits(v4[2]), w3 = split1_bits(v4[3]);
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    char* dst = reinterpret_cast<char*>(outz) + (size_t)o * 4 + h2off;
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{(w0 & 0xffffu) | (w1 << 16), (w2 & 0xffffu) | (w3 << 16)};
+                    *reinterpret_cast<u32x2*>(dst + 32) = u32x2{(w0 >> 16) | (w1 & 0xffff0000u), (w2 >> 16) | (w3 & 0xffff0000u)};
+                } else {
+                    *reinterpret_cast<f32x4*>(outz + o) = v4;
+                }
+            }
+        }
+        if (p.range_flag && amax > rlim) *p.range_flag = 1;
+        return;
+    }
+#endif
     if (full) {
-        // full brick (the common case): all 64 residual values of this lane are requested before the first one is used, so the
-        // epilogue pays one memory latency instead of sixteen
+        // full brick, scalar form (split-K launches add their halves atomically; -DDM3D_EPILOGUE_SCALAR: the A/B arm of the form above):
+        // all 64 residual values of this lane are requested before the first one is used
         float rv[4][4][4];
         if (resz) {
 #pragma unroll
@@ -772,6 +849,11 @@ int launch_v2(ConvArgs& a, hipStream_t st) {
     const size_t out_elems = (size_t)a.batch * a.fd * a.fh * a.fw * a.cout;
     a.split_atomic = 0;
     a.split_stride = 0;
+    {
+        auto al16 = [](const void* q) { return (reinterpret_cast<size_t>(q) & 15) == 0; };
+        a.epi_vec4 = a.cout % 4 == 0 && al16(a.out) && al16(a.bias) && al16(a.res) && al16(a.prelu) && al16(a.post_scale) && al16(a.post_shift)
+                     && al16(a.vec) && (a.vec == nullptr || a.vec_ld % 4 == 0);
+    }
     ConvArgs k = a;
     if (F8) k.wpk = a.wpk_f8;
     const bool linear = !a.relu && !a.prelu && !a.relu_out && a.res != a.out && a.x1 != a.out && a.x2 != a.out;
@@ -941,10 +1023,8 @@ bool dm3d_conv_h3v2_f8(const ConvArgs& a) {
 
 template <int KS, int MODE>
 static int launch_any(ConvArgs& a, hipStream_t st) {
-    if (dm3d_conv_h3v2_f8(a)) {
-        static const int f8_td = [] { const char* e = getenv("DM3D_CONV_F8_TD"); return e ? atoi(e) : 8; }();     // A/B: 4 = 4-slice bricks, two workgroups per CU
-        return f8_td == 4 ? launch_v2<KS, MODE, 4, 2, 1>(a, st) : launch_v2<KS, MODE, 8, 3, 1>(a, st);
-    }
+    // (the float8 form in 4-slice bricks, two workgroups per CU, was 8-12 % slower on the large grids and spilled registers: not built)
+    if (dm3d_conv_h3v2_f8(a)) return launch_v2<KS, MODE, 8, 3, 1>(a, st);
     return use_wide(a) ? launch_v2<KS, MODE, 8, 3>(a, st) : launch_v2<KS, MODE, 4, 2>(a, st);
 }
 

@@ -42,19 +42,13 @@ s=must(s, """    const int tid = threadIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;""",1)
 s=must(s, """    if (NBUF == 3) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
-
-    int a_rec = a_rec0;""","""    if (NBUF == 3) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
+""","""    if (NBUF == 3) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
     STAMP(1);
-
-    int a_rec = a_rec0;""")
-s=must(s, """        load_halo(ch + 1 < c_hi ? ch + 1 : ch);
-        __builtin_amdgcn_sched_barrier(0);
-
-        // end of a weight group: advance the ring, wait for the next group's DMA, one barrier""","""        if (ch - c_lo < 12) STAMP(2 + 2 * (ch - c_lo));
-        load_halo(ch + 1 < c_hi ? ch + 1 : ch);
-        __builtin_amdgcn_sched_barrier(0);
-
-        // end of a weight group: advance the ring, wait for the next group's DMA, one barrier""")
+""")
+s=must(s, """        if (!SPREAD) load_halo(ch_next);
+""","""        if (ch - c_lo < 12) STAMP(2 + 2 * (ch - c_lo));
+        if (!SPREAD) load_halo(ch_next);
+""")
 s=must(s, """            wb = wb + 1 == NBUF ? 0 : wb + 1;
             const bool last_group = g + 1 == NG;
             if (!last_group) {""","""            wb = wb + 1 == NBUF ? 0 : wb + 1;
