@@ -718,3 +718,30 @@ def test_conv3d_h3f8_handoff_pair(dev):
     ey, ey3 = _rel(y, y_ref), _rel(y3, y_ref)
     print(f"hand-off pair: conv1 {ea:.2e}, conv2 float8 {ey:.2e}, conv2 three-pass on the same input {ey3:.2e}")
     assert ea < F8_TOL and ey < F8_TOL
+
+
+def test_conv3d_h3f8_ragged_extent_concat_and_channel_masks(dev):
+    """The float8 form on a launch whose bricks are not all full (30 x 32 x 28 voxels: the scalar epilogue with its bounds checks), with a
+    concatenated input whose second part is not a multiple of 16 channels (32 + 20: zero-masked pieces in the staging) and Cout = 72 (a masked
+    second column tile), prologue + vec + relu + residual — against float64 and against the three-pass form of the same launch."""
+    from dm3d_amd import ops, _lib
+    g = torch.Generator().manual_seed(77)
+    B, dims, c1, c2, cout = 8, (30, 32, 28), 32, 20, 72
+    x1 = torch.randn(B, *dims, c1, generator=g)
+    x2 = torch.randn(B, *dims, c2, generator=g)
+    k = torch.randn(3, 3, 3, c1 + c2, cout, generator=g) / math.sqrt(27 * (c1 + c2))
+    bias, vec = torch.randn(cout, generator=g) * 0.1, torch.randn(B, cout, generator=g)
+    sc, sh = torch.rand(c1 + c2, generator=g) + 0.5, torch.randn(c1 + c2, generator=g) * 0.1
+    res = torch.randn(B, *dims, cout, generator=g)
+    ref = _conv_ref(x1, k, bias, x2=x2, pro=(sc, sh), vec=vec, relu=True, res=res)
+    c = lambda t: t.to(dev).contiguous()
+    wpk, w_exp = ops.pack_weights_h3(c(k))
+    f8 = ops.pack_weights_h3f8(c(k), w_exp)
+    kw = dict(x2=c(x2), bias=c(bias), vec=c(vec), pro_scale=c(sc), pro_shift=c(sh), relu=True, res=c(res), precision=_lib.PREC_H3, w_exp=w_exp)
+    out3 = ops.conv3d(c(x1), wpk, cout, 3, **kw)
+    out8 = ops.conv3d(c(x1), wpk, cout, 3, wpk_f8=f8, **kw)
+    torch.cuda.synchronize()
+    e3, e8 = _rel(out3, ref), _rel(out8, ref)
+    print(f"ragged: three-pass {e3:.2e}, float8 cross terms {e8:.2e}")
+    assert e3 < 2e-5 and e8 < F8_TOL
+    assert not torch.equal(out3, out8)
