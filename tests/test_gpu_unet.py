@@ -641,3 +641,33 @@ def test_generate_full_size_steps_match_oracle(dev):
     err = float((got.cpu() - x).abs().max())
     print(f"3 full-size DDPM steps: max abs difference {err:.2e} (values in [-1, 1] + noise)")
     assert err < 1e-4
+
+
+def test_rccl_collectives_the_bench_uses_single_rank(dev):
+    """bench.py's multi-GPU path talks through torch.distributed "nccl" (= RCCL): init with a device id, one flat float32 broadcast of the
+    weights, all_gather_object of the rank records, a float64 MAX all_reduce of the elapsed time, barriers.  A one-GPU box can hold one
+    RCCL rank only, so a fresh child process runs exactly those calls in a world of one (the two-rank logic is rehearsed over gloo in
+    test_bench_two_rank_rehearsal; N GPUs are the driver's to run)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, torch, torch.distributed as dist
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        flat = torch.arange(1 << 20, dtype=torch.float32, device=dev)
+        dist.broadcast(flat, src=0)
+        out = [None]
+        dist.all_gather_object(out, {"rank": 0, "sha": "abc"})
+        t = torch.tensor([1.25], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        parts = [torch.empty(4, 3, device=dev)]
+        dist.all_gather(parts, torch.ones(4, 3, device=dev))
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert out[0]["sha"] == "abc" and float(t.item()) == 1.25 and float(flat[-1]) == (1 << 20) - 1 and float(parts[0].sum()) == 12.0
+        print("rccl ok", dist.get_backend())
+        dist.destroy_process_group()
+    """)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl ok nccl" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
