@@ -240,9 +240,8 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
     // in place.  (Tried: converting chunk ch+1 inside chunk ch's MFMA phase, the two waves of a SIMD in different groups, so that only
     // [barrier, LDS stores, barrier] remain between chunks — 2.5 % slower on the three-pass form, 5 % on the float8 form: the VALU work
     // delays that wave's MFMAs more than the idle boundary costs.)
-    auto convert_halo = [&]() {
-#pragma unroll
-        for (int j = 0; j < NSLOT; ++j) {
+    auto convert_slot = [&](const int j) {
+        {
             const bool in = gvox[j] >= 0;
             h8 shi_j, slo_j;
             f32x4 v0 = raw0[j], v1 = raw1[j];
@@ -267,7 +266,130 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
             raw1[j] = __builtin_bit_cast(f32x4, slo_j);
         }
     };
+    auto convert_halo = [&]() {
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) convert_slot(j);
+    };
     int a_rec = a_rec0;
+
+    // ---- "Ping-pong" chunk loop of the three-pass 8-slice form (MI355X_MICROARCH.md, "Two waves per SIMD"): the two waves that share a SIMD
+    // (w and w + 4) alternate between a LOAD segment — the 16 ds_read_b128 of one tap pair into registers, plus every other duty: weight
+    // DMA, halo requests, operand conversion, counted waits — and a COMPUTE segment of the pair's 48 MFMAs on registers only, one barrier
+    // per segment, so that a SIMD's matrix pipe always has exactly one wave feeding it while the other fetches.  Both halves run the SAME
+    // instruction stream; half 1 passes one extra barrier in front of the loop (and half 0 one behind it), which shifts it by one segment.
+    // Stream per chunk: ST (store the converted halo pieces) | X (empty) | L0 C0 L1 C1 ... L13 C13.  Safety of the shared LDS images with
+    // the one-segment shift:  * halo: a half stores the new image at ST, two positions after its last read of the old one (L13) and one
+    // after the other half's; the first read of the new image (L0) is two positions behind ST, i.e. behind the other half's ST too.
+    // * weight ring (3 buffers, group g of the chunk in buffer wb): the DMA of group g+2 is issued at position 2g into the buffer group g-1 left
+    // at L(2g-1) — the other half passed its L(2g-1) one segment ago at the latest; group G is awaited (counted vmcnt) at L(2G-1), two
+    // positions before its first read at L(2G), so the other half's wait and a barrier lie between.  (The DMA itself is issued inside C(2g).)
+    // The conversion of the next chunk's halo (in place, slot by slot) rides in the load segments L8 .. L11, its requests in C0, C2, C4, C6.
+    // Per chunk the matrix pipe idles for the two short segments around ST only (the per-group form: ~4 700 cycles of convert / store /
+    // barriers per chunk and ~870 per group).
+#ifndef DM3D_PINGPONG
+#define DM3D_PINGPONG 1
+#endif
+    constexpr bool PP = DM3D_PINGPONG && TD == 8 && NBUF == 3 && KS == 3 && !F8 && NSLOT == 4;
+    if constexpr (PP) {
+        const int hsel = __builtin_amdgcn_readfirstlane(wave >> 2);
+        auto seg_barrier = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        convert_halo();                                   // the first chunk (its loads were drained above)
+        if (hsel) seg_barrier();
+        h8 ah[4], al[4], bh[4], bl[4];
+        for (int ch = c_lo; ch < c_hi; ++ch) {
+            asm volatile("" : "+v"(a_rec));
+            const int ch_next = ch + 1 < c_hi ? ch + 1 : ch;
+            // ---- ST
+#pragma unroll
+            for (int j = 0; j < NSLOT; ++j) {
+                if (st_off[j] >= 0) {
+                    *reinterpret_cast<h8*>(lds_in + st_off[j]) = __builtin_bit_cast(h8, raw0[j]);
+                    *reinterpret_cast<h8*>(lds_in + (st_off[j] ^ 16)) = __builtin_bit_cast(h8, raw1[j]);
+                }
+            }
+            seg_barrier();
+            // ---- X
+            seg_barrier();
+#pragma unroll
+            for (int pp = 0; pp < 2 * NG; ++pp) {
+                const int g = pp >> 1, pr = pp & 1;
+                // ---- L(pp): the operand reads go out first, the segment's other duties run while they are in flight
+                {
+                    const _Float16* wbuf = lds_w + wb * WGRP;
+                    const int ta = g * G + pr * 2, tb = ta + 1;
+                    const int tac = ta < TAPS ? ta : TAPS - 1, tbc = tb < TAPS ? tb : TAPS - 1;
+                    const int rec_a = ((tac / (KS * KS)) * HH + (tac / KS) % KS) * HWP + tac % KS;
+                    const int rec_b = ((tbc / (KS * KS)) * HH + (tbc / KS) % KS) * HWP + tbc % KS;
+                    const int v0 = a_rec + (half ? rec_b : rec_a);
+                    const int v1 = v0 + 4;
+                    const int o0 = v0 * REC + ((q ^ swz(v0)) << 3);
+                    const int o1 = v1 * REC + ((q ^ swz(v1)) << 3);
+#pragma unroll
+                    for (int py = 0; py < 2; ++py) {
+                        ah[py * 2 + 0] = *reinterpret_cast<const h8*>(lds_in + o0 + py * (48 * REC));
+                        ah[py * 2 + 1] = *reinterpret_cast<const h8*>(lds_in + o1 + py * (48 * REC));
+                        al[py * 2 + 0] = *reinterpret_cast<const h8*>(lds_in + (o0 ^ 16) + py * (48 * REC));
+                        al[py * 2 + 1] = *reinterpret_cast<const h8*>(lds_in + (o1 ^ 16) + py * (48 * REC));
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        bh[ni] = *reinterpret_cast<const h8*>(wbuf + (pr * 2 * NT + ni * 16) * REC + b_hi);
+                        bl[ni] = *reinterpret_cast<const h8*>(wbuf + (pr * 2 * NT + ni * 16) * REC + (b_hi ^ 16));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (pr == 1) {
+                    // group (pp + 1) / 2 (7 = the next chunk's first) must have landed: behind its DMA (issued in C(pp - 3)) this wave
+                    // issued the halo requests of C(pp - 3) and C(pp - 1) and the DMA of C(pp - 1)
+                    const int extra = halo_ops((pp - 3) / 2 - ((pp - 3) < 0 ? 1 : 0)) + halo_ops((pp - 1) / 2);
+                    if (extra == 0)       asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT) : "memory");
+                    else if (extra == 2)  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT + 2) : "memory");
+                    else if (extra == 4)  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT + 4) : "memory");
+                    else if (extra == 6)  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT + 6) : "memory");
+                    else if (extra == 8)  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT + 8) : "memory");
+                    else if (extra == 10) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT + 10) : "memory");
+                    else                  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT) : "memory");
+                }
+                if (pp >= 8 && pp < 8 + NSLOT) convert_slot(pp - 8);
+                __builtin_amdgcn_sched_barrier(0);
+                seg_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- C(pp): 48 MFMAs on registers, pass-major (consecutive MFMAs never share an accumulator; per accumulator the order
+                // al.bh, ah.bl, ah.bh is that of the per-group form, so the results are the same bits)
+#pragma unroll
+                for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[pi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[pi], bh[ni], acc[pi][ni], 0, 0, 0);
+                // The vector-memory requests ride here, among the MFMAs (an LDS-DMA piece costs ~60 cycles of issue beside bare MFMAs, 100-185
+                // beside ds_reads — MI355X_MICROARCH.md; in the load segment they made every second segment twice as long as a compute one)
+                if (pr == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int nxt = ch * NG + g + 2;
+                    const int b2 = wb + 2 >= 3 ? wb - 1 : wb + 2;
+                    fetch_w(nxt < g_end ? nxt : g_end - 1, b2);
+                    if (g < NSLOT) load_halo_slot(ch_next, g);
+                    if (g == 0) load_chunk_params(ch_next);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[pi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi], bl[ni], acc[pi][ni], 0, 0, 0);
+#pragma unroll
+                for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[pi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi], bh[ni], acc[pi][ni], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                seg_barrier();
+                if (pr == 1) wb = wb + 1 == NBUF ? 0 : wb + 1;
+            }
+        }
+        if (!hsel) seg_barrier();
+    } else
     for (int ch = c_lo; ch < c_hi; ++ch) {
         asm volatile("" : "+v"(a_rec));      // keeps the 14 per-pair operand addresses from being hoisted out of the chunk loop (spills)
         convert_halo();

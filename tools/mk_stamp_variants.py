@@ -75,6 +75,31 @@ s=must(s, """                    } else {
         STAMP(29);
         return;
     }""")
+# ping-pong loop: segment boundaries of the chunk loop's second chunk, waves 0 (half 0 -> entries 0..15 of the block's second row) and 4
+s=must(s, """    constexpr bool PP = DM3D_PINGPONG""", """#define STAMPW(i) do { if (g_dbg_stamps_c && (threadIdx.x == 0 || threadIdx.x == 256) && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 2048 && (i) < 16) g_dbg_stamps_c[(2048 + blockIdx.x) * 32 + (threadIdx.x ? 16 : 0) + (i)] = __builtin_readcyclecounter(); } while (0)
+    constexpr bool PP = DM3D_PINGPONG""")
+s=must(s, """            seg_barrier();
+            // ---- X
+            seg_barrier();""", """            if (ch == c_lo + 1) STAMPW(0);
+            seg_barrier();
+            if (ch == c_lo + 1) STAMPW(1);
+            // ---- X
+            seg_barrier();
+            if (ch == c_lo + 1) STAMPW(2);""")
+s=must(s, """                __builtin_amdgcn_sched_barrier(0);
+                seg_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- C(pp)""", """                __builtin_amdgcn_sched_barrier(0);
+                if (ch == c_lo + 1 && pp < 6) STAMPW(3 + 2 * pp);
+                seg_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- C(pp)""")
+s=must(s, """                __builtin_amdgcn_sched_barrier(0);
+                seg_barrier();
+                if (pr == 1) wb""", """                __builtin_amdgcn_sched_barrier(0);
+                if (ch == c_lo + 1 && pp < 6) STAMPW(4 + 2 * pp);
+                seg_barrier();
+                if (pr == 1) wb""")
 build(s, '_cst.hip', 'dm3d_conv_h3v2.o', 'variants/cst.so')
 
 # ---- gemm_tn_h3
