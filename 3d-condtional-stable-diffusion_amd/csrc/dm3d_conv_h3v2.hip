@@ -1127,6 +1127,7 @@ static bool use_wide(const ConvArgs& a) {
     static const long min_wgs = [] { const char* e = getenv("DM3D_CONV_WIDE_WGS"); return e ? atol(e) : 512L; }();
     if (mode == 0) return false;
     if (mode == 1 && (a.parity || a.s_npairs > 0)) return false;
+    if ((a.out_h2 || a.post_scale) && a.od % 8 != 0) return false;     // the fused output forms live in the full-brick epilogue: whole 8-slice bricks
     const long wgs = (long)a.batch * ((a.od + 7) / 8) * ((a.oh + 7) / 8) * ((a.ow + 7) / 8) * (a.coutpad / 64) * (a.parity ? 8 : 1);
     return wgs >= min_wgs;
 }
@@ -1139,6 +1140,7 @@ bool dm3d_conv_h3v2_wide(const ConvArgs& a) { return use_wide(a); }
 bool dm3d_conv_h3v2_f8(const ConvArgs& a) {
     static const int min_wgs = [] { const char* e = getenv("DM3D_CONV_WIDE_WGS"); return e ? atoi(e) : 512; }();
     if (!a.wpk_f8) return false;
+    if ((a.out_h2 || a.post_scale) && a.od % 8 != 0) return false;     // (as in use_wide)
     const long wgs = (long)a.batch * ((a.od + 7) / 8) * ((a.oh + 7) / 8) * ((a.ow + 7) / 8) * (a.coutpad / 64) * (a.parity ? 8 : 1);
     return wgs >= min_wgs;
 }

@@ -229,6 +229,22 @@ def test_conv3d_h3_tap_layout_arm(dev):
     assert " passed" in r.stdout
 
 
+def test_conv3d_8_slice_forms_on_every_shape(dev):
+    """DM3D_CONV_WIDE_WGS=1 DM3D_CONV_WIDE=2 (read when the library is loaded) send every k3 / parity conv to the 8-slice forms — the
+    ping-pong three-pass loop, the float8 form, skip phase and parity convs included — whatever its grid: the small, ragged and odd shapes
+    of the parity cases then run through the kernels the bench uses only on large grids.  One child interpreter."""
+    import os, subprocess, sys
+    if os.environ.get("DM3D_CONV_WIDE_WGS") == "1":
+        pytest.skip("already inside the 8-slice arm")
+    env = dict(os.environ, DM3D_CONV_WIDE_WGS="1", DM3D_CONV_WIDE="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "(test_conv3d or random_shapes) and not tap_layout_arm and not 8_slice_forms",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_conv3d_weight_layout_is_checked(dev):
     from dm3d_amd import ops, _lib
     lib = _lib.lib()
@@ -745,3 +761,26 @@ def test_conv3d_h3f8_ragged_extent_concat_and_channel_masks(dev):
     print(f"ragged: three-pass {e3:.2e}, float8 cross terms {e8:.2e}")
     assert e3 < 2e-5 and e8 < F8_TOL
     assert not torch.equal(out3, out8)
+
+
+@pytest.mark.parametrize("f8", [False, True], ids=["three_pass", "float8"])
+def test_conv3d_h2_handoff_on_a_grid_of_half_8_slice_bricks(dev, f8):
+    """D = 12: whole 4-slice bricks (what the hand-off output needs) but not whole 8-slice bricks, on a launch large enough for the 8-slice
+    forms (B = 16: 512 workgroups).  The fused output (norm + swish + DM3D_FMT_H2 store) lives in the full-brick epilogue, so such a launch
+    must stay on the 4-slice form — it once went to the 8-slice kernel, whose partial bricks stored plain float32 into the H2 tensor."""
+    from dm3d_amd import ops, _lib
+    from oracle import ref_torch as rt
+    g = torch.Generator().manual_seed(13)
+    B, dims, cm, cout = 16, (12, 32, 32), 32, 64
+    x = torch.randn(B, *dims, cm, generator=g)
+    k1 = torch.randn(3, 3, 3, cm, cout, generator=g) / math.sqrt(cm * 27)
+    b1 = torch.randn(cout, generator=g)
+    s2, t2 = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    a_ref = rt._swish(_conv_ref(x, k1, b1) * s2.double() + t2.double())
+    c = lambda t: t.to(dev).contiguous()
+    w1, e1 = ops.pack_weights_h3(c(k1))
+    kw = dict(wpk_f8=ops.pack_weights_h3f8(c(k1), e1)) if f8 else {}
+    a_h2 = ops.conv3d(c(x), w1, cout, 3, bias=c(b1), w_exp=e1, post=(c(s2), c(t2)), out_h2=True, precision=_lib.PREC_H3, **kw)
+    a_dec = ops.h2_to_f32(a_h2.reshape(-1, cout), cout).reshape(B, *dims, cout)
+    torch.cuda.synchronize()
+    assert _rel(a_dec, a_ref) < 2e-5
