@@ -671,3 +671,49 @@ def test_rccl_collectives_the_bench_uses_single_rank(dev):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rccl ok nccl" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_unet_h3f8_random_configs_through_the_8_slice_forms(dev):
+    """precision="h3f8" over a seeded sweep of build_model arguments with DM3D_CONV_WIDE_WGS=1 DM3D_CONV_WIDE=2 (a child interpreter: the
+    switches are read when the library loads), so that the float8 form, its hand-off twin, its UpSample parity form and the fused skip
+    phase behind it run on the small, odd-sized and GroupNorm configurations too — against the float64 oracle, bar max(3e-4, 8 x the
+    float32-vs-float64 conditioning of the case)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys, numpy as np, torch
+        sys.path.insert(0, os.getcwd())
+        sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+        import dm3d_amd
+        from dm3d_amd.unet import UNet
+        from oracle import ref_torch as rt
+        from test_gpu_unet import _random_unet_configs, _rel
+        dev = torch.device("cuda:0")
+        torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+        n_f8 = 0
+        for size, ch, B, _, kw in _random_unet_configs(6, 777):
+            cfg = dm3d_amd.UNetConfig(img_size=size, img_channels=ch, **kw)
+            W = dm3d_amd.synthetic_weights(cfg, seed=size + ch)
+            g = torch.Generator().manual_seed(9)
+            x = torch.randn(B, size, size, size, ch, generator=g)
+            t = torch.randint(0, 1000, (B,), generator=g)
+            ctx = torch.randint(0, 2, (B, 1, 1), generator=g)
+            ocfg = rt.UNetConfig(img_size=size, img_channels=ch, **kw)
+            Wt = {k: torch.from_numpy(v) for k, v in W.items()}
+            c = ctx if cfg.conditional else None
+            ref32 = rt.unet_forward(Wt, ocfg, x, t, c)
+            ref64 = rt.unet_forward({k: v.double() for k, v in Wt.items()}, ocfg, x.double(), t, c)
+            net = UNet(cfg, weights=W, precision="h3f8")
+            eps = net([x.to(dev), t, ctx] if cfg.conditional else [x.to(dev), t])
+            torch.cuda.synchronize()
+            kinds = net.plan(B, B, per_sample_context=bool(cfg.conditional)).count()
+            n_f8 += sum(v for k, v in kinds.items() if k.startswith("conv_f8"))
+            cond, err = _rel(ref32, ref64), _rel(eps, ref64)
+            print(f"s{size} c{ch} B{B} {kw['widths']} {kw['norm']}: err {err:.2e} cond {cond:.2e} f8 launches {sum(v for k, v in kinds.items() if k.startswith('conv_f8'))}")
+            assert err <= max(3e-4, 8 * cond), (size, ch, B, kw, err, cond)
+        assert n_f8 > 0
+        print("sweep ok")
+    """)
+    env = dict(os.environ, DM3D_CONV_WIDE_WGS="1", DM3D_CONV_WIDE="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "sweep ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
