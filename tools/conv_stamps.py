@@ -28,8 +28,8 @@ for name, e, cin, cout, res in (("32^3 64->64", 32, 64, 64, 1), ("32^3 192->64",
     print("  start->first halo issued:", int((s[:, 1] - s[:, 0]).mean()), " ->chunk0 staged:", int((s[:, 2] - s[:, 1]).mean()))
     mf = [(s[:, 3 + 2 * c] - s[:, 2 + 2 * c]).mean() for c in range(nch)]
     stg = [(s[:, 4 + 2 * c] - s[:, 3 + 2 * c]).mean() for c in range(nch - 1)]
-    print("  per chunk MFMA groups:", [int(v) for v in mf])
-    print("  per chunk boundary (convert+store+2 barriers):", [int(v) for v in stg])
+    print("  per chunk, first store / barrier to the end of its last MFMA segment (ping-pong loop: ST .. C13):", [int(v) for v in mf])
+    print("  between chunks (per-group loop: convert + store + 2 barriers; ping-pong loop: ~0, the boundary is inside the chunk):", [int(v) for v in stg])
     last = 3 + 2 * (nch - 1)
     if cin // 16 <= 12:
         print("  last group -> epilogue start:", int((s[:, 28] - s[:, last]).mean()), " epilogue:", int((s[:, 29] - s[:, 28]).mean()))

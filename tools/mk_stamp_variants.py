@@ -100,6 +100,18 @@ s=must(s, """                __builtin_amdgcn_sched_barrier(0);
                 if (ch == c_lo + 1 && pp < 6) STAMPW(4 + 2 * pp);
                 seg_barrier();
                 if (pr == 1) wb""")
+s=must(s, """            const int ch_next = ch + 1 < c_hi ? ch + 1 : ch;
+            // ---- ST""", """            const int ch_next = ch + 1 < c_hi ? ch + 1 : ch;
+            if (ch - c_lo < 12) STAMP(2 + 2 * (ch - c_lo));
+            // ---- ST""")
+s=must(s, """                if (pr == 1) wb = wb + 1 == NBUF ? 0 : wb + 1;
+            }
+        }
+        if (!hsel) seg_barrier();""", """                if (pr == 1) wb = wb + 1 == NBUF ? 0 : wb + 1;
+            }
+            if (ch - c_lo < 12) STAMP(3 + 2 * (ch - c_lo));
+        }
+        if (!hsel) seg_barrier();""")
 build(s, '_cst.hip', 'dm3d_conv_h3v2.o', 'variants/cst.so')
 
 # ---- gemm_tn_h3
