@@ -86,7 +86,7 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
     constexpr int WGRP = G * NT * REC;                       // halfs per weight group (16 KB)
     constexpr int WSLOT = WGRP * 2 / 16 / NTHR;              // 16-byte pieces per thread: 4 (256 threads) or 2 (512)
     static_assert(WGRP * 2 / 16 % NTHR == 0, "weight group must be a whole number of pieces per thread");
-    static_assert(NBUF == 2 || NBUF == 3, "two or three weight buffers");
+    static_assert(NBUF >= 2 && NBUF <= 5, "two to five weight buffers");
     static_assert(!F8 || (TD == 8 && NBUF == 3), "the float8 cross-term form exists for 8-slice bricks with three weight buffers");
 
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_v2[];
@@ -174,7 +174,10 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
     fetch_w(g_first, 0);
     // NBUF == 3: every DMA below is issued unconditionally (past the end the last group is fetched again into a free buffer): with
     // conditional issues hipcc cannot count what is in flight and falls back to vmcnt(0) in front of the halo registers' first use.
-    if (NBUF == 3) fetch_w(g_first + 1 < g_end ? g_first + 1 : g_end - 1, 1);
+    if (NBUF >= 3) {
+#pragma unroll
+        for (int i = 1; i < NBUF - 1; ++i) fetch_w(g_first + i < g_end ? g_first + i : g_end - 1, i);
+    }
     int wb = 0;                                  // buffer of the group about to be consumed
 
     constexpr bool pro = MODE == 1, xh2 = MODE == 2;
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
     load_halo(c_lo);
     // (NBUF == 3) Drain here, with an instruction hipcc's wait-count pass sees: the chunk loop's header otherwise merges "first chunk: the
     // halo loads are the newest requests" with "later chunks: 7 groups of DMAs were issued behind them" into vmcnt(0) on every iteration.
-    if (NBUF == 3) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
+    if (NBUF >= 3) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
 
     // Conversion of a chunk's halo registers (prologue norm + SiLU, float16 split / float8 operands) into the pieces the LDS image takes,
     // in place.  (Tried: converting chunk ch+1 inside chunk ch's MFMA phase, the two waves of a SIMD in different groups, so that only
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
 #ifndef DM3D_PINGPONG
 #define DM3D_PINGPONG 1
 #endif
-    constexpr bool PP = DM3D_PINGPONG && TD == 8 && NBUF == 3 && KS == 3 && !F8 && NSLOT == 4;
+    constexpr bool PP = DM3D_PINGPONG && TD == 8 && NBUF >= 3 && KS == 3 && !F8 && NSLOT == 4;
     if constexpr (PP) {
         const int hsel = __builtin_amdgcn_readfirstlane(wave >> 2);
         auto seg_barrier = [&]() {
@@ -345,14 +348,23 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
                 if (pr == 1) {
                     // group (pp + 1) / 2 (7 = the next chunk's first) must have landed: behind its DMA (issued in C(pp - 3)) this wave
                     // issued the halo requests of C(pp - 3) and C(pp - 1) and the DMA of C(pp - 1)
-                    const int extra = halo_ops((pp - 3) / 2 - ((pp - 3) < 0 ? 1 : 0)) + halo_ops((pp - 1) / 2);
-                    if (extra == 0)       asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT) : "memory");
-                    else if (extra == 2)  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT + 2) : "memory");
-                    else if (extra == 4)  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT + 4) : "memory");
-                    else if (extra == 6)  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT + 6) : "memory");
-                    else if (extra == 8)  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT + 8) : "memory");
-                    else if (extra == 10) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT + 10) : "memory");
-                    else                  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT) : "memory");
+                    // (ring of NBUF buffers: the DMAs of groups G+1 .. G+NBUF-2 are newer than group G's, as are the halo requests issued in
+                    // the compute segments of groups G-NBUF+1 .. G-1 of this chunk)
+                    const int G_ = (pp + 1) / 2;
+                    int extra = 0;
+#pragma unroll
+                    for (int k_ = 1; k_ < NBUF; ++k_) extra += halo_ops(G_ - k_);
+                    constexpr int DMA_BEHIND = WSLOT * (NBUF - 2);
+                    switch (extra) {
+                    case 0:  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_BEHIND) : "memory"); break;
+                    case 2:  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_BEHIND + 2) : "memory"); break;
+                    case 4:  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_BEHIND + 4) : "memory"); break;
+                    case 6:  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_BEHIND + 6) : "memory"); break;
+                    case 8:  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_BEHIND + 8) : "memory"); break;
+                    case 10: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_BEHIND + 10) : "memory"); break;
+                    case 12: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_BEHIND + 12) : "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_BEHIND) : "memory"); break;
+                    }
                 }
                 if (pp >= 8 && pp < 8 + NSLOT) convert_slot(pp - 8);
                 __builtin_amdgcn_sched_barrier(0);
@@ -368,8 +380,8 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
                 // beside ds_reads — MI355X_MICROARCH.md; in the load segment they made every second segment twice as long as a compute one)
                 if (pr == 0) {
                     __builtin_amdgcn_sched_barrier(0);
-                    const int nxt = ch * NG + g + 2;
-                    const int b2 = wb + 2 >= 3 ? wb - 1 : wb + 2;
+                    const int nxt = ch * NG + g + NBUF - 1;
+                    const int b2 = wb == 0 ? NBUF - 1 : wb - 1;            // the buffer group g-1 left
                     fetch_w(nxt < g_end ? nxt : g_end - 1, b2);
                     if (g < NSLOT) load_halo_slot(ch_next, g);
                     if (g == 0) load_chunk_params(ch_next);
@@ -628,7 +640,7 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
         }
     }
 
-    if (NBUF == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the redundant tail fetches: nothing may land in LDS the skip phase reuses
+    if (NBUF >= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the redundant tail fetches: nothing may land in LDS the skip phase reuses
 
     // ---- fused 1x1 conv over a second, raw input (ResidualBlock: out = conv2(...) + Conv3D(width, 1)(x), conditional_dm3d.py:243-248,
     // 268).  K = 32 per MFMA = two 16-channel chunks of the SAME voxel instead of two taps: chunk 2i goes to LDS region 0, chunk
@@ -1149,7 +1161,15 @@ template <int KS, int MODE>
 static int launch_any(ConvArgs& a, hipStream_t st) {
     // (the float8 form in 4-slice bricks, two workgroups per CU, was 8-12 % slower on the large grids and spilled registers: not built)
     if (dm3d_conv_h3v2_f8(a)) return launch_v2<KS, MODE, 8, 3, 1>(a, st);
-    return use_wide(a) ? launch_v2<KS, MODE, 8, 3>(a, st) : launch_v2<KS, MODE, 4, 2>(a, st);
+    if (!use_wide(a)) return launch_v2<KS, MODE, 4, 2>(a, st);
+    if constexpr (KS == 3) {
+        // weight-ring depth of the ping-pong loop (A/B knob, read per call): DM3D_CONV_RING = 3 (default), 4, 5
+        const char* e = getenv("DM3D_CONV_RING");
+        const int ring = e ? atoi(e) : 3;
+        if (ring == 5) return launch_v2<KS, MODE, 8, 5>(a, st);
+        if (ring == 4) return launch_v2<KS, MODE, 8, 4>(a, st);
+    }
+    return launch_v2<KS, MODE, 8, 3>(a, st);
 }
 
 int dm3d_conv_launch_h3v2(ConvArgs& a, int which, hipStream_t st) {

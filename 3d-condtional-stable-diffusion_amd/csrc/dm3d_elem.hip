@@ -444,13 +444,17 @@ __global__ __launch_bounds__(256) void ddpm_kernel(const DdpmArgs p) {
     }
 }
 
+typedef unsigned int u32x4r __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void range_check_kernel(const float* __restrict__ x, long n4, float limit, int* __restrict__ flag) {
-    float amax = 0.0f;
+    // |x| compared as integers: for non-negative floats the bit patterns order like the values and every NaN pattern lies above +inf,
+    // so a NaN raises the flag too (fmaxf drops NaNs and `amax > limit` is false for one: a NaN produced upstream — the float8
+    // conversions of the h3f8 mode return NaN beyond 448 — would otherwise pass unseen)
+    unsigned int amax = 0u;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
-        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        const u32x4r v = reinterpret_cast<const u32x4r*>(x)[i];
+        amax = max(max(amax, max(v[0] & 0x7fffffffu, v[1] & 0x7fffffffu)), max(v[2] & 0x7fffffffu, v[3] & 0x7fffffffu));
     }
-    if (amax > limit) *flag = 1;
+    if (amax > __float_as_uint(limit)) *flag = 1;
 }
 
 __global__ void add_i32_kernel(int* p, int n, int delta) {

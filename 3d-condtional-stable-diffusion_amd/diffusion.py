@@ -69,6 +69,7 @@ class DiffusionModel:
         self._trainer = None
         self._trainer_dirty = False
         self.network._before_use = self._sync_from_trainer
+        self.network._training_engine = self._engine_for_training_forward
 
     # -- the autoencoder bracket --------------------------------------------------------------------------------------
     @property
@@ -114,9 +115,15 @@ class DiffusionModel:
         self.loss, self.optimizer = loss, optimizer
 
     def load_state_dict(self, sd, strict=True):
-        self.network.load_state_dict(sd, strict)
+        """Weights by name; ``optimizer/...`` entries (save_weights of a trained model) restore the Adam slots and step count, so a
+        resumed run continues the bias correction where it stopped; without them the optimizer starts afresh."""
+        self._sync_from_trainer()                                  # a non-strict load fills missing names from the CURRENT (trained) weights
+        opt = {k: v for k, v in sd.items() if k.startswith("optimizer/")}
+        self.network.load_state_dict({k: v for k, v in sd.items() if not k.startswith("optimizer/")}, strict)
         self._drop_graphs()
         self._trainer, self._trainer_dirty = None, False          # Adam moments belong to the weights they were built for
+        if opt:
+            self.trainer.load_optimizer_state(opt)
 
     def load_weights(self, path, root=("network",)):
         """keras ``model.load_weights(ckpt)`` (main_conditional_dm.py:207-213): reads the U-Net from a TF2 checkpoint prefix
@@ -135,7 +142,10 @@ class DiffusionModel:
     def save_weights(self, path, root=("network",)):
         self._sync_from_trainer()
         if str(path).endswith(".npz"):
-            np.savez(path, **self.network.state_dict())
+            # the Adam slots travel with the weights (as in the reference's save_weights_only TF checkpoints); the TF-format writer
+            # below stores the network only
+            opt = self._trainer.optimizer_state() if self._trainer is not None and self._trainer.step_count > 0 else {}
+            np.savez(path, **self.network.state_dict(), **opt)
             return
         from . import tf_checkpoint as tc
         tc.save_unet_checkpoint(str(path), self.network.state_dict(), self.network.cfg, root=tuple(root))
@@ -169,6 +179,14 @@ class DiffusionModel:
         if self._trainer is None:
             from .train import Trainer
             self._trainer = Trainer(self.network.cfg, self.network.state_dict(), self.device, lr=self._learning_rate())
+        return self._trainer
+
+    def _engine_for_training_forward(self):
+        """``network(..., training=True)`` outside train_step runs on the model's own Trainer when it has one, so the moving statistics it
+        updates are the ones the next train_step continues from (in Keras both are the same variables)."""
+        if self._trainer is None:
+            return None
+        self._trainer_dirty = True
         return self._trainer
 
     def _sync_from_trainer(self):
@@ -215,10 +233,11 @@ class DiffusionModel:
         if self.conditional:
             ids = self._context_ids(context, B)
         tr = self.trainer
+        tr.lr = self._learning_rate()               # re-read every step: compile() / optimizer.learning_rate may have changed
         tab = self.b.device_tables(dev)
         betas = (tab[BETAS_FIELDS.index("sqrt_alpha_bar")], tab[BETAS_FIELDS.index("sqrt_one_minus_alpha_bar")])
         loss, _ = tr.loss_and_grad(latents, t, noise, ids, betas, T, self.global_bs, self.lc)
-        tr.allreduce_grads()                       # data-parallel replicas (one process per GPU): one flat RCCL all-reduce; no-op alone
+        tr.allreduce_grads(loss)                   # data-parallel replicas (one process per GPU): flat RCCL all-reduces; no-op alone
         tr.adam_step()
         self._trainer_dirty = True
         self.loss_tracker.update_state(float(loss.item()))
@@ -449,3 +468,12 @@ class Sampler:
         else:
             self._enqueue(st, self.desc)
         self._t -= 1
+        if self._t < 0:
+            self.finish()                     # the chain's last step: the one host read of a chain driven through step()
+
+    def finish(self):
+        """Reads the H3 / h3f8 range flag of the steps taken so far (one 4-byte device read) and raises if an activation left the
+        range the arithmetic covers or turned NaN — what generate() does at its end; step() calls it after a chain's last step, a
+        caller that stops a chain early calls it itself."""
+        self._own()
+        self.model.network.check_range(self.plan)

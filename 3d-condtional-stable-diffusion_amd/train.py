@@ -85,7 +85,9 @@ def _zeros(*shape, device) -> torch.Tensor:
 class Trainer:
     """Owns the trainable state of one U-Net and runs train steps on it."""
 
-    def __init__(self, cfg: UNetConfig, state: Dict[str, np.ndarray], device, lr: float = 1e-4, bn_moving_unbiased: bool = True):
+    def __init__(self, cfg: UNetConfig, state: Dict[str, np.ndarray], device, lr: float = 1e-4, bn_moving_unbiased: bool = True,
+                 forward_only: bool = False):
+        """``forward_only``: no gradient / Adam buffers (a quarter of the memory) — for ``network(..., training=True)`` outside train_step."""
         if cfg.norm != "batch":
             raise ValueError("training is built for the BatchNormalization network the reference trains (norm='batch')")
         _lib.require_device()
@@ -100,13 +102,14 @@ class Trainer:
             offs.append(off)
             off += -(-sz // 4) * 4
         self.total = off
+        self.forward_only = bool(forward_only)
         self.theta = _zeros(self.total, device=self.device)
-        self.grad = _zeros(self.total, device=self.device)
-        self.m = _zeros(self.total, device=self.device)
-        self.v = _zeros(self.total, device=self.device)
+        self.grad = None if forward_only else _zeros(self.total, device=self.device)
+        self.m = None if forward_only else _zeros(self.total, device=self.device)
+        self.v = None if forward_only else _zeros(self.total, device=self.device)
         self.params: Dict[str, Param] = {}
         for n, o, sz in zip(names, offs, sizes):
-            self.params[n] = Param(n, self.spec[n], self.theta[o:o + sz], self.grad[o:o + sz])
+            self.params[n] = Param(n, self.spec[n], self.theta[o:o + sz], None if forward_only else self.grad[o:o + sz])
         self.moving: Dict[str, torch.Tensor] = {}
         self.step_count = 0
         self.load_state(state)
@@ -588,14 +591,61 @@ class Trainer:
         self._cache = {}
         return loss, pred.v
 
-    def allreduce_grads(self):
+    def allreduce_grads(self, loss: Optional[torch.Tensor] = None):
         """Data-parallel training (what MirroredStrategy(cross_device_ops=ReductionToOneDevice()) does for the reference,
         main_conditional_dm.py:87): SUM the gradients over the ranks — the loss is already divided by the GLOBAL batch
-        (conditional_dm3d.py:496-499), and BatchNormalization statistics stay per replica as in Keras.  The flat gradient buffer
-        is the bucket: one all-reduce (RCCL over xGMI under backend "nccl") per step.  No-op without a process group."""
+        (conditional_dm3d.py:496-499).  The flat gradient buffer is the bucket: one all-reduce (RCCL over xGMI under backend "nccl")
+        per step.  BatchNormalization normalises with per-replica batch statistics as in Keras, and its moving mean / variance —
+        which Keras aggregates by MEAN across replicas (VariableAggregation.MEAN) — are averaged here as one small second bucket, so every
+        rank (and the checkpoint rank 0 writes) holds the same statistics.  ``loss`` (optional, [1] device tensor): summed over the
+        ranks in place (each rank's loss is its shard's share of the global-batch loss).  No-op without a process group."""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        world = dist.get_world_size()
+        cpu_group = dist.get_backend() == "gloo"            # rehearsal / CPU tests: gloo reduces host tensors
+        def reduce_(t: torch.Tensor, scale: float = 1.0):
+            if cpu_group and t.is_cuda:
+                h = t.detach().cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                t.copy_(h if scale == 1.0 else h * scale)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                if scale != 1.0:
+                    t.mul_(scale)
+        reduce_(self.grad)
+        names = sorted(self.moving)
+        flat = torch.cat([self.moving[n].reshape(-1) for n in names])
+        reduce_(flat, 1.0 / world)
+        off = 0
+        for n in names:
+            k = self.moving[n].numel()
+            self.moving[n].copy_(flat[off:off + k])
+            off += k
+        if loss is not None:
+            reduce_(loss)
+
+    # ---- optimizer state (keras.optimizers.Adam slots: the reference's ModelCheckpoint(save_weights_only=True) checkpoints carry them) ----
+    def optimizer_state(self) -> Dict[str, np.ndarray]:
+        """{"optimizer/iter": step count, "optimizer/m/<name>", "optimizer/v/<name>"}: what a resumed run needs beside the weights."""
+        out = {"optimizer/iter": np.asarray(self.step_count, dtype=np.int64)}
+        hm, hv, base = self.m.cpu().numpy(), self.v.cpu().numpy(), self.theta.data_ptr()
+        for n, p in self.params.items():
+            o = (p.w.data_ptr() - base) // 4
+            out[f"optimizer/m/{n}"] = hm[o:o + p.w.numel()].reshape(p.shape).copy()
+            out[f"optimizer/v/{n}"] = hv[o:o + p.w.numel()].reshape(p.shape).copy()
+        return out
+
+    def load_optimizer_state(self, st: Dict[str, np.ndarray]):
+        self.step_count = int(np.asarray(st["optimizer/iter"]).reshape(-1)[0])
+        base = self.theta.data_ptr()
+        for n, p in self.params.items():
+            o = (p.w.data_ptr() - base) // 4
+            for slot, buf in (("m", self.m), ("v", self.v)):
+                arr = np.ascontiguousarray(st[f"optimizer/{slot}/{n}"], dtype=np.float32).reshape(-1)
+                if arr.size != p.w.numel():
+                    raise ValueError(f"optimizer slot {slot} of {n}: {arr.size} values for a parameter of {p.w.numel()}")
+                buf[o:o + arr.size].copy_(torch.from_numpy(arr))
 
     def adam_step(self):
         """keras.optimizers.Adam.apply_gradients over the flat buffers (one launch)."""

@@ -85,6 +85,7 @@ class UNet:
         self._plans: Dict[tuple, "Plan"] = {}
         self._prepared = False
         self._before_use = None         # set by DiffusionModel: brings weights changed by train_step back before the network is used
+        self._training_engine = None    # set by DiffusionModel: its Trainer (if it has one) serves network(..., training=True)
         self.load_state_dict(weights if weights is not None else keras_init_weights(cfg, seed))
 
     # ---- weights -------------------------------------------------------------------------------------------------
@@ -268,6 +269,10 @@ class UNet:
         device read: the only host synchronisation of a generate() call, at its end)."""
         if plan.range_flag is None:
             return
+        # the newest x (a chain's final latent; nothing downstream would look at it) goes through the NaN-aware check as well: a NaN
+        # made anywhere in a step reaches x with the posterior update, and `amax > limit` alone is false for one
+        check(lib().dm3d_range_check(plan.x.data_ptr(), plan.x.numel(), 448.0 if self.f8 else 65504.0, plan.range_flag.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream), "range_check")
         if int(plan.range_flag.item()) != 0:
             plan.range_flag.zero_()
             if self.f8:
@@ -428,7 +433,11 @@ def _training_forward(net: "UNet", inputs) -> torch.Tensor:
     x, t = inputs[0], inputs[1]
     ctx = inputs[2] if cfg.conditional else None
     x = torch.as_tensor(x, dtype=torch.float32).to(net.device).contiguous()
-    tr = Trainer(cfg, net.state_dict(), net.device)
+    provider = getattr(net, "_training_engine", None)
+    tr = provider() if provider is not None else None          # the owning DiffusionModel's Trainer, if it has trained already
+    own = tr is None
+    if own:
+        tr = Trainer(cfg, net.state_dict(), net.device, forward_only=True)
     ids = None
     if cfg.conditional:
         ids = torch.as_tensor(ctx).reshape(-1).to(net.device, torch.int32)
@@ -436,9 +445,12 @@ def _training_forward(net: "UNet", inputs) -> torch.Tensor:
             ids = ids.repeat(x.shape[0])
     out = tr.forward(x, torch.as_tensor(t).reshape(-1).cpu().numpy().astype(np.int64), ids, update_moving=True)
     tr.tape = []
-    new = tr.state_dict()
-    net.load_state_dict({k: (new[k] if k.endswith((".mean", ".var")) else v) for k, v in net.state_dict().items()})
-    return out.v
+    tr._cache = {}
+    if own:
+        new = tr.state_dict()
+        net.load_state_dict({k: (new[k] if k.endswith((".mean", ".var")) else v) for k, v in net.state_dict().items()})
+    # (the model's own Trainer: it was marked dirty, the network picks the new statistics up on its next use)
+    return out.v.clone()
 
 
 def _gemm_desc(a, lda, b, ldb, out, ldo, m, n, k, batch=1, stride_a=0, stride_b=0, stride_o=0, alpha=1.0, bias=None,

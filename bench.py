@@ -57,27 +57,57 @@ def host_cores() -> int:
 
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this parent never initialises the GPU),
-    relay rank 0's stdout (the JSON line) and every rank's stderr, return non-zero if any rank failed."""
+    relay rank 0's stdout (the JSON line) and every rank's stderr.  All children are polled: when one exits non-zero its siblings
+    are terminated at once (a rank that dies before the rendezvous would otherwise leave the others in init_process_group until
+    the collective timeout) and the parent returns non-zero.  A port that another process grabbed between the probe and the
+    children's bind shows up as such an early failure: one retry on a fresh port."""
     import socket
     import subprocess
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0 = procs[0].communicate()[0]
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0)
-    sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        print(f"[bench] ranks failed (rank, exit code): {bad}", file=sys.stderr)
-        return 1
-    return 0
+    import threading
+
+    def attempt() -> int:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+        out0 = []
+        reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        bad = []
+        while True:
+            rcs = [p.poll() for p in procs]
+            bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+            if bad or all(rc is not None for rc in rcs):
+                break
+            time.sleep(0.2)
+        if bad:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+        reader.join(timeout=10)
+        if bad:
+            print(f"[bench] ranks failed (rank, exit code): {bad}; siblings terminated", file=sys.stderr)
+            return 1
+        sys.stdout.write(out0[0] if out0 else "")
+        sys.stdout.flush()
+        return 0
+
+    t_start = time.time()
+    rc = attempt()
+    if rc != 0 and time.time() - t_start < 60 and os.environ.get("DM3D_BENCH_NO_RETRY") != "1":
+        print("[bench] early failure: one retry on a fresh rendezvous port", file=sys.stderr)
+        rc = attempt()
+    return rc
 
 
 def csrc_digest() -> str:
@@ -140,18 +170,22 @@ def main():
     _lib.require_device()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("DM3D_BENCH_INIT_TIMEOUT", "180")))   # a dead sibling must not hold the box for the default 10 min
         if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
     comm_dev = torch.device("cpu") if rehearsal else dev
 
     B, S, Cc = args.batch, args.size, args.channels
     log(f"rank {rank}/{world}: building weights and model (B={B}, {S}^3x{Cc})")
     cfg = dm3d_amd.UNetConfig(img_size=S, img_channels=Cc)
     spec = dm3d_amd.param_spec(cfg)
-    W = dm3d_amd.synthetic_weights(cfg, seed=0) if rank == 0 else None
-    W = parallel.broadcast_state(W, spec, src=0, device=comm_dev)              # RCCL broadcast over xGMI (no-op at N=1)
+    # every rank builds the seeded weights itself (no GPU idles on rank 0's NumPy) and rank 0's copy is broadcast over them anyway:
+    # the path a real deployment takes (rank 0 loads the checkpoint), and the digests below prove what each rank ended up with
+    W = dm3d_amd.synthetic_weights(cfg, seed=0)
+    W = parallel.broadcast_state(W if rank == 0 else None, spec, src=0, device=comm_dev)   # RCCL broadcast over xGMI (no-op at N=1)
     # every rank's identity: device, Philox seed, digest of the weights it holds after the broadcast (must all agree)
     me = json.dumps({"rank": rank, "device": torch.cuda.get_device_name(dev_index), "device_index": dev_index,
                      "seed": parallel.rank_seed(1234, rank), "weights_sha": parallel.state_digest(W)})
@@ -192,8 +226,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, comm_dev)
+    my_elapsed = time.perf_counter() - t0
+    elapsed = parallel.max_over_ranks(my_elapsed, comm_dev)
     s_per_step = elapsed / K
+    for r, ms_r in enumerate(parallel.gather_strings(f"{my_elapsed / K * 1e3:.4f}")):       # the spread across GPUs
+        ranks_info["per_rank"][r]["ms_per_step"] = float(ms_r)
     log(f"timed {K} steps: {s_per_step * 1e3:.2f} ms/step")
     value = world * B / (T_FULL * s_per_step)
 
@@ -416,6 +453,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()                      # ranks != 0 wait here while rank 0 finishes its roofline leg: nobody tears the group down early
         dist.destroy_process_group()
 
 

@@ -1,0 +1,74 @@
+"""In-kernel shader clock of the conv (and GEMM) kernels as MI355X_MICROARCH.md 'DVFS give-back' item 6 defines it:
+delta(s_memtime) / delta(s_memrealtime) x 100 MHz, one stamp pair around the main loop of every workgroup, read after >= 2 s of
+back-to-back launches on random data, median over workgroups.  Needs the clock-stamp variant libraries of tools/mk_stamp_variants.py:
+    DM3D_LIB=<csrc>/variants/cck.so python tools/kernel_clock.py conv     (conv3d_igemm_h3v2; DM3D_CONV_RING etc. apply)
+    DM3D_LIB=<csrc>/variants/gst.so python tools/kernel_clock.py gemm
+Also prints the matrix-pipe duty of the stamped interval: MFMA cycles one SIMD must spend (16 per v_mfma_f32_16x16x32_f16) / delta(s_memtime).
+The stamps go to a buffer of their own (never to an output); the product library carries none of this."""
+import os, sys, time, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dm3d_amd import ops, _lib
+
+dev = torch.device("cuda:0")
+raw = C.CDLL(_lib.LIB_PATH)
+what = sys.argv[1] if len(sys.argv) > 1 else "conv"
+B = 32
+SECONDS = float(os.environ.get("CLOCK_SECONDS", "2.0"))
+
+
+def sustained(fn):
+    fn(); torch.cuda.synchronize()
+    t0 = time.time(); n = 0
+    while time.time() - t0 < SECONDS:
+        for _ in range(20): fn()
+        torch.cuda.synchronize(); n += 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / 10
+
+
+if what == "conv":
+    st = torch.zeros(4096 * 32, dtype=torch.int64, device=dev)
+    raw.dm3d_debug_set_stamps_conv(C.c_void_p(st.data_ptr()))
+    for name, e, cin, cout, res in (("32^3 64->64", 32, 64, 64, 1), ("32^3 192->64", 32, 192, 64, 0), ("16^3 128->128", 16, 128, 128, 1),
+                                    ("16^3 384->128", 16, 384, 128, 0)):
+        x = torch.randn(B, e, e, e, cin, device=dev)
+        k = torch.randn(3, 3, 3, cin, cout, device=dev) * 0.05
+        wpk, w_exp = ops.pack_weights_h3(k)
+        kw = dict(bias=torch.randn(cout, device=dev), pro_scale=torch.rand(cin, device=dev) + 0.5, pro_shift=torch.randn(cin, device=dev) * 0.1,
+                  res=torch.randn(B, e, e, e, cout, device=dev) if res else None, precision=_lib.PREC_H3, w_exp=w_exp)
+        st.zero_()
+        ms = sustained(lambda: ops.conv3d(x, wpk, cout, 3, **kw))
+        nb = min(B * (e // 8) ** 3, 4096)
+        s = st.view(4096, 32).cpu()[:nb].double()
+        dt, dr = s[:, 28] - s[:, 1], s[:, 31] - s[:, 30]
+        ok = dr > 0
+        ghz = (dt[ok] / dr[ok] * 0.1)
+        nch = cin // 16
+        mfma_cycles = 2 * nch * 14 * 48 * 16          # two waves per SIMD
+        fl = 2.0 * 27 * cin * cout * B * e ** 3
+        print(f"{name}: {ms:.3f} ms {fl / ms / 1e9:.0f} TF/s algorithmic | in-kernel clock median {ghz.median():.3f} GHz (p10 {ghz.quantile(0.1):.3f}, p90 {ghz.quantile(0.9):.3f}) "
+              f"| chunk loop {dt.median():.0f} ticks = {dr.median() / 100:.1f} us, MFMA duty in the loop {mfma_cycles / dt.median():.3f} "
+              f"| workgroup rounds {B * (e // 8) ** 3 * (cout // 64) / 256:.1f}", flush=True)
+    raw.dm3d_debug_set_stamps_conv(C.c_void_p(0))
+else:
+    st = torch.zeros(2048 * 16, dtype=torch.int64, device=dev)
+    raw.dm3d_debug_set_stamps(C.c_void_p(st.data_ptr()))
+    for m, n, k in ((16384, 1024, 256), (16384, 256, 1024), (16384, 256, 256)):
+        a = ops.split_h2(torch.randn(m, k, device=dev))
+        w = ops.split_h2(torch.randn(n, k, device=dev) * 0.05)
+        out = torch.empty(m, n, device=dev)
+        st.zero_()
+        kw = dict(m=m, n=n, k=k, lda=k, ldb=k, batch=1, stride_a=m * k, stride_b=0, bias=torch.randn(n, device=dev), act=_lib.ACT_NONE, res=None,
+                  out=out, precision=_lib.PREC_H3, a_fmt=_lib.FMT_H2, b_fmt=_lib.FMT_H2, out_fmt=_lib.FMT_F32)
+        ms = sustained(lambda: ops.gemm_tn(a, w, **kw))
+        s = st.view(2048, 16).cpu().double()
+        dt, dr = s[:, 10] - s[:, 1], s[:, 15] - s[:, 14]
+        ok = dr > 0
+        ghz = dt[ok] / dr[ok] * 0.1
+        print(f"gemm m={m} n={n} k={k}: {ms * 1e3:.1f} us {2.0 * m * n * k / ms / 1e9:.0f} TF/s | in-kernel clock median {ghz.median():.3f} GHz "
+              f"(p10 {ghz.quantile(0.1):.3f}, p90 {ghz.quantile(0.9):.3f}); K loop {dt.median():.0f} ticks", flush=True)
+    raw.dm3d_debug_set_stamps(C.c_void_p(0))

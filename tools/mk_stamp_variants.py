@@ -32,7 +32,7 @@ s=must(s, """namespace {
 
 constexpr int REC = DM3D_REC;""","""__device__ unsigned long long* g_dbg_stamps_c = nullptr;
 extern "C" int dm3d_debug_set_stamps_conv(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_stamps_c), &p, sizeof(p)); }
-#define STAMP(i) do { if (g_dbg_stamps_c && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 4096) g_dbg_stamps_c[blockIdx.x * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define STAMP(i) do { if (g_dbg_stamps_c && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 4096) { g_dbg_stamps_c[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); if ((i) == 1) g_dbg_stamps_c[blockIdx.x * 32 + 30] = __builtin_amdgcn_s_memrealtime(); if ((i) == 28) g_dbg_stamps_c[blockIdx.x * 32 + 31] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 
 namespace {
 
@@ -41,8 +41,8 @@ s=must(s, """    const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;""","""    STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;""",1)
-s=must(s, """    if (NBUF == 3) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
-""","""    if (NBUF == 3) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
+s=must(s, """    if (NBUF >= 3) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
+""","""    if (NBUF >= 3) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
     STAMP(1);
 """)
 s=must(s, """        if (!SPREAD) load_halo(ch_next);
@@ -76,7 +76,7 @@ s=must(s, """                    } else {
         return;
     }""")
 # ping-pong loop: segment boundaries of the chunk loop's second chunk, waves 0 (half 0 -> entries 0..15 of the block's second row) and 4
-s=must(s, """    constexpr bool PP = DM3D_PINGPONG""", """#define STAMPW(i) do { if (g_dbg_stamps_c && (threadIdx.x == 0 || threadIdx.x == 256) && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 2048 && (i) < 16) g_dbg_stamps_c[(2048 + blockIdx.x) * 32 + (threadIdx.x ? 16 : 0) + (i)] = __builtin_readcyclecounter(); } while (0)
+s=must(s, """    constexpr bool PP = DM3D_PINGPONG""", """#define STAMPW(i) do { if (g_dbg_stamps_c && (threadIdx.x == 0 || threadIdx.x == 256) && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 2048 && (i) < 16) g_dbg_stamps_c[(2048 + blockIdx.x) * 32 + (threadIdx.x ? 16 : 0) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     constexpr bool PP = DM3D_PINGPONG""")
 s=must(s, """            seg_barrier();
             // ---- X
@@ -113,6 +113,7 @@ s=must(s, """                if (pr == 1) wb = wb + 1 == NBUF ? 0 : wb + 1;
         }
         if (!hsel) seg_barrier();""")
 build(s, '_cst.hip', 'dm3d_conv_h3v2.o', 'variants/cst.so')
+build(s.replace('#define STAMPW(i) do {', '#define STAMPW(i) do { break;').replace('#define STAMP(i) do {', '#define STAMP(i) do { if ((i) != 1 && (i) != 28) break;'), '_cck.hip', 'dm3d_conv_h3v2.o', 'variants/cck.so')
 
 # ---- gemm_tn_h3
 s = open('dm3d_gemm_h3.hip').read()
@@ -120,7 +121,7 @@ s=must(s, """namespace {
 
 struct GemmH3Args {""","""__device__ unsigned long long* g_dbg_stamps = nullptr;
 extern "C" int dm3d_debug_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_stamps), &p, sizeof(p)); }
-#define STAMP(i) do { if (g_dbg_stamps && threadIdx.x == 0 && blockIdx.x < 2048) g_dbg_stamps[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define STAMP(i) do { if (g_dbg_stamps && threadIdx.x == 0 && blockIdx.x < 2048) { g_dbg_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); if ((i) == 1) g_dbg_stamps[blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime(); if ((i) == 10) g_dbg_stamps[blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 
 namespace {
 
