@@ -321,7 +321,9 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
     if (d->precision != DM3D_PREC_H3) return dm3d_conv_launch_f32(a, which, st);
     const int layout = dm3d_conv_weight_layout(d->ksize, d->stride, d->upsample, d->transpose, d->cout);
     DM3D_REQUIRE(d->w_layout == layout, "conv: w_layout %d but this geometry reads layout %d (dm3d_conv_weight_layout)", d->w_layout, layout);
-    return layout == DM3D_WL_PAIR ? dm3d_conv_launch_h3v2(a, which, st) : dm3d_conv_launch_h3(a, which, st);
+    if (layout != DM3D_WL_PAIR) return dm3d_conv_launch_h3(a, which, st);
+    // same packed weights, arguments and epilogue; the free-running form (dm3d_conv_h3v3.hip) unless the float8 cross-term arithmetic was asked for
+    return dm3d_conv_h3v3_serves(a, which) ? dm3d_conv_launch_h3v3(a, which, st) : dm3d_conv_launch_h3v2(a, which, st);
 }
 
 extern "C" int64_t dm3d_packed_weight_skip_h3p_bytes(int32_t cin, int32_t cout) {
@@ -345,7 +347,7 @@ extern "C" int32_t dm3d_conv_tile_form(const dm3d_conv_desc* d) {
     a.s_npairs = d->skip_wpk ? 1 : 0;
     a.wpk_f8 = d->wpk_f8;
     if (dm3d_conv_h3v2_f8(a)) return 9;
-    return dm3d_conv_h3v2_wide(a) ? 8 : 4;
+    return dm3d_conv_h3v3_td(a);
 }
 
 extern "C" int64_t dm3d_conv_scratch_bytes(const dm3d_conv_desc* d) {

@@ -43,8 +43,13 @@ enum { DM3D_CONV_K3S1 = 0, DM3D_CONV_K3S2 = 1, DM3D_CONV_K1 = 2, DM3D_CONV_UP = 
 int dm3d_conv_launch_f32(ConvArgs& a, int which, hipStream_t st);
 int dm3d_conv_launch_h3(ConvArgs& a, int which, hipStream_t st);
 int dm3d_conv_launch_h3v2(ConvArgs& a, int which, hipStream_t st);     // DM3D_WL_PAIR weights; which in {K3S1, UP}
+int dm3d_conv_launch_h3v3(ConvArgs& a, int which, hipStream_t st);     // same weights and arguments: the free-running form (dm3d_conv_h3v3.hip)
+bool dm3d_conv_h3v3_serves(const ConvArgs& a, int which);
+struct H3v2Launch { ConvArgs k; bool reduce; size_t out_elems; };       // what pre_launch decided: the kernel's own arguments, a reduce launch behind it
+int dm3d_h3v2_pre_launch(ConvArgs& a, int td, bool f8, H3v2Launch& L, hipStream_t st);
+int dm3d_h3v2_post_launch(const ConvArgs& a, const H3v2Launch& L, hipStream_t st);
 int dm3d_conv_h3v2_ksplit(const ConvArgs& a, bool with_scratch);
-bool dm3d_conv_h3v2_wide(const ConvArgs& a);            // true: the 8-slice / 512-thread / three-buffer form serves this launch
+int dm3d_conv_h3v3_td(const ConvArgs& a);              // z-slices per brick (4 or 8) the free-running kernel takes for this launch
 int64_t dm3d_h3v2_skip_image_bytes(int cin, int cout);
 int dm3d_pack_skip_h3v2(const float* keras_kernel, int cin, int cout, int w_exp, void* packed, hipStream_t st);       // split factor the launch would choose
 int64_t dm3d_h3v2_image_bytes(int taps, int cin, int cout, int f8 = 0);

@@ -1,81 +1,33 @@
-// dm3d_conv_h3v2.hip — the k3 / stride-1 (and the 2x2x2 parity) Conv3d of dm3d_conv_h3.hip rebuilt on v_mfma_f32_16x16x32_f16.
+// dm3d_conv_h3v2.hip — (1) the float8 cross-term form ("h3f8", opt-in) of the k3 / stride-1 and 2x2x2 parity Conv3d; (2) what the
+// 16x16x32 split-float16 conv kernels share on the host side: the launch bracket (Cin splitting for small grids, zero fill, reduce
+// launch), the DM3D_WL_PAIR weight packers, the tile-form predicates.  The default three-pass arithmetic lives in dm3d_conv_h3v3.hip.
 //
-// Why a second shape: on MI355X a loop of LDS-fed 16x16x32 MFMAs sustains ~14 % more FLOP/s than the same work as 32x32x16
-// (tools/micro/mfma_shapes.hip: 1690 vs 1478 TFLOP/s on random data; the chip holds a higher clock on this shape), and the
-// 32x32x16 kernel already runs at 75-85 % of its shape's ceiling.  Same split-float16 arithmetic (dm3d_h3.h), same brick /
-// halo / weight-group structure and epilogue fusions; what changes is the operand geometry:
+// Operand geometry (both kernels; helpers in dm3d_conv_h3v2_parts.h):
 //   * K = 32 per MFMA = two consecutive taps x 16 channels.  Lane l: row = l & 15, k-group kg = l >> 4; kg >> 1 picks the tap
 //     of the pair (= lane half), kg & 1 the 8-channel half (slot of the 64-byte record).  27 taps are padded to 28 (zero weights).
 //   * A 16-row tile is a 4 x 4 voxel patch; with the halo row stride padded to 12 the 16 records of a patch are distinct mod 16.
 //     The two hardware lane groups of a ds_read_b128, {0-3,12-15,20-27} and {4-11,16-19,28-31}, each mix rows {0-3,12-15} at one
 //     slot with rows {4-11} at the other; under the XOR swizzle two such reads collide iff their records differ by +-4 mod 16,
 //     so rows {0-3,12-15} take the patch columns dx in {0,1} and rows {4-11} take dx in {2,3} (record mod 4 = dx): conflict-free
-//     for every tap.  Weight rows get the same treatment by permuting their LDS position inside each group of 16 (PI below).
+//     for every tap.  Weight rows get the same treatment by permuting their LDS position inside each group of 16 (pi_pos).
 //   * A wave owns one 8 x 8 z-slice = 2 x 2 patches x 64 output channels = 16 tiles of 16 x 16 (64 accumulator registers).
 #include <cstdlib>
-#include "dm3d_conv_args.h"
-#include "dm3d_h3.h"
+#include "dm3d_conv_h3v2_parts.h"
+
+using namespace h3v2;
 
 namespace {
 
-constexpr int REC = DM3D_REC;
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-
-// LDS position (within its group of 16) of the weight row read by MFMA column c
-__host__ __device__ constexpr int pi_pos(int c) {
-    return c < 4 ? (c < 2 ? c : c + 2) : (c >= 12 ? (c < 14 ? c - 4 : c - 2) : (((c - 4) >> 1) * 4 + 2 + ((c - 4) & 1)));
-}
-// patch column of MFMA row i (rows 0-3 -> 0, 4-7 -> 2, 8-11 -> 3, 12-15 -> 1); patch row is i & 3
-__device__ __forceinline__ int dx_of_row(int i) { return (0x1320 >> ((i >> 2) * 4)) & 3; }
-
-// The three passes (al.bh, ah.bl, ah.bh) of the 4 x 2 accumulator tiles one weight batch feeds.  Default: tile-major, the three MFMAs of an
-// accumulator back to back.  -DDM3D_MFMA_PASS_MAJOR (tools/mk_variant.sh) issues them pass-major instead, 8 slots apart, so that no MFMA
-// waits for its predecessor's result: measured neutral on the conv, GEMM and 32x32x16 kernels alike (interleaved A/B, profiles/
-// r02_ab_mfma_order.log: 17.59 vs 17.59 ms/step) — with two waves per SIMD the other wave fills those slots.  (In the fused attention
-// kernel, one wave per SIMD, the same reordering was worth 2x.)
-#ifndef DM3D_MFMA_PASS_MAJOR
-#define DM3D_MFMA3_TILES(acc, nb, al, ah, bl, bh)                                                        \
-    _Pragma("unroll") for (int pi_ = 0; pi_ < 4; ++pi_)                                                  \
-        _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_) {                                               \
-            f32x4v& c_ = acc[pi_][(nb) * 2 + k_];                                                        \
-            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[pi_], bh[k_], c_, 0, 0, 0);                   \
-            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi_], bl[k_], c_, 0, 0, 0);                   \
-            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi_], bh[k_], c_, 0, 0, 0);                   \
-        }
-#else
-#define DM3D_MFMA3_TILES(acc, nb, al, ah, bl, bh)                                                        \
-    do {                                                                                                 \
-        _Pragma("unroll") for (int pi_ = 0; pi_ < 4; ++pi_)                                              \
-            _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_)                                             \
-                acc[pi_][(nb) * 2 + k_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[pi_], bh[k_], acc[pi_][(nb) * 2 + k_], 0, 0, 0); \
-        _Pragma("unroll") for (int pi_ = 0; pi_ < 4; ++pi_)                                              \
-            _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_)                                             \
-                acc[pi_][(nb) * 2 + k_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi_], bl[k_], acc[pi_][(nb) * 2 + k_], 0, 0, 0); \
-        _Pragma("unroll") for (int pi_ = 0; pi_ < 4; ++pi_)                                              \
-            _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_)                                             \
-                acc[pi_][(nb) * 2 + k_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi_], bh[k_], acc[pi_][(nb) * 2 + k_], 0, 0, 0); \
-    } while (0)
-#endif
-
-// MODE 0: float32 input as is; 1: float32 input through the fused norm + SiLU prologue; 2: x1 already activated and split
-// (DM3D_FMT_H2, written by the producing conv's epilogue): staging is two 16-byte copies per voxel and no arithmetic
-// TD = z-slices per brick = waves per workgroup (4: 256 threads, two workgroups per CU; 8: 512 threads, one workgroup per CU with 160 KB
-// of LDS to itself).  NBUF = weight-group buffers: 2 = the next group streams in while this one is consumed (one group of lead);
-// 3 = two groups of lead — a 16 KB LDS-DMA fill takes ~1.1 us from issue to landing (MI355X_MICROARCH.md "ldsdma-fill"), longer than
-// one group's 96 MFMAs, so with two buffers every group ended waiting for its successor (in-kernel stamps: ~680 cycles per group).
-// The 8-slice brick also halves the weight bytes streamed per FLOP (eight waves share a group) and trims the halo factor 2.34 -> 1.95.
-// F8 = 1 (8-slice form only): the "H3F8" arithmetic of dm3d_h3.h — ah.bh on v_mfma_f32_16x16x32_f16 as before, both cross terms on
-// v_mfma_scale_f32_16x16x128_f8f6f4 (K = 128 = 4 taps x 16 channels x 2 terms = one weight group; lane k-group kg takes tap kg of the
-// group).  Per group a wave issues 32 float16 + 16 float8 MFMAs (512 + ~455 cycles) where the three-pass form issues 96 float16 MFMAs
-// (1536 cycles); pipeline (three 16 KB buffers, counted waits) as in the three-pass form.
-#ifdef DM3D_EXP_NO_F8_READ       // timing experiment: the float8 operands come from registers instead of LDS (results are wrong)
-__device__ __forceinline__ u32x4 f8read_fake(const void* p) { u32x4 v; const unsigned t = (unsigned)(size_t)p; v[0] = t; v[1] = t * 3; v[2] = t * 5; v[3] = t * 7; return v; }
-#define F8READ(p) f8read_fake(p)
-#else
+// The "H3F8" arithmetic of dm3d_h3.h: ah.bh on v_mfma_f32_16x16x32_f16, both cross terms on v_mfma_scale_f32_16x16x128_f8f6f4 (K = 128 =
+// 4 taps x 16 channels x 2 terms = one weight group; lane k-group kg takes tap kg of the group).  Per group a wave issues 32 float16 + 16
+// float8 MFMAs (512 + ~455 cycles) where the three-pass arithmetic issues 96 float16 MFMAs (1536).  8-slice bricks (512 threads, one
+// workgroup per CU), weight groups of 4 taps (16 KB by LDS-DMA) through three buffers with two groups of lead, counted vmcnt waits
+// and raw barriers.  MODE 0: float32 input as is; 1: float32 input through the fused norm + SiLU prologue; 2: x1 already activated and
+// split (DM3D_FMT_H2, written by the producing conv's epilogue).
 #define F8READ(p) *reinterpret_cast<const u32x4*>(p)
-#endif
-template <int KS, int MODE, int TD, int NBUF, int F8 = 0>
-__global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p) {
+template <int KS, int MODE>
+__global__ __launch_bounds__(512, 2) void conv3d_igemm_h3f8(const ConvArgs p) {
+    constexpr int TD = 8, NBUF = 3;
     constexpr int TH = 8, TW = 8, CK = 16, NT = 64, NTHR = TD * 64;
     constexpr int HD = TD - 1 + KS, HH = TH - 1 + KS, HW = TW - 1 + KS, HWP = 12;
     constexpr int HVOX = HD * HH * HW;
@@ -86,8 +38,6 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
     constexpr int WGRP = G * NT * REC;                       // halfs per weight group (16 KB)
     constexpr int WSLOT = WGRP * 2 / 16 / NTHR;              // 16-byte pieces per thread: 4 (256 threads) or 2 (512)
     static_assert(WGRP * 2 / 16 % NTHR == 0, "weight group must be a whole number of pieces per thread");
-    static_assert(NBUF >= 2 && NBUF <= 5, "two to five weight buffers");
-    static_assert(!F8 || (TD == 8 && NBUF == 3), "the float8 cross-term form exists for 8-slice bricks with three weight buffers");
 
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_v2[];
     _Float16* lds_w = smem_v2;                  // [NBUF][G][NT][REC]   (first: every weight read is base + a 16-bit immediate)
@@ -95,7 +45,7 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int half = lane >> 5, q = (lane >> 4) & 1, row = lane & 15, g4 = lane >> 4;
+    const int half = lane >> 5, q = (lane >> 4) & 1, row = lane & 15;
 
     int brick = blockIdx.x;
     const int bpv = p.bd * p.bh * p.bw;
@@ -132,9 +82,6 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
             if (iz >= 0 && iz < p.ind && iy >= 0 && iy < p.inh && ix >= 0 && ix < p.inw)
                 g = ((b * p.ind + iz) * p.inh + iy) * p.inw + ix;
         }
-#ifdef DM3D_EXP_HALO_CACHED           // timing experiment: every halo load hits the same few cache-resident voxels (results are wrong)
-        if (g >= 0) g &= 1023;
-#endif
         gvox[j] = g;
         const int v = (hv / HW) * HWP + hv % HW;
         st_off[j] = hv < HVOX ? v * REC + ((piece ^ swz(v)) << 3) : -1;
@@ -156,15 +103,9 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
     // linear 16 KB copy; wave w moves the 1 KB pieces w, w+TD, ...  Buffer = group index mod NBUF, counted from this workgroup's
     // first group (NG is odd for k3, so the phase differs from chunk to chunk: a running counter).
     const char* w_img = reinterpret_cast<const char*>(wbase + (size_t)ntile * p.nchunks * NG * WGRP) + wave * 1024 + lane * 16;
-#ifdef DM3D_EXP_NO_DMA
-    const int g_first_dma = c_lo * NG;
-#endif
     auto fetch_w = [&](int gg, int buf) {
         const char* src = w_img + (size_t)gg * (WGRP * 2);
         char* dst = reinterpret_cast<char*>(lds_w) + buf * (WGRP * 2) + wave * 1024;
-#ifdef DM3D_EXP_NO_DMA          // timing experiment: no weight stream (results are wrong)
-        if (gg > g_first_dma + 1) return;
-#endif
 #pragma unroll
         for (int i = 0; i < WSLOT; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * (NTHR * 16)),
@@ -172,12 +113,9 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
     };
     const int g_first = c_lo * NG, g_end = c_hi * NG;
     fetch_w(g_first, 0);
-    // NBUF == 3: every DMA below is issued unconditionally (past the end the last group is fetched again into a free buffer): with
+    // every DMA below is issued unconditionally (past the end the last group is fetched again into a free buffer): with
     // conditional issues hipcc cannot count what is in flight and falls back to vmcnt(0) in front of the halo registers' first use.
-    if (NBUF >= 3) {
-#pragma unroll
-        for (int i = 1; i < NBUF - 1; ++i) fetch_w(g_first + i < g_end ? g_first + i : g_end - 1, i);
-    }
+    fetch_w(g_first + 1 < g_end ? g_first + 1 : g_end - 1, 1);
     int wb = 0;                                  // buffer of the group about to be consumed
 
     constexpr bool pro = MODE == 1, xh2 = MODE == 2;
@@ -228,16 +166,13 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
     // group's weight DMA) instead of all of them in front of group 0: requests return in order, so with everything issued up front the
     // whole 64 KB per workgroup — 16 MB across the chip, in one burst — had to land before the wait for the DMA issued one group later
     // could pass (two groups, ~2.8 us); measured with cache-resident halos the kernel was 8-10 % faster, i.e. that wait was exposed.
-#ifndef DM3D_HALO_SPREAD
-#define DM3D_HALO_SPREAD 1
-#endif
-    constexpr bool SPREAD = DM3D_HALO_SPREAD && NG > NSLOT;
+    constexpr bool SPREAD = NG > NSLOT;
     // vector-memory requests issued inside group g of a chunk (beside its weight DMA)
     auto halo_ops = [&](int g) { return SPREAD ? ((g >= 0 && g < NSLOT) ? 2 + (g == 0 ? PLOADS : 0) : 0) : 0; };
     load_halo(c_lo);
-    // (NBUF == 3) Drain here, with an instruction hipcc's wait-count pass sees: the chunk loop's header otherwise merges "first chunk: the
+    // Drain here, with an instruction hipcc's wait-count pass sees: the chunk loop's header otherwise merges "first chunk: the
     // halo loads are the newest requests" with "later chunks: 7 groups of DMAs were issued behind them" into vmcnt(0) on every iteration.
-    if (NBUF >= 3) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
 
     // Conversion of a chunk's halo registers (prologue norm + SiLU, float16 split / float8 operands) into the pieces the LDS image takes,
     // in place.  (Tried: converting chunk ch+1 inside chunk ch's MFMA phase, the two waves of a SIMD in different groups, so that only
@@ -259,11 +194,9 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 shi_j = __builtin_bit_cast(h8, in ? v0 : z);
                 slo_j = __builtin_bit_cast(h8, in ? v1 : z);
-                if (F8) slo_j = h2_to_x8(shi_j, slo_j);                 // (hi16, lo16) of the hand-off format -> [ah8 | al8]
-            } else if (F8) {
-                split8_f8(v0, v1, (in && ok0) ? DM3D_F8_LIMIT : 0.0f, (in && ok1) ? DM3D_F8_LIMIT : 0.0f, shi_j, slo_j);
+                slo_j = h2_to_x8(shi_j, slo_j);                         // (hi16, lo16) of the hand-off format -> [ah8 | al8]
             } else {
-                split8(v0, v1, (in && ok0) ? 65504.0f : 0.0f, (in && ok1) ? 65504.0f : 0.0f, shi_j, slo_j);
+                split8_f8(v0, v1, (in && ok0) ? DM3D_F8_LIMIT : 0.0f, (in && ok1) ? DM3D_F8_LIMIT : 0.0f, shi_j, slo_j);
             }
             raw0[j] = __builtin_bit_cast(f32x4, shi_j);
             raw1[j] = __builtin_bit_cast(f32x4, slo_j);
@@ -275,146 +208,15 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
     };
     int a_rec = a_rec0;
 
-    // ---- "Ping-pong" chunk loop of the three-pass 8-slice form (MI355X_MICROARCH.md, "Two waves per SIMD"): the two waves that share a SIMD
-    // (w and w + 4) alternate between a LOAD segment — the 16 ds_read_b128 of one tap pair into registers, plus every other duty: weight
-    // DMA, halo requests, operand conversion, counted waits — and a COMPUTE segment of the pair's 48 MFMAs on registers only, one barrier
-    // per segment, so that a SIMD's matrix pipe always has exactly one wave feeding it while the other fetches.  Both halves run the SAME
-    // instruction stream; half 1 passes one extra barrier in front of the loop (and half 0 one behind it), which shifts it by one segment.
-    // Stream per chunk: ST (store the converted halo pieces) | X (empty) | L0 C0 L1 C1 ... L13 C13.  Safety of the shared LDS images with
-    // the one-segment shift:  * halo: a half stores the new image at ST, two positions after its last read of the old one (L13) and one
-    // after the other half's; the first read of the new image (L0) is two positions behind ST, i.e. behind the other half's ST too.
-    // * weight ring (3 buffers, group g of the chunk in buffer wb): the DMA of group g+2 is issued at position 2g into the buffer group g-1 left
-    // at L(2g-1) — the other half passed its L(2g-1) one segment ago at the latest; group G is awaited (counted vmcnt) at L(2G-1), two
-    // positions before its first read at L(2G), so the other half's wait and a barrier lie between.  (The DMA itself is issued inside C(2g).)
-    // The conversion of the next chunk's halo (in place, slot by slot) rides in the load segments L8 .. L11, its requests in C0, C2, C4, C6.
-    // Per chunk the matrix pipe idles for the two short segments around ST only (the per-group form: ~4 700 cycles of convert / store /
-    // barriers per chunk and ~870 per group).
-#ifndef DM3D_PINGPONG
-#define DM3D_PINGPONG 1
-#endif
-    constexpr bool PP = DM3D_PINGPONG && TD == 8 && NBUF >= 3 && KS == 3 && !F8 && NSLOT == 4;
-    if constexpr (PP) {
-        const int hsel = __builtin_amdgcn_readfirstlane(wave >> 2);
-        auto seg_barrier = [&]() {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        };
-        convert_halo();                                   // the first chunk (its loads were drained above)
-        if (hsel) seg_barrier();
-        h8 ah[4], al[4], bh[4], bl[4];
-        for (int ch = c_lo; ch < c_hi; ++ch) {
-            asm volatile("" : "+v"(a_rec));
-            const int ch_next = ch + 1 < c_hi ? ch + 1 : ch;
-            // ---- ST
-#pragma unroll
-            for (int j = 0; j < NSLOT; ++j) {
-                if (st_off[j] >= 0) {
-                    *reinterpret_cast<h8*>(lds_in + st_off[j]) = __builtin_bit_cast(h8, raw0[j]);
-                    *reinterpret_cast<h8*>(lds_in + (st_off[j] ^ 16)) = __builtin_bit_cast(h8, raw1[j]);
-                }
-            }
-            seg_barrier();
-            // ---- X
-            seg_barrier();
-#pragma unroll
-            for (int pp = 0; pp < 2 * NG; ++pp) {
-                const int g = pp >> 1, pr = pp & 1;
-                // ---- L(pp): the operand reads go out first, the segment's other duties run while they are in flight
-                {
-                    const _Float16* wbuf = lds_w + wb * WGRP;
-                    const int ta = g * G + pr * 2, tb = ta + 1;
-                    const int tac = ta < TAPS ? ta : TAPS - 1, tbc = tb < TAPS ? tb : TAPS - 1;
-                    const int rec_a = ((tac / (KS * KS)) * HH + (tac / KS) % KS) * HWP + tac % KS;
-                    const int rec_b = ((tbc / (KS * KS)) * HH + (tbc / KS) % KS) * HWP + tbc % KS;
-                    const int v0 = a_rec + (half ? rec_b : rec_a);
-                    const int v1 = v0 + 4;
-                    const int o0 = v0 * REC + ((q ^ swz(v0)) << 3);
-                    const int o1 = v1 * REC + ((q ^ swz(v1)) << 3);
-#pragma unroll
-                    for (int py = 0; py < 2; ++py) {
-                        ah[py * 2 + 0] = *reinterpret_cast<const h8*>(lds_in + o0 + py * (48 * REC));
-                        ah[py * 2 + 1] = *reinterpret_cast<const h8*>(lds_in + o1 + py * (48 * REC));
-                        al[py * 2 + 0] = *reinterpret_cast<const h8*>(lds_in + (o0 ^ 16) + py * (48 * REC));
-                        al[py * 2 + 1] = *reinterpret_cast<const h8*>(lds_in + (o1 ^ 16) + py * (48 * REC));
-                    }
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) {
-                        bh[ni] = *reinterpret_cast<const h8*>(wbuf + (pr * 2 * NT + ni * 16) * REC + b_hi);
-                        bl[ni] = *reinterpret_cast<const h8*>(wbuf + (pr * 2 * NT + ni * 16) * REC + (b_hi ^ 16));
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (pr == 1) {
-                    // group (pp + 1) / 2 (7 = the next chunk's first) must have landed: behind its DMA (issued in C(pp - 3)) this wave
-                    // issued the halo requests of C(pp - 3) and C(pp - 1) and the DMA of C(pp - 1)
-                    // (ring of NBUF buffers: the DMAs of groups G+1 .. G+NBUF-2 are newer than group G's, as are the halo requests issued in
-                    // the compute segments of groups G-NBUF+1 .. G-1 of this chunk)
-                    const int G_ = (pp + 1) / 2;
-                    int extra = 0;
-#pragma unroll
-                    for (int k_ = 1; k_ < NBUF; ++k_) extra += halo_ops(G_ - k_);
-                    constexpr int DMA_BEHIND = WSLOT * (NBUF - 2);
-                    switch (extra) {
-                    case 0:  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_BEHIND) : "memory"); break;
-                    case 2:  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_BEHIND + 2) : "memory"); break;
-                    case 4:  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_BEHIND + 4) : "memory"); break;
-                    case 6:  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_BEHIND + 6) : "memory"); break;
-                    case 8:  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_BEHIND + 8) : "memory"); break;
-                    case 10: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_BEHIND + 10) : "memory"); break;
-                    case 12: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_BEHIND + 12) : "memory"); break;
-                    default: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_BEHIND) : "memory"); break;
-                    }
-                }
-                if (pp >= 8 && pp < 8 + NSLOT) convert_slot(pp - 8);
-                __builtin_amdgcn_sched_barrier(0);
-                seg_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- C(pp): 48 MFMAs on registers, pass-major (consecutive MFMAs never share an accumulator; per accumulator the order
-                // al.bh, ah.bl, ah.bh is that of the per-group form, so the results are the same bits)
-#pragma unroll
-                for (int pi = 0; pi < 4; ++pi)
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) acc[pi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[pi], bh[ni], acc[pi][ni], 0, 0, 0);
-                // The vector-memory requests ride here, among the MFMAs (an LDS-DMA piece costs ~60 cycles of issue beside bare MFMAs, 100-185
-                // beside ds_reads — MI355X_MICROARCH.md; in the load segment they made every second segment twice as long as a compute one)
-                if (pr == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    const int nxt = ch * NG + g + NBUF - 1;
-                    const int b2 = wb == 0 ? NBUF - 1 : wb - 1;            // the buffer group g-1 left
-                    fetch_w(nxt < g_end ? nxt : g_end - 1, b2);
-                    if (g < NSLOT) load_halo_slot(ch_next, g);
-                    if (g == 0) load_chunk_params(ch_next);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int pi = 0; pi < 4; ++pi)
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) acc[pi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi], bl[ni], acc[pi][ni], 0, 0, 0);
-#pragma unroll
-                for (int pi = 0; pi < 4; ++pi)
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) acc[pi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi], bh[ni], acc[pi][ni], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                seg_barrier();
-                if (pr == 1) wb = wb + 1 == NBUF ? 0 : wb + 1;
-            }
-        }
-        if (!hsel) seg_barrier();
-    } else
     for (int ch = c_lo; ch < c_hi; ++ch) {
         asm volatile("" : "+v"(a_rec));      // keeps the 14 per-pair operand addresses from being hoisted out of the chunk loop (spills)
         convert_halo();
         // With weight groups in flight across barriers (NBUF == 3) every barrier is a raw s_barrier behind counted waits:
         // __syncthreads() would drain the VM counter, i.e. wait for the DMAs that are meant to stay in flight (cdna_hip_programming.md,
         // "glds with >1 tile in flight across the barrier").
-        if (NBUF == 2) {
-            __syncthreads();
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of the previous halo image are retired
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of the previous halo image are retired
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) {
             if (st_off[j] >= 0) {
@@ -422,10 +224,7 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
                 *reinterpret_cast<h8*>(lds_in + (st_off[j] ^ 16)) = __builtin_bit_cast(h8, raw1[j]);
             }
         }
-        if (NBUF == 2) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk's first weight group (issued a group ago)
-            __syncthreads();
-        } else {
+        {
             // outstanding, oldest first: [this chunk's first group] [its second group] (the first chunk: + its own halo loads, which the
             // conversion above already waited for): the first group must have landed; the halo stores must be visible
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT) : "memory");
@@ -449,9 +248,7 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
             wb = wb + 1 == NBUF ? 0 : wb + 1;
             const bool last_group = g + 1 == NG;
             if (!last_group) {
-                if (NBUF == 2) {
-                    __syncthreads();      // the DMA of the next group has landed (vmcnt) and every wave is done with this one
-                } else {
+                {
                     // group g+1 must have landed; newer than it in the queue: group g+2's DMA and, behind the chunk's first iteration,
                     // the next chunk's halo loads (issued between the DMAs of g+1 and g+2)
                     // (SPREAD: the requests issued beside the DMAs of groups g-1 and g, see halo_ops)
@@ -464,60 +261,11 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
                     else if (extra == 2 * NSLOT) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT + 2 * NSLOT) : "memory");
                     else                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WSLOT) : "memory");
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifndef DM3D_EXP_NO_GROUP_BARRIER      // timing experiment: results are wrong without it
                     __builtin_amdgcn_s_barrier();
-#endif
                     asm volatile("" ::: "memory");
                 }
             }
         };
-        auto group_body = [&](const int g) {
-            if (NBUF == 2) {
-                const int nxt = ch * NG + g + 1;
-                if (nxt < g_end) fetch_w(nxt, wb ^ 1);
-            } else {
-                // group g+2 goes into the buffer group g-1 occupied: every wave is past g-1 (the barrier that opened this iteration)
-                const int nxt = ch * NG + g + 2;
-                const int b2 = wb + 2 >= 3 ? wb - 1 : wb + 2;
-                fetch_w(nxt < g_end ? nxt : g_end - 1, b2);
-            }
-            halo_in_group(g);
-            __builtin_amdgcn_sched_barrier(0);
-            const _Float16* wbuf = lds_w + wb * WGRP;
-#pragma unroll
-            for (int pr = 0; pr < G / 2; ++pr) {                        // tap pairs of the group
-                // taps of the pair (compile-time after unrolling); the pad tap (>= TAPS) re-reads the last real tap's voxels
-                const int ta = g * G + pr * 2, tb = ta + 1;
-                const int tac = ta < TAPS ? ta : TAPS - 1, tbc = tb < TAPS ? tb : TAPS - 1;
-                const int rec_a = ((tac / (KS * KS)) * HH + (tac / KS) % KS) * HWP + tac % KS;
-                const int rec_b = ((tbc / (KS * KS)) * HH + (tbc / KS) % KS) * HWP + tbc % KS;
-                const int v0 = a_rec + (half ? rec_b : rec_a);          // patch column px = 0
-                const int v1 = v0 + 4;                                   // px = 1 (different swizzle term)
-                const int o0 = v0 * REC + ((q ^ swz(v0)) << 3);
-                const int o1 = v1 * REC + ((q ^ swz(v1)) << 3);
-                h8 ah[4], al[4];
-#pragma unroll
-                for (int py = 0; py < 2; ++py) {                         // patch rows are 4*HWP = 48 records apart: same swizzle
-                    ah[py * 2 + 0] = *reinterpret_cast<const h8*>(lds_in + o0 + py * (48 * REC));
-                    ah[py * 2 + 1] = *reinterpret_cast<const h8*>(lds_in + o1 + py * (48 * REC));
-                    al[py * 2 + 0] = *reinterpret_cast<const h8*>(lds_in + (o0 ^ 16) + py * (48 * REC));
-                    al[py * 2 + 1] = *reinterpret_cast<const h8*>(lds_in + (o1 ^ 16) + py * (48 * REC));
-                }
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {                         // weights in two batches of two column tiles
-                    h8 bh[2], bl[2];
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int ni = nb * 2 + k;
-                        bh[k] = *reinterpret_cast<const h8*>(wbuf + (pr * 2 * NT + ni * 16) * REC + b_hi);
-                        bl[k] = *reinterpret_cast<const h8*>(wbuf + (pr * 2 * NT + ni * 16) * REC + (b_hi ^ 16));
-                    }
-                    DM3D_MFMA3_TILES(acc, nb, al, ah, bl, bh);
-                }
-            }
-            group_end(g);
-        };
-
         // ---- the float8 cross-term form's group: 32 float16 MFMAs (ah.bh of the two tap pairs) + 16 float8 MFMAs (one K = 128 step:
         // ah.bl + al.bh of all four taps), software-pipelined by hand: the LDS reads of a batch are issued in front of the previous batch's
         // MFMAs (sched_barrier keeps them there), so the matrix pipe never waits for an operand that was requested a few cycles ago — left
@@ -530,10 +278,8 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
         h8 a_carry[4];                                                   // ah of the next group's first pair, read during this group's tail
         auto group_body_f8 = [&](const int g) {
             const bool last_group = g + 1 == NG;
-            if (NBUF == 2) {
-                const int nxt = ch * NG + g + 1;
-                if (nxt < g_end) fetch_w(nxt, wb ^ 1);
-            } else {
+            {
+                // group g+2 goes into the buffer group g-1 occupied: every wave is past g-1 (the barrier that opened this iteration)
                 const int nxt = ch * NG + g + 2;
                 const int b2 = wb + 2 >= 3 ? wb - 1 : wb + 2;
                 fetch_w(nxt < g_end ? nxt : g_end - 1, b2);
@@ -563,24 +309,16 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
                 return i32x8{(int)x0[0], (int)x0[1], (int)x0[2], (int)x0[3], (int)x1[0], (int)x1[1], (int)x1[2], (int)x1[3]};
             };
             auto mma_hi = [&](const h8 (&a)[4], const h8 (&b)[2], int nb) {
-#ifndef DM3D_EXP_NO_HI_MFMA
 #pragma unroll
                 for (int pi = 0; pi < 4; ++pi)
 #pragma unroll
                     for (int k = 0; k < 2; ++k)
                         acc[pi][nb * 2 + k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[pi], b[k], acc[pi][nb * 2 + k], 0, 0, 0);
-#else
-                asm volatile("" :: "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]));
-#endif
             };
             auto mma_f8 = [&](const i32x8& a8, const i32x8 (&b8)[4], int pi) {
-#ifndef DM3D_EXP_NO_F8_MFMA
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
                     acc[pi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[ni], acc[pi][ni], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-#else
-                asm volatile("" :: "v"(a8), "v"(b8[0]), "v"(b8[1]), "v"(b8[2]), "v"(b8[3]));
-#endif
             };
             h8 a0[4], a1[4], b0[2], b1[2], b2[2], b3[2];
             if (g == 0) {
@@ -631,283 +369,18 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v2(const ConvArgs p
             mma_f8(x1, b8, 3);
             group_end(g);
         };
-        if constexpr (F8) {
 #pragma unroll
-            for (int g = 0; g < NG; ++g) group_body_f8(g);
-        } else {
-#pragma unroll
-            for (int g = 0; g < NG; ++g) group_body(g);
-        }
+        for (int g = 0; g < NG; ++g) group_body_f8(g);
     }
 
-    if (NBUF >= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the redundant tail fetches: nothing may land in LDS the skip phase reuses
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the redundant tail fetches: nothing may land in LDS the skip phase reuses
 
-    // ---- fused 1x1 conv over a second, raw input (ResidualBlock: out = conv2(...) + Conv3D(width, 1)(x), conditional_dm3d.py:243-248,
-    // 268).  K = 32 per MFMA = two 16-channel chunks of the SAME voxel instead of two taps: chunk 2i goes to LDS region 0, chunk
-    // 2i+1 to region 1 (brick voxels only, rows padded to 12 records like the halo so the patch reads stay conflict-free), the
-    // lane half picks the region.  One pair of chunks = one barrier pair + 48 MFMAs per wave; the next pair's weights (8 KB by
-    // LDS-DMA) and voxels (registers) are in flight meanwhile.  Part 0 of a split-K launch carries it.
-    if constexpr (KS == 3) if (p.s_npairs > 0 && khalf == 0) {     // (the launcher admits a skip conv behind k3 / stride 1 only)
-        constexpr int SREC = TD * TH * HWP;                                // 384 records per region
-        _Float16* lds_sa = smem_v2;                                        // [2][SREC][REC]            (0 .. 48 KB)
-        _Float16* lds_sw = smem_v2 + 2 * SREC * REC;                       // [2 buffers][2][NT][REC]   (48 .. 64 KB)
-        static_assert((2 * SREC * REC + 2 * 2 * NT * REC) * 2 <= (HD * HH * HWP * REC + NBUF * WGRP) * 2, "skip phase LDS carve");
-        constexpr int SITEMS = TD * TH * TW * 2;                          // 16-byte pieces per region (= 2 * NTHR: four per thread in all)
-        int sgv[4], sst[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int item = tid + j * NTHR, t = item / SITEMS, iv = (item % SITEMS) >> 1;
-            const int z = iv >> 6, y = (iv >> 3) & 7, x = iv & 7;
-            const bool in = oz0 + z < p.ind && oy0 + y < p.inh && ox0 + x < p.inw;
-            sgv[j] = in ? ((b * p.ind + oz0 + z) * p.inh + oy0 + y) * p.inw + ox0 + x : -1;
-            const int v = (z * TH + y) * HWP + x;
-            sst[j] = (t * SREC + v) * REC + ((piece ^ swz(v)) << 3);       // piece = tid & 1 = item & 1
-        }
-        f32x4 sr0[4], sr1[4];
-        bool sok0[4], sok1[4];
-        auto sload = [&](int pp) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c0 = (pp * 2 + (tid + j * NTHR) / SITEMS) * CK;
-                const float* src;
-                int ldc, cb;
-                if (c0 < p.sc1) { src = p.sx1; ldc = p.sc1; cb = c0; } else { src = p.sx2; ldc = p.sc2; cb = c0 - p.sc1; }
-                const int cpos = cb + piece * 8;
-                const bool real = src != nullptr && cb < ldc;               // a pad chunk past the last channel reads zeros
-                sok0[j] = real && cpos < ldc;
-                sok1[j] = real && cpos + 4 < ldc;
-                const float* qp = (real ? src : p.sx1) + (size_t)(sgv[j] >= 0 ? sgv[j] : 0) * (real ? ldc : p.sc1);
-                sr0[j] = *reinterpret_cast<const f32x4*>(qp + (sok0[j] ? cpos : 0));
-                sr1[j] = *reinterpret_cast<const f32x4*>(qp + (sok1[j] ? cpos + 4 : 0));
-            }
-        };
-        const char* sw_img = reinterpret_cast<const char*>(p.swpk) + (size_t)ntile * p.s_npairs * (2 * NT * REC * 2) + wave * 1024 + lane * 16;
-        auto sdma = [&](int pp) {                                          // 8 KB per pair: 8 / TD pieces of 1 KB per wave
-            const char* src = sw_img + (size_t)pp * (2 * NT * REC * 2);
-            char* dst = reinterpret_cast<char*>(lds_sw) + (pp & 1) * (2 * NT * REC * 2) + wave * 1024;
-#pragma unroll
-            for (int i = 0; i < 8 / TD; ++i)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * (TD * 1024)),
-                                                 (__attribute__((address_space(3))) void*)(dst + i * (TD * 1024)), 16, 0, 0);
-        };
-        const int sa_rec = (wave * TH + (row & 3)) * HWP + dx_of_row(row) + half * SREC;
-        const int sb_hi = b_hi;                                            // same [2 taps][NT][REC] row layout as a main weight pair
-        sload(0);
-        for (int pp = 0; pp < p.s_npairs; ++pp) {
-            h8 shi[4], slo[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                split8(sr0[j], sr1[j], (sgv[j] >= 0 && sok0[j]) ? 65504.0f : 0.0f, (sgv[j] >= 0 && sok1[j]) ? 65504.0f : 0.0f, shi[j], slo[j]);
-            __syncthreads();                                               // everyone has left the previous LDS image
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                *reinterpret_cast<h8*>(lds_sa + sst[j]) = shi[j];
-                *reinterpret_cast<h8*>(lds_sa + (sst[j] ^ 16)) = slo[j];
-            }
-            if (pp == 0) sdma(0);                                          // (its buffer overlays the halo: only free after the barrier)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (pp + 1 < p.s_npairs) sdma(pp + 1);
-            sload(pp + 1 < p.s_npairs ? pp + 1 : pp);
-            __builtin_amdgcn_sched_barrier(0);
-            const _Float16* wbuf = lds_sw + (pp & 1) * (2 * NT * REC);
-            const int v0 = sa_rec, v1 = sa_rec + 4;
-            const int o0 = v0 * REC + ((q ^ swz(v0)) << 3);
-            const int o1 = v1 * REC + ((q ^ swz(v1)) << 3);
-            h8 ah[4], al[4];
-#pragma unroll
-            for (int py = 0; py < 2; ++py) {
-                ah[py * 2 + 0] = *reinterpret_cast<const h8*>(lds_sa + o0 + py * (48 * REC));
-                al[py * 2 + 0] = *reinterpret_cast<const h8*>(lds_sa + (o0 ^ 16) + py * (48 * REC));
-                ah[py * 2 + 1] = *reinterpret_cast<const h8*>(lds_sa + o1 + py * (48 * REC));
-                al[py * 2 + 1] = *reinterpret_cast<const h8*>(lds_sa + (o1 ^ 16) + py * (48 * REC));
-            }
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                h8 bh[2], bl[2];
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    bh[k] = *reinterpret_cast<const h8*>(wbuf + ((nb * 2 + k) * 16) * REC + sb_hi);
-                    bl[k] = *reinterpret_cast<const h8*>(wbuf + ((nb * 2 + k) * 16) * REC + (sb_hi ^ 16));
-                }
-                DM3D_MFMA3_TILES(acc, nb, al, ah, bl, bh);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    const Brick br = {b, oz0, oy0, ox0, ooz, ooy, oox, ntile, khalf};
+    if constexpr (KS == 3) {                        // (the launcher admits a skip conv behind k3 / stride 1 only)
+        static_assert(KS != 3 || skip_lds_halfs<TD>() <= HD * HH * HWP * REC + NBUF * WGRP, "skip phase LDS carve");
+        skip_phase<TD>(p, smem_v2, acc, br);
     }
-
-    // ---- epilogue.  Accumulator register r of tile (patch pi, column tile ni): voxel (dy = 4*(pi>>1) + r, dx = 4*(pi&1) +
-    // dx_of_row(4*g4)), output channel ni*16 + row.
-    const int vrow = p.vec ? (p.vec_idx ? p.vec_idx[b] : b) : 0;
-    const int n0 = ntile * NT;
-    const bool full = oz0 + TD <= p.od && oy0 + TH <= p.oh && ox0 + TW <= p.ow && n0 + NT <= p.cout;
-    const int oz = oz0 + wave;
-    const bool z_ok = oz < p.od;
-    const size_t zbase = (((size_t)b * p.fd + (z_ok ? oz * p.os + ooz : 0)) * p.fh) * p.fw * p.cout;
-    float* outz = p.out + zbase + (size_t)khalf * p.split_stride;
-    // atomic mode: half 0 carries the epilogue operands; scratch mode: every part stores its raw partial sums into its own
-    // image (the launcher cleared the epilogue operands; dm3d_conv_split_reduce applies them)
-    const bool split = p.split_atomic != 0, lead = khalf == 0 || !split;
-    const float* resz = (p.res && lead) ? p.res + zbase : nullptr;
-    const float* prz = p.prelu ? p.prelu + (zbase - (size_t)b * p.fd * p.fh * p.fw * p.cout) : nullptr;
-    const int dxl = dx_of_row(4 * g4);
-    const int ystep = p.os * p.fw * p.cout;                              // one brick row further in the output
-    float amax = 0.0f;                                                   // range guard: largest |value| this lane stores
-    const float rlim = split ? 0.5f * p.range_limit : p.range_limit;     // two atomic halves: either may carry half the sum
-#ifndef DM3D_EPILOGUE_SCALAR
-    if (full && !split && p.epi_vec4) {
-        // Full brick, plain stores, aligned operands (the common case).  The MFMA leaves a lane with ONE channel of FOUR voxels (r = 0..3: brick rows); stored
-        // like that every access is 4 bytes per lane — 64 loads + 64 stores per lane with a residual, and the epilogue of a 64 -> 64 conv
-        // took 17-25 thousand cycles (in-kernel stamps), bound by the number of memory instructions, not by bytes.  A 4 x 4 transpose
-        // inside each quad of lanes (two DPP exchange rounds, 16 VALU per tile) gives a lane FOUR consecutive channels of ONE voxel
-        // (row k = n & 3, channels (n & ~3) .. +3): 16-byte accesses, a quarter of the instructions.  Per element the arithmetic and its
-        // order are those of the scalar path below (-DDM3D_EPILOGUE_SCALAR), so the results are bit-identical.
-        const int k = row & 3, c4 = row & ~3;
-        const bool b0 = (row & 1) != 0, b1 = (row & 2) != 0;
-        auto xor1 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)); };
-        auto xor2 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)); };
-        f32x4 rv4[4][4];
-        if (resz) {                                     // all residual pieces requested before the first one is used
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int pi = 0; pi < 4; ++pi)
-                    rv4[ni][pi] = *reinterpret_cast<const f32x4*>(resz + (((oy0 + 4 * (pi >> 1) + k) * p.os + ooy) * p.fw
-                                                                          + (ox0 + 4 * (pi & 1) + dxl) * p.os + oox) * p.cout + n0 + ni * 16 + c4);
-        }
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + ni * 16 + c4;             // first of this lane's four channels
-            f32x4 add = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.vec) {
-                const f32x4 vv = *reinterpret_cast<const f32x4*>(p.vec + (size_t)vrow * p.vec_ld + n);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) add[j] += vv[j];
-            }
-            const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 ps = p.post_scale ? *reinterpret_cast<const f32x4*>(p.post_scale + n) : one;
-            const f32x4 pt = p.post_scale ? *reinterpret_cast<const f32x4*>(p.post_shift + n) : zero;
-            // DM3D_FMT_H2: the hi halves of channels n..n+3 are 8 contiguous bytes of the voxel's record, the lo halves 32 bytes further
-            const int h2off = (n >> 4) * 64 + ((n >> 3) & 1) * 16 + (n & 7) * 2 - n * 4;
-#pragma unroll
-            for (int pi = 0; pi < 4; ++pi) {
-                float a[4] = {acc[pi][ni][0], acc[pi][ni][1], acc[pi][ni][2], acc[pi][ni][3]};
-                {   // quad transpose: a[j] of lane k  <-  a[k] of lane j
-                    float s0 = b0 ? a[0] : a[1], s1 = b0 ? a[2] : a[3];
-                    float r0 = xor1(s0), r1 = xor1(s1);
-                    if (b0) { a[0] = r0; a[2] = r1; } else { a[1] = r0; a[3] = r1; }
-                    s0 = b1 ? a[0] : a[2]; s1 = b1 ? a[1] : a[3];
-                    r0 = xor2(s0); r1 = xor2(s1);
-                    if (b1) { a[0] = r0; a[1] = r1; } else { a[2] = r0; a[3] = r1; }
-                }
-                const int o = (((oy0 + 4 * (pi >> 1) + k) * p.os + ooy) * p.fw + (ox0 + 4 * (pi & 1) + dxl) * p.os + oox) * p.cout + n;
-                f32x4 al4 = zero;
-                if (prz) al4 = *reinterpret_cast<const f32x4*>(prz + o);
-                f32x4 v4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = fmaf(a[j], p.out_scale, add[j]);
-                    if (p.relu) v = fmaxf(v, 0.0f);
-                    if (prz) v = v > 0.0f ? v : al4[j] * v;
-                    if (resz) v += rv4[ni][pi][j];
-                    if (p.relu_out) v = fmaxf(v, 0.0f);
-                    if (p.post_scale) v = dm3d_silu(fmaf(v, ps[j], pt[j]));           // the consumer's norm + SiLU, applied once here
-                    DM3D_AMAX(amax, v);
-                    v4[j] = v;
-                }
-                if (p.out_h2) {
-                    const unsigned int w0 = split1_bits(v4[0]), w1 = split1_bits(v4[1]), w2 = split1_bits(v4[2]), w3 = split1_bits(v4[3]);
-                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                    char* dst = reinterpret_cast<char*>(outz) + (size_t)o * 4 + h2off;
-                    *reinterpret_cast<u32x2*>(dst) = u32x2{(w0 & 0xffffu) | (w1 << 16), (w2 & 0xffffu) | (w3 << 16)};
-                    *reinterpret_cast<u32x2*>(dst + 32) = u32x2{(w0 >> 16) | (w1 & 0xffff0000u), (w2 >> 16) | (w3 & 0xffff0000u)};
-                } else {
-                    *reinterpret_cast<f32x4*>(outz + o) = v4;
-                }
-            }
-        }
-        if (p.range_flag && amax > rlim) *p.range_flag = 1;
-        return;
-    }
-#endif
-    if (full) {
-        // full brick, scalar form (split-K launches add their halves atomically; -DDM3D_EPILOGUE_SCALAR: the A/B arm of the form above):
-        // all 64 residual values of this lane are requested before the first one is used
-        float rv[4][4][4];
-        if (resz) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int pi = 0; pi < 4; ++pi)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        rv[ni][pi][r] = resz[((oy0 + 4 * (pi >> 1)) * p.os + ooy) * p.fw * p.cout
-                                             + ((ox0 + 4 * (pi & 1) + dxl) * p.os + oox) * p.cout + n0 + ni * 16 + row + r * ystep];
-        }
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + ni * 16 + row;
-            float add = p.bias ? p.bias[n] : 0.0f;
-            if (p.vec) add += p.vec[(size_t)vrow * p.vec_ld + n];
-            if (!lead) add = 0.0f;
-            const float ps = p.post_scale ? p.post_scale[n] : 1.0f, pt = p.post_scale ? p.post_shift[n] : 0.0f;
-            // DM3D_FMT_H2 position of channel n inside its voxel's row (see dm3d_gemm_h3.hip): lanes n and n^1 exchange halves
-            const int h2col = (n >> 4) * 64 + ((n >> 3) & 1) * 16 + ((n & 7) >> 1) * 4 + (n & 1) * 32 - n * 4;
-#pragma unroll
-            for (int pi = 0; pi < 4; ++pi) {
-                const int base = (((oy0 + 4 * (pi >> 1)) * p.os + ooy) * p.fw + (ox0 + 4 * (pi & 1) + dxl) * p.os + oox) * p.cout + n;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = base + r * ystep;
-                    float v = fmaf(acc[pi][ni][r], p.out_scale, add);
-                    if (p.relu) v = fmaxf(v, 0.0f);
-                    if (prz) { const float al = prz[o]; v = v > 0.0f ? v : al * v; }
-                    if (resz) v += rv[ni][pi][r];
-                    if (p.relu_out) v = fmaxf(v, 0.0f);
-                    if (p.post_scale) v = dm3d_silu(fmaf(v, ps, pt));                 // the consumer's norm + SiLU, applied once here
-                    DM3D_AMAX(amax, v);
-                    if (p.out_h2) {
-                        const unsigned int mine = split1_bits(v);
-                        const unsigned int oth = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, false);   // lane ^ 1
-                        const unsigned int word = (n & 1) ? ((oth >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (oth << 16));
-                        *reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(outz) + (size_t)o * 4 + h2col) = word;
-                    } else if (split) {
-                        unsafeAtomicAdd(outz + o, v);
-                    } else {
-                        outz[o] = v;
-                    }
-                }
-            }
-        }
-        if (p.range_flag && amax > rlim) *p.range_flag = 1;
-        return;
-    }
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + ni * 16 + row;
-        const bool n_ok = n < p.cout;
-        const int nc = n_ok ? n : p.cout - 1;
-        float add = p.bias ? p.bias[nc] : 0.0f;
-        if (p.vec) add += p.vec[(size_t)vrow * p.vec_ld + nc];
-        if (!lead) add = 0.0f;
-#pragma unroll
-        for (int pi = 0; pi < 4; ++pi) {
-            const int oyb = oy0 + 4 * (pi >> 1), ox = ox0 + 4 * (pi & 1) + dxl;
-            const int base = ((oyb * p.os + ooy) * p.fw + ox * p.os + oox) * p.cout + nc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool ok = n_ok && z_ok && oyb + r < p.oh && ox < p.ow;
-                const int o = ok ? base + r * ystep : 0;
-                float v = fmaf(acc[pi][ni][r], p.out_scale, add);
-                if (p.relu) v = fmaxf(v, 0.0f);
-                if (prz) { const float al = prz[o]; v = v > 0.0f ? v : al * v; }
-                if (resz) v += resz[o];
-                if (p.relu_out) v = fmaxf(v, 0.0f);
-                if (ok) { DM3D_AMAX(amax, v); if (split) unsafeAtomicAdd(outz + o, v); else outz[o] = v; }
-            }
-        }
-    }
-    if (p.range_flag && amax > rlim) *p.range_flag = 1;
+    epilogue<TD>(p, acc, br);
 }
 
 // out = epilogue(sum of the ksplit partial-sum images, added in image order): + bias[c] + vec[row(b)][c] -> ReLU -> PReLU -> + res ->
@@ -962,24 +435,19 @@ __global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, lo
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[n4 * 4 + threadIdx.x] = 0.f;
 }
 
-template <int KS, int MODE, int TD, int NBUF, int F8 = 0>
-int launch_v2(ConvArgs& a, hipStream_t st) {
-    constexpr int HREC = (TD - 1 + KS) * (7 + KS) * 12;
-    constexpr size_t lds = (size_t)(HREC * REC + NBUF * 4 * 64 * REC) * sizeof(_Float16);
-    static_assert((TD == 4 ? 2 : 1) * lds <= 160 * 1024, "workgroups per CU x LDS");
-    a.bd = (a.od + TD - 1) / TD;
+}  // namespace
+
+// Everything around the conv launch itself that the v2 and v3 kernels share: brick counts, Cin splitting for small grids (zero fill +
+// two-way atomic add, or raw partial sums into caller scratch + a reduce launch that applies the epilogue), 16-byte epilogue eligibility.
+int dm3d_h3v2_pre_launch(ConvArgs& a, int td, bool f8, H3v2Launch& L, hipStream_t st) {
+    a.bd = (a.od + td - 1) / td;
     a.bh = (a.oh + 7) / 8;
     a.bw = (a.ow + 7) / 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3v2<KS, MODE, TD, NBUF, F8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
     // Small grids (the 8^3 level at B = 32 has 64 bricks x 4 channel tiles = one workgroup per CU, i.e. one wave per SIMD with
     // nothing to hide its barriers and LDS latency behind: in-kernel stamps showed 58 % MFMA occupancy inside the tap loop there;
     // at B = 1 that level has 8 workgroups for 256 CUs) split the Cin chunks over several workgroups per brick.
     const bool with_scratch = a.scratch != nullptr;
-    a.ksplit = (TD != 4 || a.out_h2 || a.post_scale) ? 1 : dm3d_conv_h3v2_ksplit(a, with_scratch);     // the fused output forms live in the plain epilogue
+    a.ksplit = (td != 4 || a.out_h2 || a.post_scale) ? 1 : dm3d_conv_h3v2_ksplit(a, with_scratch);     // the fused output forms live in the plain epilogue
     const size_t out_elems = (size_t)a.batch * a.fd * a.fh * a.fw * a.cout;
     a.split_atomic = 0;
     a.split_stride = 0;
@@ -988,11 +456,14 @@ int launch_v2(ConvArgs& a, hipStream_t st) {
         a.epi_vec4 = a.cout % 4 == 0 && al16(a.out) && al16(a.bias) && al16(a.res) && al16(a.prelu) && al16(a.post_scale) && al16(a.post_shift)
                      && al16(a.vec) && (a.vec == nullptr || a.vec_ld % 4 == 0);
     }
-    ConvArgs k = a;
-    if (F8) k.wpk = a.wpk_f8;
+    ConvArgs& k = L.k;
+    k = a;
+    if (f8) k.wpk = a.wpk_f8;
     const bool linear = !a.relu && !a.prelu && !a.relu_out && a.res != a.out && a.x1 != a.out && a.x2 != a.out;
     static const bool no_atomic = [] { const char* e = getenv("DM3D_CONV_NO_ATOMIC"); return e && e[0] == '1'; }();
     const bool atomic2 = a.ksplit == 2 && linear && a.nchunks >= 8 && !(no_atomic && with_scratch);       // cheaper than a reduce launch when two parts suffice
+    L.out_elems = out_elems;
+    L.reduce = false;
     if (a.ksplit > 1 && (!with_scratch || atomic2)) {         // two halves, order-independent atomic add into the zeroed output
         k.split_atomic = 1;
         long zg = ((long)(out_elems / 4) + 255) / 256;
@@ -1007,11 +478,14 @@ int launch_v2(ConvArgs& a, hipStream_t st) {
         k.split_stride = (long)out_elems;
         k.bias = nullptr; k.vec = nullptr; k.res = nullptr; k.relu = 0; k.prelu = nullptr; k.relu_out = 0;
         k.range_flag = nullptr;                               // the reduce launch checks the finished values
+        L.reduce = true;
     }
-    dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64 * a.ksplit), a.parity ? 8u : 1u);
-    hipLaunchKernelGGL((conv3d_igemm_h3v2<KS, MODE, TD, NBUF, F8>), grid, dim3(TD * 64), lds, st, k);
-    int rc = dm3d_launch_check("conv3d_igemm_h3v2");
-    if (rc || !(a.ksplit > 1 && with_scratch && !atomic2)) return rc;
+    return DM3D_OK;
+}
+
+int dm3d_h3v2_post_launch(const ConvArgs& a, const H3v2Launch& L, hipStream_t st) {
+    if (!L.reduce) return DM3D_OK;
+    const size_t out_elems = L.out_elems;
     const long n4 = (long)(out_elems / 4);                    // cout % 4 == 0 is not required of cout: fall back to scalar lanes
     const bool vec4 = a.cout % 4 == 0;
     const long work = vec4 ? n4 : (long)out_elems;
@@ -1021,6 +495,27 @@ int launch_v2(ConvArgs& a, hipStream_t st) {
                        (long)out_elems, a.out, a.cout, (long)a.fd * a.fh * a.fw * a.cout, a.bias, a.vec, a.vec_idx, a.vec_ld, a.relu, a.prelu,
                        a.res, a.relu_out, vec4 ? 1 : 0, a.range_flag, a.range_limit);
     return dm3d_launch_check("conv_split_reduce_kernel");
+}
+
+namespace {
+
+template <int KS, int MODE>
+int launch_f8(ConvArgs& a, hipStream_t st) {
+    constexpr int TD = 8, NBUF = 3;
+    constexpr int HREC = (TD - 1 + KS) * (7 + KS) * 12;
+    constexpr size_t lds = (size_t)(HREC * REC + NBUF * 4 * 64 * REC) * sizeof(_Float16);
+    static_assert(lds <= 160 * 1024, "one workgroup per CU");
+    static bool attr_set = false;
+    if (!attr_set) {
+        DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3f8<KS, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    H3v2Launch L;
+    if (int rc = dm3d_h3v2_pre_launch(a, TD, true, L, st)) return rc;
+    dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64 * a.ksplit), a.parity ? 8u : 1u);
+    hipLaunchKernelGGL((conv3d_igemm_h3f8<KS, MODE>), grid, dim3(TD * 64), lds, st, L.k);
+    if (int rc = dm3d_launch_check("conv3d_igemm_h3f8")) return rc;
+    return dm3d_h3v2_post_launch(a, L, st);
 }
 
 // weight image of the v2 kernel: [coutpad/64][cinpad/16][TAPSP][64 positions][REC]; position 16*t16 + PI(c) holds output channel
@@ -1127,55 +622,23 @@ int dm3d_conv_h3v2_ksplit(const ConvArgs& a, bool with_scratch) {
     return best;
 }
 
-// The 8-slice / 512-thread / three-buffer form serves launches with enough bricks to fill the chip at one workgroup per CU; the
-// 4-slice / 256-thread / two-buffer form (two workgroups per CU, Cin splitting for tiny grids) serves the rest.  DM3D_CONV_WIDE=0 forces
-// the narrow form (A/B), DM3D_CONV_WIDE_WGS overrides the threshold.
-// Measured (B = 32, 32^3 x 8ch, per-layer HIP events, tools/layer_profile.py): the wide form is 1-4 % faster on the large-Cin k3 convs
-// (32^3 192->64: 1.627 -> 1.612 ms, 16^3 384->128: 0.808 -> 0.773), 5-9 % slower where a fused skip phase follows (its barriers span
-// eight waves) and 12 % slower on the UpSample parity convs (2 weight groups per chunk: nothing for the deeper ring to run ahead of).
-// DM3D_CONV_WIDE: 0 never, 1 (default) k3 without skip phase, 2 wherever the grid is large enough.
-static bool use_wide(const ConvArgs& a) {
-    static const int mode = [] { const char* e = getenv("DM3D_CONV_WIDE"); return e ? atoi(e) : 1; }();
-    static const long min_wgs = [] { const char* e = getenv("DM3D_CONV_WIDE_WGS"); return e ? atol(e) : 512L; }();
-    if (mode == 0) return false;
-    if (mode == 1 && (a.parity || a.s_npairs > 0)) return false;
-    if ((a.out_h2 || a.post_scale) && a.od % 8 != 0) return false;     // the fused output forms live in the full-brick epilogue: whole 8-slice bricks
-    const long wgs = (long)a.batch * ((a.od + 7) / 8) * ((a.oh + 7) / 8) * ((a.ow + 7) / 8) * (a.coutpad / 64) * (a.parity ? 8 : 1);
-    return wgs >= min_wgs;
-}
-
-bool dm3d_conv_h3v2_wide(const ConvArgs& a) { return use_wide(a); }
-
 // The float8 cross-term form (F8) serves a launch when the caller supplied the second weight image (wpk_f8) and the grid is large enough
 // for 8-slice bricks.  (A fused skip phase keeps its own staging, weight image and three-pass arithmetic; the hand-off output format is
 // the epilogue's business: both are independent of the main loop's operand format.)
 bool dm3d_conv_h3v2_f8(const ConvArgs& a) {
     static const int min_wgs = [] { const char* e = getenv("DM3D_CONV_WIDE_WGS"); return e ? atoi(e) : 512; }();
     if (!a.wpk_f8) return false;
-    if ((a.out_h2 || a.post_scale) && a.od % 8 != 0) return false;     // (as in use_wide)
+    if ((a.out_h2 || a.post_scale) && a.od % 8 != 0) return false;     // the fused output forms live in the full-brick epilogue: whole 8-slice bricks
     const long wgs = (long)a.batch * ((a.od + 7) / 8) * ((a.oh + 7) / 8) * ((a.ow + 7) / 8) * (a.coutpad / 64) * (a.parity ? 8 : 1);
     return wgs >= min_wgs;
 }
 
-template <int KS, int MODE>
-static int launch_any(ConvArgs& a, hipStream_t st) {
-    // (the float8 form in 4-slice bricks, two workgroups per CU, was 8-12 % slower on the large grids and spilled registers: not built)
-    if (dm3d_conv_h3v2_f8(a)) return launch_v2<KS, MODE, 8, 3, 1>(a, st);
-    if (!use_wide(a)) return launch_v2<KS, MODE, 4, 2>(a, st);
-    if constexpr (KS == 3) {
-        // weight-ring depth of the ping-pong loop (A/B knob, read per call): DM3D_CONV_RING = 3 (default), 4, 5
-        const char* e = getenv("DM3D_CONV_RING");
-        const int ring = e ? atoi(e) : 3;
-        if (ring == 5) return launch_v2<KS, MODE, 8, 5>(a, st);
-        if (ring == 4) return launch_v2<KS, MODE, 8, 4>(a, st);
-    }
-    return launch_v2<KS, MODE, 8, 3>(a, st);
-}
-
+// only the float8 cross-term launches come here (dm3d_conv.hip: dm3d_conv_h3v3_serves() is false for them)
 int dm3d_conv_launch_h3v2(ConvArgs& a, int which, hipStream_t st) {
-    if (which == DM3D_CONV_UP) return a.pscale ? launch_any<2, 1>(a, st) : launch_any<2, 0>(a, st);
-    if (a.x_h2) return launch_any<3, 2>(a, st);
-    return a.pscale ? launch_any<3, 1>(a, st) : launch_any<3, 0>(a, st);
+    DM3D_REQUIRE(dm3d_conv_h3v2_f8(a), "conv: dm3d_conv_launch_h3v2 serves the float8 cross-term form only");
+    if (which == DM3D_CONV_UP) return a.pscale ? launch_f8<2, 1>(a, st) : launch_f8<2, 0>(a, st);
+    if (a.x_h2) return launch_f8<3, 2>(a, st);
+    return a.pscale ? launch_f8<3, 1>(a, st) : launch_f8<3, 0>(a, st);
 }
 
 // f8: the image of the float8 cross-term form (taps padded to a multiple of 8, records in the H3F8 layout)

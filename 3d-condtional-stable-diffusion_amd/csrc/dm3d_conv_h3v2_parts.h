@@ -1,0 +1,323 @@
+// dm3d_conv_h3v2_parts.h — pieces shared by the two 16x16x32 split-float16 Conv3d kernels (dm3d_conv_h3v2.hip: the per-segment
+// ping-pong / float8 forms; dm3d_conv_h3v3.hip: the free-running software-pipelined form): operand geometry helpers, the fused 1x1
+// skip-conv tail phase and the epilogue.  Both kernels own a [4 patches][4 column tiles] accumulator per wave, one 8 x 8 z-slice each.
+#pragma once
+#include "dm3d_conv_args.h"
+#include "dm3d_h3.h"
+
+namespace h3v2 {
+
+constexpr int REC = DM3D_REC;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// LDS position (within its group of 16) of the weight row read by MFMA column c
+__host__ __device__ constexpr int pi_pos(int c) {
+    return c < 4 ? (c < 2 ? c : c + 2) : (c >= 12 ? (c < 14 ? c - 4 : c - 2) : (((c - 4) >> 1) * 4 + 2 + ((c - 4) & 1)));
+}
+// patch column of MFMA row i (rows 0-3 -> 0, 4-7 -> 2, 8-11 -> 3, 12-15 -> 1); patch row is i & 3
+__device__ __forceinline__ int dx_of_row(int i) { return (0x1320 >> ((i >> 2) * 4)) & 3; }
+
+// The three passes (al.bh, ah.bl, ah.bh) of the 4 x 2 accumulator tiles one weight batch feeds, tile-major.
+#define DM3D_MFMA3_TILES(acc, nb, al, ah, bl, bh)                                                        \
+    _Pragma("unroll") for (int pi_ = 0; pi_ < 4; ++pi_)                                                  \
+        _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_) {                                               \
+            f32x4v& c_ = acc[pi_][(nb) * 2 + k_];                                                        \
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[pi_], bh[k_], c_, 0, 0, 0);                   \
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi_], bl[k_], c_, 0, 0, 0);                   \
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pi_], bh[k_], c_, 0, 0, 0);                   \
+        }
+
+// geometry of one workgroup's brick, as both kernels compute it
+struct Brick {
+    int b, oz0, oy0, ox0;            // sample, first output voxel
+    int ooz, ooy, oox;               // output offset in the full tensor (parity bits)
+    int ntile, khalf;                // 64-column tile, split-K part
+};
+
+// LDS bytes the skip phase needs (it overlays the main loop's images once every wave has left them)
+template <int TD> constexpr int skip_lds_halfs() { return 2 * TD * 8 * 12 * REC + 2 * 2 * 64 * REC; }
+
+template <int TD>
+__device__ __forceinline__ void skip_phase(const ConvArgs& p, _Float16* smem, f32x4v (&acc)[4][4], const Brick& br) {
+    constexpr int TH = 8, TW = 8, CK = 16, NT = 64, NTHR = TD * 64, HWP = 12, KS = 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, q = (lane >> 4) & 1, row = lane & 15, piece = tid & 1;
+    const int b = br.b, oz0 = br.oz0, oy0 = br.oy0, ox0 = br.ox0, ntile = br.ntile, khalf = br.khalf;
+    const int b_pos = pi_pos(row);
+    const int b_hi = (half * NT + b_pos) * REC + ((q ^ swz(b_pos)) << 3);
+    // ---- fused 1x1 conv over a second, raw input (ResidualBlock: out = conv2(...) + Conv3D(width, 1)(x), conditional_dm3d.py:243-248,
+    // 268).  K = 32 per MFMA = two 16-channel chunks of the SAME voxel instead of two taps: chunk 2i goes to LDS region 0, chunk
+    // 2i+1 to region 1 (brick voxels only, rows padded to 12 records like the halo so the patch reads stay conflict-free), the
+    // lane half picks the region.  One pair of chunks = one barrier pair + 48 MFMAs per wave; the next pair's weights (8 KB by
+    // LDS-DMA) and voxels (registers) are in flight meanwhile.  Part 0 of a split-K launch carries it.
+    if constexpr (KS == 3) if (p.s_npairs > 0 && khalf == 0) {     // (the launcher admits a skip conv behind k3 / stride 1 only)
+        constexpr int SREC = TD * TH * HWP;                                // 384 records per region
+        _Float16* lds_sa = smem;                                        // [2][SREC][REC]            (0 .. 48 KB)
+        _Float16* lds_sw = smem + 2 * SREC * REC;                       // [2 buffers][2][NT][REC]   (48 .. 64 KB)
+        constexpr int SITEMS = TD * TH * TW * 2;                          // 16-byte pieces per region (= 2 * NTHR: four per thread in all)
+        int sgv[4], sst[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int item = tid + j * NTHR, t = item / SITEMS, iv = (item % SITEMS) >> 1;
+            const int z = iv >> 6, y = (iv >> 3) & 7, x = iv & 7;
+            const bool in = oz0 + z < p.ind && oy0 + y < p.inh && ox0 + x < p.inw;
+            sgv[j] = in ? ((b * p.ind + oz0 + z) * p.inh + oy0 + y) * p.inw + ox0 + x : -1;
+            const int v = (z * TH + y) * HWP + x;
+            sst[j] = (t * SREC + v) * REC + ((piece ^ swz(v)) << 3);       // piece = tid & 1 = item & 1
+        }
+        f32x4 sr0[4], sr1[4];
+        bool sok0[4], sok1[4];
+        auto sload = [&](int pp) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c0 = (pp * 2 + (tid + j * NTHR) / SITEMS) * CK;
+                const float* src;
+                int ldc, cb;
+                if (c0 < p.sc1) { src = p.sx1; ldc = p.sc1; cb = c0; } else { src = p.sx2; ldc = p.sc2; cb = c0 - p.sc1; }
+                const int cpos = cb + piece * 8;
+                const bool real = src != nullptr && cb < ldc;               // a pad chunk past the last channel reads zeros
+                sok0[j] = real && cpos < ldc;
+                sok1[j] = real && cpos + 4 < ldc;
+                const float* qp = (real ? src : p.sx1) + (size_t)(sgv[j] >= 0 ? sgv[j] : 0) * (real ? ldc : p.sc1);
+                sr0[j] = *reinterpret_cast<const f32x4*>(qp + (sok0[j] ? cpos : 0));
+                sr1[j] = *reinterpret_cast<const f32x4*>(qp + (sok1[j] ? cpos + 4 : 0));
+            }
+        };
+        const char* sw_img = reinterpret_cast<const char*>(p.swpk) + (size_t)ntile * p.s_npairs * (2 * NT * REC * 2) + wave * 1024 + lane * 16;
+        auto sdma = [&](int pp) {                                          // 8 KB per pair: 8 / TD pieces of 1 KB per wave
+            const char* src = sw_img + (size_t)pp * (2 * NT * REC * 2);
+            char* dst = reinterpret_cast<char*>(lds_sw) + (pp & 1) * (2 * NT * REC * 2) + wave * 1024;
+#pragma unroll
+            for (int i = 0; i < 8 / TD; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * (TD * 1024)),
+                                                 (__attribute__((address_space(3))) void*)(dst + i * (TD * 1024)), 16, 0, 0);
+        };
+        const int sa_rec = (wave * TH + (row & 3)) * HWP + dx_of_row(row) + half * SREC;
+        const int sb_hi = b_hi;                                            // same [2 taps][NT][REC] row layout as a main weight pair
+        sload(0);
+        for (int pp = 0; pp < p.s_npairs; ++pp) {
+            h8 shi[4], slo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                split8(sr0[j], sr1[j], (sgv[j] >= 0 && sok0[j]) ? 65504.0f : 0.0f, (sgv[j] >= 0 && sok1[j]) ? 65504.0f : 0.0f, shi[j], slo[j]);
+            __syncthreads();                                               // everyone has left the previous LDS image
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *reinterpret_cast<h8*>(lds_sa + sst[j]) = shi[j];
+                *reinterpret_cast<h8*>(lds_sa + (sst[j] ^ 16)) = slo[j];
+            }
+            if (pp == 0) sdma(0);                                          // (its buffer overlays the halo: only free after the barrier)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (pp + 1 < p.s_npairs) sdma(pp + 1);
+            sload(pp + 1 < p.s_npairs ? pp + 1 : pp);
+            __builtin_amdgcn_sched_barrier(0);
+            const _Float16* wbuf = lds_sw + (pp & 1) * (2 * NT * REC);
+            const int v0 = sa_rec, v1 = sa_rec + 4;
+            const int o0 = v0 * REC + ((q ^ swz(v0)) << 3);
+            const int o1 = v1 * REC + ((q ^ swz(v1)) << 3);
+            h8 ah[4], al[4];
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                ah[py * 2 + 0] = *reinterpret_cast<const h8*>(lds_sa + o0 + py * (48 * REC));
+                al[py * 2 + 0] = *reinterpret_cast<const h8*>(lds_sa + (o0 ^ 16) + py * (48 * REC));
+                ah[py * 2 + 1] = *reinterpret_cast<const h8*>(lds_sa + o1 + py * (48 * REC));
+                al[py * 2 + 1] = *reinterpret_cast<const h8*>(lds_sa + (o1 ^ 16) + py * (48 * REC));
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                h8 bh[2], bl[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    bh[k] = *reinterpret_cast<const h8*>(wbuf + ((nb * 2 + k) * 16) * REC + sb_hi);
+                    bl[k] = *reinterpret_cast<const h8*>(wbuf + ((nb * 2 + k) * 16) * REC + (sb_hi ^ 16));
+                }
+                DM3D_MFMA3_TILES(acc, nb, al, ah, bl, bh);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+}
+
+template <int TD>
+__device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][4], const Brick& br) {
+    constexpr int TH = 8, TW = 8, NT = 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = lane & 15, g4 = lane >> 4;
+    const int b = br.b, oz0 = br.oz0, oy0 = br.oy0, ox0 = br.ox0, ooz = br.ooz, ooy = br.ooy, oox = br.oox, ntile = br.ntile, khalf = br.khalf;
+    // ---- epilogue.  Accumulator register r of tile (patch pi, column tile ni): voxel (dy = 4*(pi>>1) + r, dx = 4*(pi&1) +
+    // dx_of_row(4*g4)), output channel ni*16 + row.
+    const int vrow = p.vec ? (p.vec_idx ? p.vec_idx[b] : b) : 0;
+    const int n0 = ntile * NT;
+    const bool full = oz0 + TD <= p.od && oy0 + TH <= p.oh && ox0 + TW <= p.ow && n0 + NT <= p.cout;
+    const int oz = oz0 + wave;
+    const bool z_ok = oz < p.od;
+    const size_t zbase = (((size_t)b * p.fd + (z_ok ? oz * p.os + ooz : 0)) * p.fh) * p.fw * p.cout;
+    float* outz = p.out + zbase + (size_t)khalf * p.split_stride;
+    // atomic mode: half 0 carries the epilogue operands; scratch mode: every part stores its raw partial sums into its own
+    // image (the launcher cleared the epilogue operands; dm3d_conv_split_reduce applies them)
+    const bool split = p.split_atomic != 0, lead = khalf == 0 || !split;
+    const float* resz = (p.res && lead) ? p.res + zbase : nullptr;
+    const float* prz = p.prelu ? p.prelu + (zbase - (size_t)b * p.fd * p.fh * p.fw * p.cout) : nullptr;
+    const int dxl = dx_of_row(4 * g4);
+    const int ystep = p.os * p.fw * p.cout;                              // one brick row further in the output
+    float amax = 0.0f;                                                   // range guard: largest |value| this lane stores
+    const float rlim = split ? 0.5f * p.range_limit : p.range_limit;     // two atomic halves: either may carry half the sum
+#ifndef DM3D_EPILOGUE_SCALAR
+    if (full && !split && p.epi_vec4) {
+        // Full brick, plain stores, aligned operands (the common case).  The MFMA leaves a lane with ONE channel of FOUR voxels (r = 0..3: brick rows); stored
+        // like that every access is 4 bytes per lane — 64 loads + 64 stores per lane with a residual, and the epilogue of a 64 -> 64 conv
+        // took 17-25 thousand cycles (in-kernel stamps), bound by the number of memory instructions, not by bytes.  A 4 x 4 transpose
+        // inside each quad of lanes (two DPP exchange rounds, 16 VALU per tile) gives a lane FOUR consecutive channels of ONE voxel
+        // (row k = n & 3, channels (n & ~3) .. +3): 16-byte accesses, a quarter of the instructions.  Per element the arithmetic and its
+        // order are those of the scalar path below (-DDM3D_EPILOGUE_SCALAR), so the results are bit-identical.
+        const int k = row & 3, c4 = row & ~3;
+        const bool b0 = (row & 1) != 0, b1 = (row & 2) != 0;
+        auto xor1 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)); };
+        auto xor2 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)); };
+        f32x4 rv4[4][4];
+        if (resz) {                                     // all residual pieces requested before the first one is used
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int pi = 0; pi < 4; ++pi)
+                    rv4[ni][pi] = *reinterpret_cast<const f32x4*>(resz + (((oy0 + 4 * (pi >> 1) + k) * p.os + ooy) * p.fw
+                                                                          + (ox0 + 4 * (pi & 1) + dxl) * p.os + oox) * p.cout + n0 + ni * 16 + c4);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + ni * 16 + c4;             // first of this lane's four channels
+            f32x4 add = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.vec) {
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(p.vec + (size_t)vrow * p.vec_ld + n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) add[j] += vv[j];
+            }
+            const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 ps = p.post_scale ? *reinterpret_cast<const f32x4*>(p.post_scale + n) : one;
+            const f32x4 pt = p.post_scale ? *reinterpret_cast<const f32x4*>(p.post_shift + n) : zero;
+            // DM3D_FMT_H2: the hi halves of channels n..n+3 are 8 contiguous bytes of the voxel's record, the lo halves 32 bytes further
+            const int h2off = (n >> 4) * 64 + ((n >> 3) & 1) * 16 + (n & 7) * 2 - n * 4;
+#pragma unroll
+            for (int pi = 0; pi < 4; ++pi) {
+                float a[4] = {acc[pi][ni][0], acc[pi][ni][1], acc[pi][ni][2], acc[pi][ni][3]};
+                {   // quad transpose: a[j] of lane k  <-  a[k] of lane j
+                    float s0 = b0 ? a[0] : a[1], s1 = b0 ? a[2] : a[3];
+                    float r0 = xor1(s0), r1 = xor1(s1);
+                    if (b0) { a[0] = r0; a[2] = r1; } else { a[1] = r0; a[3] = r1; }
+                    s0 = b1 ? a[0] : a[2]; s1 = b1 ? a[1] : a[3];
+                    r0 = xor2(s0); r1 = xor2(s1);
+                    if (b1) { a[0] = r0; a[1] = r1; } else { a[2] = r0; a[3] = r1; }
+                }
+                const int o = (((oy0 + 4 * (pi >> 1) + k) * p.os + ooy) * p.fw + (ox0 + 4 * (pi & 1) + dxl) * p.os + oox) * p.cout + n;
+                f32x4 al4 = zero;
+                if (prz) al4 = *reinterpret_cast<const f32x4*>(prz + o);
+                f32x4 v4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = fmaf(a[j], p.out_scale, add[j]);
+                    if (p.relu) v = fmaxf(v, 0.0f);
+                    if (prz) v = v > 0.0f ? v : al4[j] * v;
+                    if (resz) v += rv4[ni][pi][j];
+                    if (p.relu_out) v = fmaxf(v, 0.0f);
+                    if (p.post_scale) v = dm3d_silu(fmaf(v, ps[j], pt[j]));           // the consumer's norm + SiLU, applied once here
+                    DM3D_AMAX(amax, v);
+                    v4[j] = v;
+                }
+                if (p.out_h2) {
+                    const unsigned int w0 = split1_bits(v4[0]), w1 = split1_bits(v4[1]), w2 = split1_bits(v4[2]), w3 = split1_bits(v4[3]);
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    char* dst = reinterpret_cast<char*>(outz) + (size_t)o * 4 + h2off;
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{(w0 & 0xffffu) | (w1 << 16), (w2 & 0xffffu) | (w3 << 16)};
+                    *reinterpret_cast<u32x2*>(dst + 32) = u32x2{(w0 >> 16) | (w1 & 0xffff0000u), (w2 >> 16) | (w3 & 0xffff0000u)};
+                } else {
+                    *reinterpret_cast<f32x4*>(outz + o) = v4;
+                }
+            }
+        }
+        if (p.range_flag && amax > rlim) *p.range_flag = 1;
+        return;
+    }
+#endif
+    if (full) {
+        // full brick, scalar form (split-K launches add their halves atomically; -DDM3D_EPILOGUE_SCALAR: the A/B arm of the form above):
+        // all 64 residual values of this lane are requested before the first one is used
+        float rv[4][4][4];
+        if (resz) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        rv[ni][pi][r] = resz[((oy0 + 4 * (pi >> 1)) * p.os + ooy) * p.fw * p.cout
+                                             + ((ox0 + 4 * (pi & 1) + dxl) * p.os + oox) * p.cout + n0 + ni * 16 + row + r * ystep];
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + ni * 16 + row;
+            float add = p.bias ? p.bias[n] : 0.0f;
+            if (p.vec) add += p.vec[(size_t)vrow * p.vec_ld + n];
+            if (!lead) add = 0.0f;
+            const float ps = p.post_scale ? p.post_scale[n] : 1.0f, pt = p.post_scale ? p.post_shift[n] : 0.0f;
+            // DM3D_FMT_H2 position of channel n inside its voxel's row (see dm3d_gemm_h3.hip): lanes n and n^1 exchange halves
+            const int h2col = (n >> 4) * 64 + ((n >> 3) & 1) * 16 + ((n & 7) >> 1) * 4 + (n & 1) * 32 - n * 4;
+#pragma unroll
+            for (int pi = 0; pi < 4; ++pi) {
+                const int base = (((oy0 + 4 * (pi >> 1)) * p.os + ooy) * p.fw + (ox0 + 4 * (pi & 1) + dxl) * p.os + oox) * p.cout + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = base + r * ystep;
+                    float v = fmaf(acc[pi][ni][r], p.out_scale, add);
+                    if (p.relu) v = fmaxf(v, 0.0f);
+                    if (prz) { const float al = prz[o]; v = v > 0.0f ? v : al * v; }
+                    if (resz) v += rv[ni][pi][r];
+                    if (p.relu_out) v = fmaxf(v, 0.0f);
+                    if (p.post_scale) v = dm3d_silu(fmaf(v, ps, pt));                 // the consumer's norm + SiLU, applied once here
+                    DM3D_AMAX(amax, v);
+                    if (p.out_h2) {
+                        const unsigned int mine = split1_bits(v);
+                        const unsigned int oth = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, false);   // lane ^ 1
+                        const unsigned int word = (n & 1) ? ((oth >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (oth << 16));
+                        *reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(outz) + (size_t)o * 4 + h2col) = word;
+                    } else if (split) {
+                        unsafeAtomicAdd(outz + o, v);
+                    } else {
+                        outz[o] = v;
+                    }
+                }
+            }
+        }
+        if (p.range_flag && amax > rlim) *p.range_flag = 1;
+        return;
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + ni * 16 + row;
+        const bool n_ok = n < p.cout;
+        const int nc = n_ok ? n : p.cout - 1;
+        float add = p.bias ? p.bias[nc] : 0.0f;
+        if (p.vec) add += p.vec[(size_t)vrow * p.vec_ld + nc];
+        if (!lead) add = 0.0f;
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) {
+            const int oyb = oy0 + 4 * (pi >> 1), ox = ox0 + 4 * (pi & 1) + dxl;
+            const int base = ((oyb * p.os + ooy) * p.fw + ox * p.os + oox) * p.cout + nc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = n_ok && z_ok && oyb + r < p.oh && ox < p.ow;
+                const int o = ok ? base + r * ystep : 0;
+                float v = fmaf(acc[pi][ni][r], p.out_scale, add);
+                if (p.relu) v = fmaxf(v, 0.0f);
+                if (prz) { const float al = prz[o]; v = v > 0.0f ? v : al * v; }
+                if (resz) v += resz[o];
+                if (p.relu_out) v = fmaxf(v, 0.0f);
+                if (ok) { DM3D_AMAX(amax, v); if (split) unsafeAtomicAdd(outz + o, v); else outz[o] = v; }
+            }
+        }
+    }
+    if (p.range_flag && amax > rlim) *p.range_flag = 1;
+}
+
+}  // namespace h3v2

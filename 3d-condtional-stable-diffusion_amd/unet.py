@@ -573,7 +573,7 @@ class Plan:
         elif stride == 2:
             kind = "conv_k3s2"
         elif form == 9:
-            kind = "conv_f8_up" if upsample else ("conv_f8_h2in" if x1_h2 else "conv_f8")    # conv3d_igemm_h3v2<KS, MODE, 8, 2, 1>: float8 cross terms
+            kind = "conv_f8_up" if upsample else ("conv_f8_h2in" if x1_h2 else "conv_f8")    # conv3d_igemm_h3f8<KS, MODE>: float8 cross terms
         elif upsample:
             kind = "conv_up"            # 8 parity 2x2x2 convs
         elif w.cout <= 32 and w.precision == _lib.PREC_H3:
@@ -581,9 +581,9 @@ class Plan:
         elif x1_h2:
             kind = "conv_k3s1_h2in"     # kernel MODE 2: pre-activated DM3D_FMT_H2 input (ResidualBlock conv2 behind a hand-off)
         elif w.precision == _lib.PREC_H3 and pro is not None and form == 4:
-            kind = "conv_k3s1_td4"      # conv3d_igemm_h3v2<3, 1, 4, 2>: the 4-slice form (small grids, fused skip phase)
+            kind = "conv_k3s1_td4"      # conv3d_igemm_h3v3<3, 1, 4>: 4-slice bricks (small grids, fused skip phase)
         else:
-            kind = "conv_k3s1"          # h3: conv3d_igemm_h3v2<3, 1, 8, 3> (prologue, 8-slice bricks); fp32: conv3d_igemm_f32
+            kind = "conv_k3s1"          # h3: conv3d_igemm_h3v3<3, 1, 8> (prologue, 8-slice bricks); fp32: conv3d_igemm_f32
         self.ops.append((lib().dm3d_conv3d_ndhwc, (C.byref(d),), kind,
                          {"desc": f"{kind} {edge_in}^3{'x2up' if upsample else ''} cin={w.cin} cout={w.cout}"
                                   + (f" +k1 skip cin={skip[2] + skip[3]}" if skip is not None else ""),

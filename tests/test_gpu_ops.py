@@ -230,13 +230,13 @@ def test_conv3d_h3_tap_layout_arm(dev):
 
 
 def test_conv3d_8_slice_forms_on_every_shape(dev):
-    """DM3D_CONV_WIDE_WGS=1 DM3D_CONV_WIDE=2 (read when the library is loaded) send every k3 / parity conv to the 8-slice forms — the
-    ping-pong three-pass loop, the float8 form, skip phase and parity convs included — whatever its grid: the small, ragged and odd shapes
-    of the parity cases then run through the kernels the bench uses only on large grids.  One child interpreter."""
+    """DM3D_CONV_WIDE_WGS=1 DM3D_CONV_V3_TD=8 send every k3 / parity conv to the 8-slice forms — the 512-thread free-running loop, the
+    float8 form, skip phase and parity convs included — whatever its grid: the small, ragged and odd shapes of the parity cases then run
+    through the kernels the bench uses only on large grids.  One child interpreter."""
     import os, subprocess, sys
     if os.environ.get("DM3D_CONV_WIDE_WGS") == "1":
         pytest.skip("already inside the 8-slice arm")
-    env = dict(os.environ, DM3D_CONV_WIDE_WGS="1", DM3D_CONV_WIDE="2")
+    env = dict(os.environ, DM3D_CONV_WIDE_WGS="1", DM3D_CONV_V3_TD="8")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
                         "(test_conv3d or random_shapes) and not tap_layout_arm and not 8_slice_forms",
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900,

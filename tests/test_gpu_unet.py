@@ -674,8 +674,8 @@ def test_rccl_collectives_the_bench_uses_single_rank(dev):
 
 
 def test_unet_h3f8_random_configs_through_the_8_slice_forms(dev):
-    """precision="h3f8" over a seeded sweep of build_model arguments with DM3D_CONV_WIDE_WGS=1 DM3D_CONV_WIDE=2 (a child interpreter: the
-    switches are read when the library loads), so that the float8 form, its hand-off twin, its UpSample parity form and the fused skip
+    """precision="h3f8" over a seeded sweep of build_model arguments with DM3D_CONV_WIDE_WGS=1 DM3D_CONV_V3_TD=8 (a child interpreter: the
+    threshold is read when the library loads), so that the float8 form, its hand-off twin, its UpSample parity form and the fused skip
     phase behind it run on the small, odd-sized and GroupNorm configurations too — against the float64 oracle, bar max(3e-4, 8 x the
     float32-vs-float64 conditioning of the case)."""
     import subprocess, sys, textwrap
@@ -713,7 +713,7 @@ def test_unet_h3f8_random_configs_through_the_8_slice_forms(dev):
         assert n_f8 > 0
         print("sweep ok")
     """)
-    env = dict(os.environ, DM3D_CONV_WIDE_WGS="1", DM3D_CONV_WIDE="2")
+    env = dict(os.environ, DM3D_CONV_WIDE_WGS="1", DM3D_CONV_V3_TD="8")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "sweep ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

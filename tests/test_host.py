@@ -68,13 +68,13 @@ int main(void) {
 
 
 def test_stamp_variant_tool_still_patches_the_kernels(built_library):
-    """tools/mk_stamp_variants.py edits the kernel sources by exact-match patches (it asserts every one): keep it in step."""
+    """tools/mk_stamp_variants.py builds the diagnostic libraries (conv: -DDM3D_CLOCK_STAMPS; GEMM: exact-match source patches, each asserted)."""
     import shutil
     import sys
     vdir = os.path.join(os.path.dirname(built_library), "variants")
     try:
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mk_stamp_variants.py")], check=True, capture_output=True, cwd=ROOT)
-        assert os.path.exists(os.path.join(vdir, "cst.so")) and os.path.exists(os.path.join(vdir, "gst.so"))
+        assert os.path.exists(os.path.join(vdir, "cck.so")) and os.path.exists(os.path.join(vdir, "gst.so"))
     finally:
         shutil.rmtree(vdir, ignore_errors=True)
 

@@ -1,7 +1,8 @@
 """In-kernel shader clock of the conv (and GEMM) kernels as MI355X_MICROARCH.md 'DVFS give-back' item 6 defines it:
 delta(s_memtime) / delta(s_memrealtime) x 100 MHz, one stamp pair around the main loop of every workgroup, read after >= 2 s of
 back-to-back launches on random data, median over workgroups.  Needs the clock-stamp variant libraries of tools/mk_stamp_variants.py:
-    DM3D_LIB=<csrc>/variants/cck.so python tools/kernel_clock.py conv     (conv3d_igemm_h3v2; DM3D_CONV_RING etc. apply)
+    DM3D_LIB=<csrc>/variants/cck.so python tools/kernel_clock.py conv     (conv3d_igemm_h3v3; DM3D_CONV_V3_TD applies)
+    DM3D_CONV_V3=0 DM3D_LIB=<csrc>/variants/cck_v2.so python tools/kernel_clock.py conv     (conv3d_igemm_h3v2)
     DM3D_LIB=<csrc>/variants/gst.so python tools/kernel_clock.py gemm
 Also prints the matrix-pipe duty of the stamped interval: MFMA cycles one SIMD must spend (16 per v_mfma_f32_16x16x32_f16) / delta(s_memtime).
 The stamps go to a buffer of their own (never to an output); the product library carries none of this."""
@@ -37,13 +38,15 @@ if what == "conv":
                                     ("16^3 384->128", 16, 384, 128, 0)):
         x = torch.randn(B, e, e, e, cin, device=dev)
         k = torch.randn(3, 3, 3, cin, cout, device=dev) * 0.05
+        if os.environ.get("CLOCK_ZEROS") == "1":      # all-zero operands: the clock the chip holds when the data costs no switching power
+            x.zero_(); k.zero_()
         wpk, w_exp = ops.pack_weights_h3(k)
         kw = dict(bias=torch.randn(cout, device=dev), pro_scale=torch.rand(cin, device=dev) + 0.5, pro_shift=torch.randn(cin, device=dev) * 0.1,
                   res=torch.randn(B, e, e, e, cout, device=dev) if res else None, precision=_lib.PREC_H3, w_exp=w_exp)
         st.zero_()
         ms = sustained(lambda: ops.conv3d(x, wpk, cout, 3, **kw))
-        nb = min(B * (e // 8) ** 3, 4096)
-        s = st.view(4096, 32).cpu()[:nb].double()
+        s = st.view(4096, 32).cpu().double()
+        s = s[s[:, 1] > 0]                            # the workgroups that stamped (blockIdx.y == 0, the first 4096)
         dt, dr = s[:, 28] - s[:, 1], s[:, 31] - s[:, 30]
         ok = dr > 0
         ghz = (dt[ok] / dr[ok] * 0.1)
@@ -52,7 +55,7 @@ if what == "conv":
         fl = 2.0 * 27 * cin * cout * B * e ** 3
         print(f"{name}: {ms:.3f} ms {fl / ms / 1e9:.0f} TF/s algorithmic | in-kernel clock median {ghz.median():.3f} GHz (p10 {ghz.quantile(0.1):.3f}, p90 {ghz.quantile(0.9):.3f}) "
               f"| chunk loop {dt.median():.0f} ticks = {dr.median() / 100:.1f} us, MFMA duty in the loop {mfma_cycles / dt.median():.3f} "
-              f"| workgroup rounds {B * (e // 8) ** 3 * (cout // 64) / 256:.1f}", flush=True)
+              f"| {s.shape[0]} workgroups stamped; whole workgroup {((s[:, 29] - s[:, 0])[s[:, 29] > 0]).median() if (s[:, 29] > 0).any() else 0:.0f} ticks", flush=True)
     raw.dm3d_debug_set_stamps_conv(C.c_void_p(0))
 else:
     st = torch.zeros(2048 * 16, dtype=torch.int64, device=dev)
