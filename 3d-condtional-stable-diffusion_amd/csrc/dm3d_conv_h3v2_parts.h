@@ -4,6 +4,7 @@
 #pragma once
 #include "dm3d_conv_args.h"
 #include "dm3d_h3.h"
+#include <type_traits>
 
 namespace h3v2 {
 
@@ -35,7 +36,7 @@ struct Brick {
 };
 
 // LDS bytes the skip phase needs (it overlays the main loop's images once every wave has left them)
-template <int TD> constexpr int skip_lds_halfs() { return 2 * TD * 8 * 12 * REC + 2 * 2 * 64 * REC; }
+template <int TD> constexpr int skip_lds_halfs() { return 2 * TD * 8 * 12 * REC + 3 * 2 * 64 * REC; }
 
 template <int TD>
 __device__ __forceinline__ void skip_phase(const ConvArgs& p, _Float16* smem, f32x4v (&acc)[4][4], const Brick& br) {
@@ -48,12 +49,14 @@ __device__ __forceinline__ void skip_phase(const ConvArgs& p, _Float16* smem, f3
     // ---- fused 1x1 conv over a second, raw input (ResidualBlock: out = conv2(...) + Conv3D(width, 1)(x), conditional_dm3d.py:243-248,
     // 268).  K = 32 per MFMA = two 16-channel chunks of the SAME voxel instead of two taps: chunk 2i goes to LDS region 0, chunk
     // 2i+1 to region 1 (brick voxels only, rows padded to 12 records like the halo so the patch reads stay conflict-free), the
-    // lane half picks the region.  One pair of chunks = one barrier pair + 48 MFMAs per wave; the next pair's weights (8 KB by
-    // LDS-DMA) and voxels (registers) are in flight meanwhile.  Part 0 of a split-K launch carries it.
-    if constexpr (KS == 3) if (p.s_npairs > 0 && khalf == 0) {     // (the launcher admits a skip conv behind k3 / stride 1 only)
+    // lane half picks the region.  One pair of chunks = one barrier pair + 48 MFMAs per wave; the next two pairs' weights (8 KB by
+    // LDS-DMA) and voxels (registers) are in flight meanwhile.
+    // A split-K launch spreads the pairs over its parts as it spreads the main loop's chunks (the skip sum is linear like them).
+    const int s_lo = p.s_npairs * khalf / p.ksplit, s_hi = p.s_npairs * (khalf + 1) / p.ksplit;
+    if constexpr (KS == 3) if (s_hi > s_lo) {                      // (the launcher admits a skip conv behind k3 / stride 1 only)
         constexpr int SREC = TD * TH * HWP;                                // 384 records per region
         _Float16* lds_sa = smem;                                        // [2][SREC][REC]            (0 .. 48 KB)
-        _Float16* lds_sw = smem + 2 * SREC * REC;                       // [2 buffers][2][NT][REC]   (48 .. 64 KB)
+        _Float16* lds_sw = smem + 2 * SREC * REC;                       // [3 buffers][2][NT][REC]   (48 .. 72 KB)
         constexpr int SITEMS = TD * TH * TW * 2;                          // 16-byte pieces per region (= 2 * NTHR: four per thread in all)
         int sgv[4], sst[4];
 #pragma unroll
@@ -65,9 +68,15 @@ __device__ __forceinline__ void skip_phase(const ConvArgs& p, _Float16* smem, f3
             const int v = (z * TH + y) * HWP + x;
             sst[j] = (t * SREC + v) * REC + ((piece ^ swz(v)) << 3);       // piece = tid & 1 = item & 1
         }
-        f32x4 sr0[4], sr1[4];
-        bool sok0[4], sok1[4];
-        auto sload = [&](int pp) {
+        // Two register sets and three weight buffers: while pair pp is multiplied, the voxels and weights of pairs pp+1 AND pp+2 are in
+        // flight.  (Round 2 kept one pair of lookahead: a pair is 48 MFMAs, ~0.4 us, and every pair waited out most of a memory round trip
+        // behind vmcnt(0) — 2 us per pair at small batch, where no other workgroup fills the gap: profiles/r03_layers_B4.log.)  The loop runs
+        // whole rounds of two steps without a branch around its loads; a step past the last pair re-reads the last weights against zeros.
+        f32x4 sr0[2][4], sr1[2][4];
+        bool sok0[2][4], sok1[2][4];
+        const int np = s_hi;                                               // this part's pairs: s_lo .. np-1
+        auto sload = [&](auto SET, int pp) {
+            constexpr int S = decltype(SET)::value;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c0 = (pp * 2 + (tid + j * NTHR) / SITEMS) * CK;
@@ -75,44 +84,72 @@ __device__ __forceinline__ void skip_phase(const ConvArgs& p, _Float16* smem, f3
                 int ldc, cb;
                 if (c0 < p.sc1) { src = p.sx1; ldc = p.sc1; cb = c0; } else { src = p.sx2; ldc = p.sc2; cb = c0 - p.sc1; }
                 const int cpos = cb + piece * 8;
-                const bool real = src != nullptr && cb < ldc;               // a pad chunk past the last channel reads zeros
-                sok0[j] = real && cpos < ldc;
-                sok1[j] = real && cpos + 4 < ldc;
+                const bool real = src != nullptr && cb < ldc && pp < np;    // a pad chunk past the last channel (or pair) reads zeros
+                sok0[S][j] = real && cpos < ldc;
+                sok1[S][j] = real && cpos + 4 < ldc;
                 const float* qp = (real ? src : p.sx1) + (size_t)(sgv[j] >= 0 ? sgv[j] : 0) * (real ? ldc : p.sc1);
-                sr0[j] = *reinterpret_cast<const f32x4*>(qp + (sok0[j] ? cpos : 0));
-                sr1[j] = *reinterpret_cast<const f32x4*>(qp + (sok1[j] ? cpos + 4 : 0));
+                sr0[S][j] = *reinterpret_cast<const f32x4*>(qp + (sok0[S][j] ? cpos : 0));
+                sr1[S][j] = *reinterpret_cast<const f32x4*>(qp + (sok1[S][j] ? cpos + 4 : 0));
             }
         };
+        constexpr int WS = 8 / TD;                                         // 1 KB DMA pieces per wave and pair
         const char* sw_img = reinterpret_cast<const char*>(p.swpk) + (size_t)ntile * p.s_npairs * (2 * NT * REC * 2) + wave * 1024 + lane * 16;
-        auto sdma = [&](int pp) {                                          // 8 KB per pair: 8 / TD pieces of 1 KB per wave
-            const char* src = sw_img + (size_t)pp * (2 * NT * REC * 2);
-            char* dst = reinterpret_cast<char*>(lds_sw) + (pp & 1) * (2 * NT * REC * 2) + wave * 1024;
+        auto sdma = [&](int pp, int buf) {                                 // 8 KB per pair (past the end: the last pair again)
+            const char* src = sw_img + (size_t)(pp < np ? pp : np - 1) * (2 * NT * REC * 2);
+            char* dst = reinterpret_cast<char*>(lds_sw) + buf * (2 * NT * REC * 2) + wave * 1024;
 #pragma unroll
-            for (int i = 0; i < 8 / TD; ++i)
+            for (int i = 0; i < WS; ++i)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * (TD * 1024)),
                                                  (__attribute__((address_space(3))) void*)(dst + i * (TD * 1024)), 16, 0, 0);
         };
         const int sa_rec = (wave * TH + (row & 3)) * HWP + dx_of_row(row) + half * SREC;
         const int sb_hi = b_hi;                                            // same [2 taps][NT][REC] row layout as a main weight pair
-        sload(0);
-        for (int pp = 0; pp < p.s_npairs; ++pp) {
-            h8 shi[4], slo[4];
+        // vmcnt waits as builtins hipcc's wait-count pass sees (behind an LDS-DMA it guards every load result with vmcnt(0) of its own
+        // otherwise).  simm16 = vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14
+#define DM3D_WAIT_VM(n) __builtin_amdgcn_s_waitcnt((((n) & 15) | (7 << 4) | (15 << 8) | ((((n) >> 4) & 3) << 14)))
+        const std::integral_constant<int, 0> S0;
+        const std::integral_constant<int, 1> S1;
+        // every wave has left the main loop's LDS images (the weight buffers and regions below overlay them) and nothing is in flight
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        sdma(s_lo, 0);
+        sload(S0, s_lo);
+        sdma(s_lo + 1, 1);
+        sload(S1, s_lo + 1);
+        int wbuf_i = 0;                                                    // weight buffer of the pair being multiplied (pp mod 3)
+        auto step = [&](auto SET, int pp) {
+            constexpr int S = decltype(SET)::value;
+            // this pair's voxels and weights were requested two steps ago (the first two: in front of the loop); newer: the other set's
+            // 8 loads and one pair of weights.  The same count in every step: a branch here makes hipcc merge the two states into vmcnt(0).
+            DM3D_WAIT_VM(8 + WS);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                split8(sr0[j], sr1[j], (sgv[j] >= 0 && sok0[j]) ? 65504.0f : 0.0f, (sgv[j] >= 0 && sok1[j]) ? 65504.0f : 0.0f, shi[j], slo[j]);
-            __syncthreads();                                               // everyone has left the previous LDS image
+            for (int j = 0; j < 4; ++j) {                                  // in place: the set's registers become the two 16-byte pieces
+                h8 hi_, lo_;
+                split8(sr0[S][j], sr1[S][j], (sgv[j] >= 0 && sok0[S][j]) ? 65504.0f : 0.0f, (sgv[j] >= 0 && sok1[S][j]) ? 65504.0f : 0.0f, hi_, lo_);
+                sr0[S][j] = __builtin_bit_cast(f32x4, hi_);
+                sr1[S][j] = __builtin_bit_cast(f32x4, lo_);
+            }
+            // raw barriers behind this wave's own LDS traffic: __syncthreads() would also drain the vector-memory counter, i.e. wait for
+            // the requests that are meant to stay in flight across it
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                  // everyone has left the previous LDS image
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                *reinterpret_cast<h8*>(lds_sa + sst[j]) = shi[j];
-                *reinterpret_cast<h8*>(lds_sa + (sst[j] ^ 16)) = slo[j];
+                *reinterpret_cast<f32x4*>(lds_sa + sst[j]) = sr0[S][j];
+                *reinterpret_cast<f32x4*>(lds_sa + (sst[j] ^ 16)) = sr1[S][j];
             }
-            if (pp == 0) sdma(0);                                          // (its buffer overlays the halo: only free after the barrier)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (pp + 1 < p.s_npairs) sdma(pp + 1);
-            sload(pp + 1 < p.s_npairs ? pp + 1 : pp);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                  // the image and this pair's weights are visible
+            asm volatile("" ::: "memory");
+            {
+                const int b2 = wbuf_i + 2 >= 3 ? wbuf_i - 1 : wbuf_i + 2;  // the buffer pair pp-1 left (every wave is past it: the barrier above)
+                sdma(pp + 2, b2);
+                sload(SET, pp + 2);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            const _Float16* wbuf = lds_sw + (pp & 1) * (2 * NT * REC);
+            const _Float16* wbuf = lds_sw + wbuf_i * (2 * NT * REC);
             const int v0 = sa_rec, v1 = sa_rec + 4;
             const int o0 = v0 * REC + ((q ^ swz(v0)) << 3);
             const int o1 = v1 * REC + ((q ^ swz(v1)) << 3);
@@ -135,7 +172,14 @@ __device__ __forceinline__ void skip_phase(const ConvArgs& p, _Float16* smem, f3
                 DM3D_MFMA3_TILES(acc, nb, al, ah, bl, bh);
             }
             __builtin_amdgcn_sched_barrier(0);
+            wbuf_i = wbuf_i + 1 == 3 ? 0 : wbuf_i + 1;
+        };
+        for (int pp = s_lo; pp < np; pp += 2) {
+            step(S0, pp);
+            step(S1, pp + 1);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the tail requests
+#undef DM3D_WAIT_VM
     }
 
 }

@@ -9,12 +9,18 @@
 // the XOR-swizzled LDS records; a float32 operand is still accepted (split on the fly) for the tensors that enter a block
 // from a convolution.
 //
-// Workgroup = 256 threads = 2 x 2 waves of 64 x 64, tile 128 (m) x 128 (n), K in chunks of 32 (two 16-k records per row), LDS
-// double-buffered (2 x 32 KB -> two workgroups per CU), next chunk prefetched into registers during the MFMAs, one barrier
-// per chunk.  The square tile matters: this kernel re-stages both operands every chunk and is bound by LDS write bandwidth
-// (ds_write_b128 ~ 70 B/clk/CU); 128 x 128 stages 341 B per MFMA against 427 B for a 256 x 64 tile, and the model's GEMMs
-// (m = B*L = 16384, n = 256...1024) still yield >= 256 workgroups.
+// Workgroup = 256 threads = 2 x 2 waves, K in chunks of 32 (two 16-k records per row), LDS double-buffered, the next chunks prefetched
+// into registers during the MFMAs, one barrier per chunk.  Two tile forms (template MR = 32 x 32 MFMA tiles per wave and axis):
+//   MR = 2: tile 128 x 128, waves of 64 x 64, two chunks in flight.  The square tile matters: the kernel re-stages both operands every
+//           chunk and is bound by LDS write bandwidth (ds_write_b128 ~ 70 B/clk/CU); 128 x 128 stages 341 B per MFMA against 427 B for a
+//           256 x 64 tile, and the model's GEMMs at B = 32 (m = B*L = 16384, n = 256...1024) still yield >= 256 workgroups.
+//   MR = 1: tile 64 x 64, waves of 32 x 32, EIGHT chunks in flight (16 registers each) — the small-batch form (round 3).  At B = 4 a
+//           K = 256 GEMM of the attention block is 32 tiles of 128 x 128 on a 256-CU chip, and each of its 8 chunks (~0.4 us of MFMAs)
+//           waited out a memory round trip with two chunks of lookahead: 20 us per launch, 36 launches per step = 22 % of the step
+//           (profiles/r03_layers_B4.log).  With every chunk of a K = 256 row requested up front the loop pays one round trip, and four
+//           times as many workgroups share the chip.  Chosen when the 128 x 128 form would leave CUs without a workgroup.
 #include "dm3d_h3.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -42,11 +48,13 @@ struct GemmGroup {                      // independent problems served by one la
 };
 
 constexpr int REC = DM3D_REC;
-constexpr int KC = 32, TM = 128, NT = 128;        // 2 x 2 waves of 64 x 64: A and B staging balanced, 256 B staged per MFMA
-constexpr int A_BUF = 2 * TM * REC, B_BUF = 2 * NT * REC;      // halfs per buffer (two records per row)
+constexpr int KC = 32;
 
-template <bool A_F32, bool B_F32>
+template <bool A_F32, bool B_F32, int MR>
 __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
+    constexpr int TM = 64 * MR, NT = 64 * MR;                     // 2 x 2 waves of (32 MR) x (32 MR): A and B staging balanced
+    constexpr int A_BUF = 2 * TM * REC, B_BUF = 2 * NT * REC;     // halfs per buffer (two records per row)
+    constexpr int NS = MR == 2 ? 2 : 8;                           // register sets = chunks in flight behind the one being multiplied
     // problem selection (uniform): flat tile index -> (problem, batch, tile_m, tile_n); m tiles vary fastest so that
     // consecutive workgroups share the B tile (the weight operand) through L2
     int which = 0;
@@ -71,9 +79,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
     // ---- staging maps (all loads unconditional on clamped rows; rows beyond m / n only feed outputs that are never stored)
     // H2 source: a row's chunk is 128 contiguous bytes = 8 pieces (record kk = w >> 2, slot w & 3)
     // F32 source: item = (row, 8-k group g): two float4 -> hi slot g & 1, lo slot 2 + (g & 1) of record g >> 1
-    constexpr int A_ITEMS = A_F32 ? 2 : 4;
-    constexpr int BI = B_F32 ? 2 : 4;
-    f32x4 ra[2][4], rb[2][4];                   // two register sets: two chunks in flight behind the one being multiplied
+    constexpr int A_ITEMS = (A_F32 ? 1 : 2) * MR;
+    constexpr int BI = (B_F32 ? 1 : 2) * MR;
+    constexpr int RA = A_F32 ? 2 * A_ITEMS : A_ITEMS, RB = B_F32 ? 2 * BI : BI;
+    f32x4 ra[NS][RA], rb[NS][RB];               // NS register sets: NS chunks in flight behind the one being multiplied
     size_t a_src[A_ITEMS];
     int a_dst[A_ITEMS];
 #pragma unroll
@@ -137,8 +146,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
             }
         }
     };
-    // k tail: the chunk's second record is absent when k % 32 == 16; its LDS image is zero filled
-    auto publish = [&](auto SET, int buf, bool second_rec) {
+    // k tail: the chunk's second record is absent when k % 32 == 16; its LDS image is zero filled.  `live` false (a step past the last
+    // chunk: the loop runs whole rounds of NS steps without a branch around its loads): the whole image is zero, the step adds nothing.
+    auto publish = [&](auto SET, int buf, bool second_rec, bool live) {
         constexpr int S = decltype(SET)::value;
         _Float16* da = lds_a + buf * A_BUF;
         _Float16* db = lds_b + buf * B_BUF;
@@ -146,26 +156,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
 #pragma unroll
         for (int i = 0; i < A_ITEMS; ++i) {
             if (A_F32) {
-                const bool ok = second_rec || ((tid + i * 256) & 3) < 2;
+                const bool ok = live && (second_rec || ((tid + i * 256) & 3) < 2);
                 h8 hi, lo;
                 split8(ra[S][2 * i], ra[S][2 * i + 1], ok ? 65504.0f : 0.0f, ok ? 65504.0f : 0.0f, hi, lo);
                 *reinterpret_cast<h8*>(da + a_dst[i]) = hi;
                 *reinterpret_cast<h8*>(da + (a_dst[i] ^ 16)) = lo;
             } else {
-                const bool ok = second_rec || ((tid + i * 256) & 7) < 4;
+                const bool ok = live && (second_rec || ((tid + i * 256) & 7) < 4);
                 *reinterpret_cast<f32x4*>(da + a_dst[i]) = ok ? ra[S][i] : z;
             }
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
             if (B_F32) {
-                const bool ok = second_rec || ((tid + i * 256) & 3) < 2;
+                const bool ok = live && (second_rec || ((tid + i * 256) & 3) < 2);
                 h8 hi, lo;
                 split8(rb[S][2 * i], rb[S][2 * i + 1], ok ? 65504.0f : 0.0f, ok ? 65504.0f : 0.0f, hi, lo);
                 *reinterpret_cast<h8*>(db + b_dst[i]) = hi;
                 *reinterpret_cast<h8*>(db + (b_dst[i] ^ 16)) = lo;
             } else {
-                const bool ok = second_rec || ((tid + i * 256) & 7) < 4;
+                const bool ok = live && (second_rec || ((tid + i * 256) & 7) < 4);
                 *reinterpret_cast<f32x4*>(db + b_dst[i]) = ok ? rb[S][i] : z;
             }
         }
@@ -175,16 +185,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
     const int wm = wave >> 1, wn = wave & 1;
     int a_hi, b_hi;
     {
-        const int row = wm * 64 + l32, col = wn * 64 + l32;
+        const int row = wm * 32 * MR + l32, col = wn * 32 * MR + l32;
         a_hi = row * REC + ((half ^ swz(row)) << 3);
         b_hi = col * REC + ((half ^ swz(col)) << 3);
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[MR][MR];
 #pragma unroll
-    for (int mr = 0; mr < 2; ++mr)
+    for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-        for (int nr = 0; nr < 2; ++nr)
+        for (int nr = 0; nr < MR; ++nr)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.0f;
 
@@ -193,73 +203,53 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
         const _Float16* lb = lds_b + buf * B_BUF;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            h8 ah[2], al[2], bh[2], bl[2];
+            h8 ah[MR], al[MR], bh[MR], bl[MR];
 #pragma unroll
-            for (int mr = 0; mr < 2; ++mr) {
+            for (int mr = 0; mr < MR; ++mr) {
                 ah[mr] = *reinterpret_cast<const h8*>(la + a_hi + (kk * TM + mr * 32) * REC);
                 al[mr] = *reinterpret_cast<const h8*>(la + (a_hi ^ 16) + (kk * TM + mr * 32) * REC);
             }
 #pragma unroll
-            for (int nr = 0; nr < 2; ++nr) {
+            for (int nr = 0; nr < MR; ++nr) {
                 bh[nr] = *reinterpret_cast<const h8*>(lb + b_hi + (kk * NT + nr * 32) * REC);
                 bl[nr] = *reinterpret_cast<const h8*>(lb + (b_hi ^ 16) + (kk * NT + nr * 32) * REC);
             }
-#ifndef DM3D_MFMA_PASS_MAJOR
 #pragma unroll
-            for (int mr = 0; mr < 2; ++mr)
+            for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-                for (int nr = 0; nr < 2; ++nr) {
+                for (int nr = 0; nr < MR; ++nr) {
                     acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mr], bh[nr], acc[mr][nr], 0, 0, 0);
                     acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mr], bl[nr], acc[mr][nr], 0, 0, 0);
                     acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mr], bh[nr], acc[mr][nr], 0, 0, 0);
                 }
-#else
-            // pass-major over the 2 x 2 tiles: the three MFMAs into one accumulator are four issue slots (128 cycles) apart, more than a
-            // 32x32x16's result latency; back to back, the second and third wait for their predecessor (see dm3d_conv_h3v2.hip)
-#pragma unroll
-            for (int mr = 0; mr < 2; ++mr)
-#pragma unroll
-                for (int nr = 0; nr < 2; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mr], bh[nr], acc[mr][nr], 0, 0, 0);
-#pragma unroll
-            for (int mr = 0; mr < 2; ++mr)
-#pragma unroll
-                for (int nr = 0; nr < 2; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mr], bl[nr], acc[mr][nr], 0, 0, 0);
-#pragma unroll
-            for (int mr = 0; mr < 2; ++mr)
-#pragma unroll
-                for (int nr = 0; nr < 2; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mr], bh[nr], acc[mr][nr], 0, 0, 0);
-#endif
         }
     };
 
-    // Chunk c travels in register set c & 1 and LDS buffer c & 1; while chunk c is multiplied, c+1 and c+2 are in flight
-    // (a K = 256 GEMM has only 8 chunks of ~0.4 us each — one chunk of lookahead does not cover a memory round trip).
+    // Chunk c travels in register set c % NS and LDS buffer c & 1; while chunk c is multiplied, c+1 .. c+NS are in flight (a K = 256
+    // GEMM has only 8 chunks of ~0.4 us each — one chunk of lookahead does not cover a memory round trip).  The loop runs whole rounds of
+    // NS steps; loads past the last chunk re-read it (clamped, never behind a branch) and their steps publish zeros.
     const int nchunks = (p.k + KC - 1) / KC, last = nchunks - 1;
-    const std::integral_constant<int, 0> S0;
-    const std::integral_constant<int, 1> S1;
     auto clampk = [&](int c) { return (c < last ? c : last) * KC; };
-    fetch(S0, 0);
-    fetch(S1, clampk(1));
+    auto for_sets = [&](auto&& f) {                       // f(integral_constant<j>) for j = 0 .. NS-1: static register-set indices
+        f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{});
+        if constexpr (NS == 8) {
+            f(std::integral_constant<int, 2>{}); f(std::integral_constant<int, 3>{}); f(std::integral_constant<int, 4>{});
+            f(std::integral_constant<int, 5>{}); f(std::integral_constant<int, 6>{}); f(std::integral_constant<int, 7>{});
+        }
+    };
+    for_sets([&](auto J) { fetch(J, clampk(decltype(J)::value)); });
     __builtin_amdgcn_sched_barrier(0);
-    int it = 0;
-    for (; it + 1 < nchunks; it += 2) {
-        publish(S0, 0, it * KC + 16 < p.k);
-        __syncthreads();                        // chunk `it` visible; everyone has left chunk it-1 (other buffer)
-        fetch(S0, clampk(it + 2));
-        __builtin_amdgcn_sched_barrier(0);
-        compute(0);
-        __builtin_amdgcn_sched_barrier(0);
-        publish(S1, 1, (it + 1) * KC + 16 < p.k);
-        __syncthreads();
-        fetch(S1, clampk(it + 3));
-        __builtin_amdgcn_sched_barrier(0);
-        compute(1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (it < nchunks) {                         // odd tail: chunk `it` (even) sits in set 0
-        publish(S0, 0, it * KC + 16 < p.k);
-        __syncthreads();
-        compute(0);
+    for (int it = 0; it < nchunks; it += NS) {
+        for_sets([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            const int c = it + j;
+            publish(J, j & 1, c * KC + 16 < p.k, c < nchunks);
+            __syncthreads();                    // chunk c visible; everyone has left chunk c-1 (other buffer)
+            fetch(J, clampk(c + NS));
+            __builtin_amdgcn_sched_barrier(0);
+            compute(j & 1);
+            __builtin_amdgcn_sched_barrier(0);
+        });
     }
 
     // ---- epilogue: lane (l32, half) holds column n and rows acc_row(r, half) of each 32 x 32 tile.  Addresses are a uniform
@@ -276,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
     const float* Bm = p.bias + m0;
     const float* Bn = has_bn ? p.bias : dummy;
     const int r_mul = has_r ? 1 : 0, bn_mul = has_bn ? 1 : 0;
-    const int lrow = wm * 64 + 4 * half;                       // + mr*32 + (r&3) + 8*(r>>2)
+    const int lrow = wm * 32 * MR + 4 * half;                  // + mr*32 + (r&3) + 8*(r>>2)
     const int ldo = (int)p.ldo, ldr = (int)p.ldr;
     const float lo_bound = p.act == DM3D_ACT_RELU ? 0.0f : -3.4e38f;
     const int row_max = p.m - 1 - m0;                          // last valid row of this tile (partial tiles clamp their loads)
@@ -284,8 +274,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
     auto epilogue = [&](auto FULL_T, auto H2_T) {
         constexpr bool FULL = decltype(FULL_T)::value, H2 = decltype(H2_T)::value;
 #pragma unroll
-        for (int nr = 0; nr < 2; ++nr) {
-            const int n = n0 + wn * 64 + nr * 32 + l32;
+        for (int nr = 0; nr < MR; ++nr) {
+            const int n = n0 + wn * 32 * MR + nr * 32 + l32;
             const bool n_ok = FULL || n < p.n;
             const int nc = n_ok ? n : p.n - 1;
             const float bnv = Bn[nc * bn_mul];
@@ -294,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
             // exchange halves so that every lane stores one dword: even lanes the hi pair, odd lanes the lo pair
             const int ocol = H2 ? (n >> 4) * 64 + ((n >> 3) & 1) * 16 + ((n & 7) >> 1) * 4 + (n & 1) * 32 : n * 4;
 #pragma unroll
-            for (int mr = 0; mr < 2; ++mr) {
+            for (int mr = 0; mr < MR; ++mr) {
                 __builtin_amdgcn_sched_barrier(0);                   // one 32 x 32 block at a time: 16 loads in flight, not 64
                 float rv[16], v[16];
 #pragma unroll
@@ -421,12 +411,14 @@ static int fill_args(const dm3d_gemm_desc* d, GemmH3Args& a) {
     return DM3D_OK;
 }
 
-static int launch_group(GemmGroup& g, bool af, bool bf, hipStream_t st) {
-    constexpr size_t lds = (size_t)(2 * A_BUF + 2 * B_BUF) * sizeof(_Float16);     // 65536
+template <int MR>
+static int launch_group_mr(GemmGroup& g, bool af, bool bf, hipStream_t st) {
+    constexpr int TM = 64 * MR, NT = 64 * MR;
+    constexpr size_t lds = (size_t)(2 * 2 * TM * REC + 2 * 2 * NT * REC) * sizeof(_Float16);     // 65536 (MR 2) / 32768 (MR 1)
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[] = {reinterpret_cast<const void*>(&gemm_tn_h3<false, false>), reinterpret_cast<const void*>(&gemm_tn_h3<true, false>),
-                             reinterpret_cast<const void*>(&gemm_tn_h3<false, true>), reinterpret_cast<const void*>(&gemm_tn_h3<true, true>)};
+        const void* fns[] = {reinterpret_cast<const void*>(&gemm_tn_h3<false, false, MR>), reinterpret_cast<const void*>(&gemm_tn_h3<true, false, MR>),
+                             reinterpret_cast<const void*>(&gemm_tn_h3<false, true, MR>), reinterpret_cast<const void*>(&gemm_tn_h3<true, true, MR>)};
         for (const void* f : fns) DM3D_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
@@ -439,11 +431,23 @@ static int launch_group(GemmGroup& g, bool af, bool bf, hipStream_t st) {
     for (int i = g.count; i <= MAX_GROUP; ++i) g.tstart[i] = (int)t;
     DM3D_REQUIRE(t > 0 && t < (1l << 31), "gemm(h3): %ld tiles do not fit the grid", t);
     dim3 grid((unsigned)t);
-    if (af && bf) hipLaunchKernelGGL((gemm_tn_h3<true, true>), grid, dim3(256), lds, st, g);
-    else if (af) hipLaunchKernelGGL((gemm_tn_h3<true, false>), grid, dim3(256), lds, st, g);
-    else if (bf) hipLaunchKernelGGL((gemm_tn_h3<false, true>), grid, dim3(256), lds, st, g);
-    else hipLaunchKernelGGL((gemm_tn_h3<false, false>), grid, dim3(256), lds, st, g);
+    if (af && bf) hipLaunchKernelGGL((gemm_tn_h3<true, true, MR>), grid, dim3(256), lds, st, g);
+    else if (af) hipLaunchKernelGGL((gemm_tn_h3<true, false, MR>), grid, dim3(256), lds, st, g);
+    else if (bf) hipLaunchKernelGGL((gemm_tn_h3<false, true, MR>), grid, dim3(256), lds, st, g);
+    else hipLaunchKernelGGL((gemm_tn_h3<false, false, MR>), grid, dim3(256), lds, st, g);
     return dm3d_launch_check("gemm_tn_h3");
+}
+
+// Tile form of a launch: 64 x 64 tiles with eight chunks in flight when the 128 x 128 form would give fewer workgroups than
+// DM3D_GEMM_SMALL_TILES (default 512 = two per CU), else 128 x 128.  DM3D_GEMM_MR = 1 | 2 forces one form (A/B knob, read per call).
+static int launch_group(GemmGroup& g, bool af, bool bf, hipStream_t st) {
+    long t128 = 0;
+    for (int i = 0; i < g.count; ++i) t128 += (long)((g.prob[i].m + 127) / 128) * ((g.prob[i].n + 127) / 128) * g.prob[i].batch;
+    const char* e = getenv("DM3D_GEMM_MR");
+    const char* th = getenv("DM3D_GEMM_SMALL_TILES");
+    const int force = e ? atoi(e) : 0;
+    const bool small = force == 1 || (force != 2 && t128 < (th ? atol(th) : 512L));
+    return small ? launch_group_mr<1>(g, af, bf, st) : launch_group_mr<2>(g, af, bf, st);
 }
 
 int dm3d_gemm_h3_launch(const dm3d_gemm_desc* d, hipStream_t st) {

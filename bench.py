@@ -316,6 +316,37 @@ def main():
         if reason:
             roofline["traffic_note"] = reason
             log("roofline.traffic = null: " + reason)
+        # matrix-pipe occupancy (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), rocprofv3 --pmc passes over this same command,
+        # profiles/summarize_sq.py) and the in-kernel shader clock (tools/kernel_clock.py): attached, like traffic, only from committed
+        # summaries whose "# workload:" line records this workload / these kernel sources
+        roofline["mfma_busy_frac"], roofline["clock_ghz"] = None, None
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq.csv")), reverse=True):
+            lines = open(path).read().splitlines()
+            if not any(l.startswith("# workload: ") and l[len("# workload: "):].strip() == sig for l in lines):
+                continue
+            body = [l for l in lines if not l.startswith("#")]
+            rows = list(csv.DictReader(body))
+            hit = [r for r in rows if r["kernel"] == want]
+            if hit:
+                roofline["mfma_busy_frac"] = float(hit[0]["mfma_busy_frac"])
+                roofline["mfma_busy_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs) of " + want + ", whole launch incl. prologue / "
+                                              "epilogue, profiled passes (" + os.path.basename(path) + "); valu_per_mfma " + hit[0]["valu_per_mfma"] +
+                                              ", lds_conflict " + hit[0]["lds_conflict"] + ", wait_frac " + hit[0]["wait_frac"] + ", stall_frac " + hit[0]["stall_frac"])
+                break
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_clock.csv")), reverse=True):
+            lines = open(path).read().splitlines()
+            if not any(l.startswith("# workload: ") and l.strip().endswith("csrc=" + csrc_digest()) for l in lines):
+                continue
+            rows = list(csv.DictReader(l for l in lines if not l.startswith("#")))
+            if rows:
+                vals = sorted(float(r["clock_ghz_median"]) for r in rows)
+                roofline["clock_ghz"] = vals[len(vals) // 2]
+                roofline["clock_note"] = ("in-kernel shader clock of the k3 conv kernel under sustained load on random data (median of " +
+                                          ", ".join(f'{r["shape"]}: {r["clock_ghz_median"]}' for r in rows) + " GHz; matrix-pipe duty inside the chunk loop " +
+                                          ", ".join(r["mfma_duty_in_loop"] for r in rows) + "; " + os.path.basename(path) +
+                                          "); the same instruction stream on all-zero operands holds ~2.39 GHz: the kernel is bound by the chip's power "
+                                          "management, not by its instruction schedule (DESIGN.md section 4)")
+                break
 
     # ---- the same K steps in exact-float32 arithmetic (v_mfma_f32_32x32x2_f32), so that number is timed in this run too ------
     fp32_mode = None

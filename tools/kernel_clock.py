@@ -31,6 +31,7 @@ def sustained(fn):
     return e0.elapsed_time(e1) / 10
 
 
+rows_out = []
 if what == "conv":
     st = torch.zeros(4096 * 32, dtype=torch.int64, device=dev)
     raw.dm3d_debug_set_stamps_conv(C.c_void_p(st.data_ptr()))
@@ -56,6 +57,7 @@ if what == "conv":
         print(f"{name}: {ms:.3f} ms {fl / ms / 1e9:.0f} TF/s algorithmic | in-kernel clock median {ghz.median():.3f} GHz (p10 {ghz.quantile(0.1):.3f}, p90 {ghz.quantile(0.9):.3f}) "
               f"| chunk loop {dt.median():.0f} ticks = {dr.median() / 100:.1f} us, MFMA duty in the loop {mfma_cycles / dt.median():.3f} "
               f"| {s.shape[0]} workgroups stamped; whole workgroup {((s[:, 29] - s[:, 0])[s[:, 29] > 0]).median() if (s[:, 29] > 0).any() else 0:.0f} ticks", flush=True)
+        rows_out.append((name, ms, fl / ms / 1e9, float(ghz.median()), float(ghz.quantile(0.1)), float(ghz.quantile(0.9)), mfma_cycles / float(dt.median())))
     raw.dm3d_debug_set_stamps_conv(C.c_void_p(0))
 else:
     st = torch.zeros(2048 * 16, dtype=torch.int64, device=dev)
@@ -75,3 +77,15 @@ else:
         print(f"gemm m={m} n={n} k={k}: {ms * 1e3:.1f} us {2.0 * m * n * k / ms / 1e9:.0f} TF/s | in-kernel clock median {ghz.median():.3f} GHz "
               f"(p10 {ghz.quantile(0.1):.3f}, p90 {ghz.quantile(0.9):.3f}); K loop {dt.median():.0f} ticks", flush=True)
     raw.dm3d_debug_set_stamps(C.c_void_p(0))
+
+if os.environ.get("CLOCK_OUT") and rows_out:
+    # "# workload:" carries the digest of the kernel sources: bench.py attaches roofline.clock_ghz only from a file measured on them
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    with open(os.environ["CLOCK_OUT"], "w") as f:
+        f.write("# in-kernel shader clock = delta(s_memtime) / delta(s_memrealtime) x 100 MHz around the chunk loop, median over workgroups, after "
+                f"{SECONDS:.0f} s of back-to-back launches on {'ZERO' if os.environ.get('CLOCK_ZEROS') == '1' else 'random'} data (tools/kernel_clock.py conv, B=32, k3 conv with norm+SiLU prologue)\n")
+        f.write(f"# workload: kernel_clock conv csrc={bench.csrc_digest()}\n")
+        f.write("shape,ms,algorithmic_tflops,clock_ghz_median,clock_ghz_p10,clock_ghz_p90,mfma_duty_in_loop\n")
+        for r in rows_out:
+            f.write(f'"{r[0]}",{r[1]:.4f},{r[2]:.1f},{r[3]:.3f},{r[4]:.3f},{r[5]:.3f},{r[6]:.3f}\n')

@@ -23,4 +23,16 @@ done
 python3 profiles/summarize_pmc.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/${tag}_pmc_hbm.csv \
   "$tag: rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph (B=32, 32^3x8ch); KB per launch" \
   "batch=32 size=32 channels=8 norm=batch precision=$prec csrc=$(python3 bench.py --print-csrc-digest)" | head -8
-rm -rf $out/prof_stats $out/prof_FETCH_SIZE $out/prof_WRITE_SIZE $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
+# 4. SQ counters of the same command (two passes, 8 SQ slots each) -> <tag>_sq.csv (profiles/summarize_sq.py)
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/prof_sqA -o run -- python3 bench.py --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-h3f8-mode --no-full-chain --no-graph > $out/prof_sqA.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/prof_sqB -o run -- python3 bench.py --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-h3f8-mode --no-full-chain --no-graph > $out/prof_sqB.log 2>&1
+python3 profiles/summarize_sq.py $out/${tag}_sq.csv \
+  "$tag: rocprofv3 --pmc <8 SQ counters> GRBM_GUI_ACTIVE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph (B=32, 32^3x8ch; two passes); averages per launch" \
+  "batch=32 size=32 channels=8 norm=batch precision=$prec csrc=$(python3 bench.py --print-csrc-digest)" $out/prof_sqA $out/prof_sqB | head -6 | cut -c1-400
+# 5. in-kernel clock of the conv kernel (diagnostic library variants/cck.so: python3 tools/mk_stamp_variants.py) -> <tag>_clock.csv
+if [ -f 3d-condtional-stable-diffusion_amd/csrc/variants/cck.so ]; then
+  CLOCK_OUT=$out/${tag}_clock.csv DM3D_LIB=$PWD/3d-condtional-stable-diffusion_amd/csrc/variants/cck.so python3 tools/kernel_clock.py conv > $out/${tag}_clock.log 2>&1 || tail -5 $out/${tag}_clock.log
+  CLOCK_ZEROS=1 CLOCK_OUT=$out/${tag}_clock_zeros.txt DM3D_LIB=$PWD/3d-condtional-stable-diffusion_amd/csrc/variants/cck.so python3 tools/kernel_clock.py conv > $out/${tag}_clock_zeros.log 2>&1 || true
+  cat $out/${tag}_clock.csv
+fi
+rm -rf $out/prof_stats $out/prof_FETCH_SIZE $out/prof_WRITE_SIZE $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/prof_sqA $out/prof_sqB
