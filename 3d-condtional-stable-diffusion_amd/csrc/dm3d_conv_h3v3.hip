@@ -359,6 +359,27 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v3(const ConvArgs p
             // ---- pass C: ah(pp).bl(pp); requests bh(pp+1) (pair pp+1 is visible since the barrier above)
             read_bh(ws1);
             if (pp >= CV0 && pp < CV0 + NREQ) {                          // the next chunk's staging registers
+                // Their requests went out in pass B of pair pp - CV0.  k3: that is >= 8 pairs back and the barrier heads since have waited
+                // past them.  The 4-pair parity form converts one pair after the request: say so with a counted wait hipcc's pass sees
+                // (newer: the DMA pieces and staging requests of the pairs in between), or it guards the registers with vmcnt(0).
+                if constexpr (CV0 < 3) {
+                    int newer = 0;
+#pragma unroll
+                    for (int k_ = pp - CV0 + 1; k_ <= pp; ++k_) newer += WSLOT + halo_ops(k_);
+                    switch (newer) {
+                    case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;   // vmcnt(n), expcnt 7, lgkmcnt 15: n | 0x0F70
+                    case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
+                    case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
+                    case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
+                    case 5: __builtin_amdgcn_s_waitcnt(0x0F75); break;
+                    case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
+                    case 7: __builtin_amdgcn_s_waitcnt(0x0F77); break;
+                    case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break;
+                    case 9: __builtin_amdgcn_s_waitcnt(0x0F79); break;
+                    case 10: __builtin_amdgcn_s_waitcnt(0x0F7A); break;
+                    default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+                    }
+                }
 #pragma unroll
                 for (int j = (pp - CV0) * SPP; j < (pp - CV0 + 1) * SPP && j < NSLOT; ++j) convert_slot(j);
             }
