@@ -7,8 +7,8 @@ from dm3d_amd import ops, _lib
 var, vals = sys.argv[1], sys.argv[2:]
 rounds = 5
 if vals and vals[-1].startswith("r="): rounds = int(vals.pop()[2:])
-dev = torch.device("cuda:0"); B = 32
-CASES = [("32^3 64->64 pro+res", 32, 64, 64, 1), ("32^3 96->64 pro", 32, 96, 64, 0), ("32^3 192->64 pro", 32, 192, 64, 0),
+dev = torch.device("cuda:0"); B = int(os.environ.get("AB_BATCH", "32"))
+CASES = [("8^3 256->256 pro+res", 8, 256, 256, 1), ("8^3 512->256 pro", 8, 512, 256, 0), ("16^3 128->128 pro", 16, 128, 128, 0)] if os.environ.get("AB_SMALL") == "1" else [("32^3 64->64 pro+res", 32, 64, 64, 1), ("32^3 96->64 pro", 32, 96, 64, 0), ("32^3 192->64 pro", 32, 192, 64, 0),
          ("16^3 128->128 pro+res", 16, 128, 128, 1), ("16^3 384->128 pro", 16, 384, 128, 0)]
 for name, e, cin, cout, res in CASES:
     x = torch.randn(B, e, e, e, cin, device=dev)
