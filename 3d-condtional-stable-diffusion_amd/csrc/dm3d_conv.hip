@@ -368,7 +368,7 @@ extern "C" int32_t dm3d_conv_weight_layout(int32_t ksize, int32_t stride, int32_
     static const bool pair_off = [] { const char* e = getenv("DM3D_CONV_PAIR"); return e && e[0] == '0'; }();   // A/B switch
     if (pair_off) return DM3D_WL_TAP;
     if (upsample || transpose) return DM3D_WL_PAIR;
-    return (ksize == 3 && stride == 1 && cout > 32) ? DM3D_WL_PAIR : DM3D_WL_TAP;
+    return (ksize == 3 && stride == 1) ? DM3D_WL_PAIR : DM3D_WL_TAP;     // (round 3: also Cout <= 32, the narrow column forms of the 16x16x32 kernel)
 }
 
 extern "C" int64_t dm3d_packed_weight_h3p_bytes(int32_t taps, int32_t cin, int32_t cout) {

@@ -184,8 +184,9 @@ __device__ __forceinline__ void skip_phase(const ConvArgs& p, _Float16* smem, f3
 
 }
 
-template <int TD>
-__device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][4], const Brick& br) {
+// NCT = 16-column tiles per wave the caller computed (4: a whole 64-column tile; 1 / 2: the narrow forms for Cout <= 16 / 32)
+template <int TD, int NCT = 4>
+__device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT], const Brick& br) {
     constexpr int TH = 8, TW = 8, NT = 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = lane & 15, g4 = lane >> 4;
@@ -220,17 +221,17 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][4],
         const bool b0 = (row & 1) != 0, b1 = (row & 2) != 0;
         auto xor1 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)); };
         auto xor2 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)); };
-        f32x4 rv4[4][4];
+        f32x4 rv4[NCT][4];
         if (resz) {                                     // all residual pieces requested before the first one is used
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < NCT; ++ni)
 #pragma unroll
                 for (int pi = 0; pi < 4; ++pi)
                     rv4[ni][pi] = *reinterpret_cast<const f32x4*>(resz + (((oy0 + 4 * (pi >> 1) + k) * p.os + ooy) * p.fw
                                                                           + (ox0 + 4 * (pi & 1) + dxl) * p.os + oox) * p.cout + n0 + ni * 16 + c4);
         }
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int ni = 0; ni < NCT; ++ni) {
             const int n = n0 + ni * 16 + c4;             // first of this lane's four channels
             f32x4 add = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.vec) {
@@ -287,10 +288,10 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][4],
     if (full) {
         // full brick, scalar form (split-K launches add their halves atomically; -DDM3D_EPILOGUE_SCALAR: the A/B arm of the form above):
         // all 64 residual values of this lane are requested before the first one is used
-        float rv[4][4][4];
+        float rv[NCT][4][4];
         if (resz) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < NCT; ++ni)
 #pragma unroll
                 for (int pi = 0; pi < 4; ++pi)
 #pragma unroll
@@ -299,7 +300,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][4],
                                              + ((ox0 + 4 * (pi & 1) + dxl) * p.os + oox) * p.cout + n0 + ni * 16 + row + r * ystep];
         }
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int ni = 0; ni < NCT; ++ni) {
             const int n = n0 + ni * 16 + row;
             float add = p.bias ? p.bias[n] : 0.0f;
             if (p.vec) add += p.vec[(size_t)vrow * p.vec_ld + n];
@@ -337,7 +338,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][4],
         return;
     }
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
+    for (int ni = 0; ni < NCT; ++ni) {
         const int n = n0 + ni * 16 + row;
         const bool n_ok = n < p.cout;
         const int nc = n_ok ? n : p.cout - 1;

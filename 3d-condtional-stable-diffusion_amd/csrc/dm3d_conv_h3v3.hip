@@ -48,7 +48,9 @@ namespace {
 
 // MODE 0: float32 input as is; 1: float32 input through the fused norm + SiLU prologue; 2: x1 already activated and split (DM3D_FMT_H2)
 // TD = z-slices per brick = waves per workgroup: 4 (256 threads, two workgroups per CU) or 8 (512 threads, one per CU)
-template <int KS, int MODE, int TD>
+// NCT = 16-column tiles per wave: 4 = the whole 64-column tile of the packed image; 1 / 2 = only its first 16 / 32 columns (conv_out 64 -> 8,
+// conv_in 8 -> 32: round 2 ran them on the 32-column 32x32x16 kernel, 4x / 1x the needed MFMA work at 77 / 117 TFLOP/s algorithmic)
+template <int KS, int MODE, int TD, int NCT = 4>
 __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v3(const ConvArgs p) {
     constexpr int TH = 8, TW = 8, CK = 16, NT = 64, NTHR = TD * 64;
     constexpr int HD = TD - 1 + KS, HH = TH - 1 + KS, HW = TW - 1 + KS, HWP = 12;
@@ -134,11 +136,11 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v3(const ConvArgs p
     const int b_pos = pi_pos(row);
     const int b_hi = (half * NT + b_pos) * REC + ((q ^ swz(b_pos)) << 3);
 
-    f32x4v acc[4][4];
+    f32x4v acc[4][NCT];
 #pragma unroll
     for (int pi = 0; pi < 4; ++pi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[pi][ni] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < NCT; ++ni) acc[pi][ni] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     // weights go global -> LDS by LDS-DMA: the packed image IS the LDS image, pair pq of this (column tile) is a linear 8 KB copy; wave w
     // moves the 1 KB pieces w, w + TD.  Ring slot = running pair number mod 4 (NP mod 4 = 2 for k3: the phase differs from chunk to chunk).
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v3(const ConvArgs p
 
     // ---- operand reads.  Pair pp of a chunk = taps 2pp, 2pp + 1 (the lane half picks the tap; the pad tap re-reads the last real tap's
     // voxels against zero weights); patch (py, px) of the wave's slice sits 48 * py + 4 * px records further.
-    h8 ah[4], al[4], bh[4], bl[4];
+    h8 ah[4], al[4], bh[NCT], bl[NCT];
     auto a_offs = [&](const int pp, int& o0, int& o1) {
         const int ta = 2 * pp, tb = ta + 1;
         const int tac = ta < TAPS ? ta : TAPS - 1, tbc = tb < TAPS ? tb : TAPS - 1;
@@ -289,15 +291,19 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v3(const ConvArgs p
     };
     auto read_bh = [&](int slot) {
         const unsigned wa = w_addr + (slot * WPAIR + b_hi) * 2;
-        DM3D_DSR(bh[0], wa, 0); DM3D_DSR(bh[1], wa, 16 * REC * 2); DM3D_DSR(bh[2], wa, 32 * REC * 2); DM3D_DSR(bh[3], wa, 48 * REC * 2);
+        DM3D_DSR(bh[0], wa, 0);
+        if constexpr (NCT >= 2) DM3D_DSR(bh[1], wa, 16 * REC * 2);
+        if constexpr (NCT == 4) { DM3D_DSR(bh[2], wa, 32 * REC * 2); DM3D_DSR(bh[3], wa, 48 * REC * 2); }
     };
     auto read_bl = [&](int slot) {
         const unsigned wa = w_addr + (slot * WPAIR + (b_hi ^ 16)) * 2;
-        DM3D_DSR(bl[0], wa, 0); DM3D_DSR(bl[1], wa, 16 * REC * 2); DM3D_DSR(bl[2], wa, 32 * REC * 2); DM3D_DSR(bl[3], wa, 48 * REC * 2);
+        DM3D_DSR(bl[0], wa, 0);
+        if constexpr (NCT >= 2) DM3D_DSR(bl[1], wa, 16 * REC * 2);
+        if constexpr (NCT == 4) { DM3D_DSR(bl[2], wa, 32 * REC * 2); DM3D_DSR(bl[3], wa, 48 * REC * 2); }
     };
 #define DM3D_PASS(A, B)                                                                                          \
     _Pragma("unroll") for (int pi_ = 0; pi_ < 4; ++pi_)                                                        \
-        _Pragma("unroll") for (int ni_ = 0; ni_ < 4; ++ni_)                                                    \
+        _Pragma("unroll") for (int ni_ = 0; ni_ < NCT; ++ni_)                                                  \
             acc[pi_][ni_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[pi_], B[ni_], acc[pi_][ni_], 0, 0, 0)
 
     read_al(0);
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v3(const ConvArgs p
             read_ah(pp);
             read_bl(ws);
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");           // al, bh (requested a pass or more ago) are back; the 8 reads above may be out
+            asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(4 + NCT) : "memory");   // al, bh (requested a pass or more ago) are back; the 4 + NCT reads above may be out
             __builtin_amdgcn_sched_barrier(0);
             DM3D_PASS(al, bh);
             __builtin_amdgcn_sched_barrier(0);
@@ -403,35 +409,43 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v3(const ConvArgs p
     asm volatile("" ::: "memory");
 
     const Brick br = {b, oz0, oy0, ox0, ooz, ooy, oox, ntile, khalf};
-    if constexpr (KS == 3) {                        // (the launcher admits a skip conv behind k3 / stride 1 only)
+    if constexpr (KS == 3 && NCT == 4) {            // (the launcher admits a skip conv behind k3 / stride 1 / Cout > 32 only)
         // (the launcher sizes the dynamic LDS for whichever of the two phases needs more: v3_lds_halfs)
         skip_phase<TD>(p, smem_v3, acc, br);
     }
-    epilogue<TD>(p, acc, br);
+    epilogue<TD, NCT>(p, acc, br);
     STAMP(29);
 }
 
-template <int KS, int MODE, int TD>
+template <int KS, int MODE, int TD, int NCT = 4>
 int launch_v3(ConvArgs& a, hipStream_t st) {
     constexpr int HREC = (TD - 1 + KS) * (7 + KS) * 12;
-    constexpr int main_halfs = HREC * REC + 4 * 2 * 64 * REC, skip_halfs = KS == 3 ? skip_lds_halfs<TD>() : 0;
+    constexpr int main_halfs = HREC * REC + 4 * 2 * 64 * REC, skip_halfs = (KS == 3 && NCT == 4) ? skip_lds_halfs<TD>() : 0;
     constexpr size_t lds = (size_t)(main_halfs > skip_halfs ? main_halfs : skip_halfs) * sizeof(_Float16);
     static_assert((TD == 4 ? 2 : 1) * lds <= 160 * 1024, "workgroups per CU x LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3v3<KS, MODE, TD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3v3<KS, MODE, TD, NCT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     H3v2Launch L;
     if (int rc = dm3d_h3v2_pre_launch(a, TD, false, L, st)) return rc;
     dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64 * a.ksplit), a.parity ? 8u : 1u);
-    hipLaunchKernelGGL((conv3d_igemm_h3v3<KS, MODE, TD>), grid, dim3(TD * 64), lds, st, L.k);
+    hipLaunchKernelGGL((conv3d_igemm_h3v3<KS, MODE, TD, NCT>), grid, dim3(TD * 64), lds, st, L.k);
     if (int rc = dm3d_launch_check("conv3d_igemm_h3v3")) return rc;
     return dm3d_h3v2_post_launch(a, L, st);
 }
 
 template <int KS, int MODE>
 int launch_td(ConvArgs& a, hipStream_t st) {
+    if constexpr (KS == 3 && MODE != 2) {           // the narrow column forms: k3 convs with few output channels
+        if (a.cout <= 32) {
+            DM3D_REQUIRE(a.s_npairs == 0 && !a.out_h2, "conv: the fused skip conv / hand-off output need cout > 32");
+            // (4-slice bricks: with 8-slice bricks conv_out / conv_in were 4 % / 11 % slower — these launches are bound by staging the input,
+            // 12 or 24 MFMAs per pair against the same halo, not by the matrix pipe: profiles/r03_layers_h3.log)
+            return a.cout <= 16 ? launch_v3<KS, MODE, 4, 1>(a, st) : launch_v3<KS, MODE, 4, 2>(a, st);
+        }
+    }
     return dm3d_conv_h3v3_td(a) == 8 ? launch_v3<KS, MODE, 8>(a, st) : launch_v3<KS, MODE, 4>(a, st);
 }
 

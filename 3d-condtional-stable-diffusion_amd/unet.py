@@ -212,7 +212,7 @@ class UNet:
             if blk.kind == "res":
                 P[f"{n}.conv1"] = self._pack(s[f"{n}.conv1.kernel"], s[f"{n}.conv1.bias"], conv=True)
                 if (f"{n}.skip.kernel" in s and self.precision == "h3" and self.fuse_skip
-                        and lib().dm3d_conv_weight_layout(3, 1, 0, 0, blk.cout) == _lib.WL_PAIR):      # (the Cout <= 32 kernel has no tail phase)
+                        and blk.cout > 32 and lib().dm3d_conv_weight_layout(3, 1, 0, 0, blk.cout) == _lib.WL_PAIR):      # (the narrow column forms have no tail phase)
                     # the 1x1 skip conv rides in conv2's launch (dm3d_conv_desc.skip_*): both images share one exponent, the
                     # skip bias joins conv2's
                     e = _h3_exponent(s[f"{n}.conv2.kernel"], s[f"{n}.skip.kernel"])

@@ -251,7 +251,7 @@ def test_conv3d_weight_layout_is_checked(dev):
     assert lib.dm3d_conv_weight_layout(3, 1, 0, 0, 64) in (_lib.WL_TAP, _lib.WL_PAIR)
     assert lib.dm3d_conv_weight_layout(3, 2, 0, 0, 64) == _lib.WL_TAP
     assert lib.dm3d_conv_weight_layout(1, 1, 0, 0, 64) == _lib.WL_TAP
-    assert lib.dm3d_conv_weight_layout(3, 1, 0, 0, 8) == _lib.WL_TAP
+    assert lib.dm3d_conv_weight_layout(3, 1, 0, 0, 8) in (_lib.WL_TAP, _lib.WL_PAIR)      # round 3: the narrow column forms of the 16x16x32 kernel
     x = torch.randn(1, 8, 8, 8, 16, device=dev)
     k = torch.randn(3, 3, 3, 16, 64, device=dev)
     wpk, w_exp = ops.pack_weights_h3(k, stride=2)            # stride-2 image ...
