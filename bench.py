@@ -12,7 +12,7 @@ Contract (one JSON line from rank 0):  python bench.py --gpus N --steps K --warm
     `python bench.py --gpus N` it launches the N ranks itself as fresh child processes — before this process has touched the
     GPU — relays rank 0's JSON line and exits non-zero if any rank fails.
   * roofline: the dominant kernel is the k3/stride-1 Conv3d implicit GEMM with the norm+SiLU prologue in its 8-slice form,
-    conv3d_igemm_h3v3<3, 1, 8> (10 launches/step: the large-Cin convs of the 32^3 and 16^3 levels, ~39 % of the step; the 4-slice
+    conv3d_igemm_h3v3<3, 1, 8, 4> (10 launches/step: the large-Cin convs of the 32^3 and 16^3 levels, ~39 % of the step; the 4-slice
     form, the H2-input twin, conv_in/conv_out and the two UpSample convs are other instantiations, listed under per_kernel_kind);
     achieved = algorithmic FLOPs (2*27*Cin*Cout*B*Dout^3 per launch, plus those of a fused 1x1 skip conv) /
     HIP-event time of those launches, measured live on the launch stream; peak = the dense MFMA peak of the datatype the
@@ -264,11 +264,11 @@ def main():
                      "stream (float8 e4m3 copies of the halves), fp32 accumulate)")
             peak, passes = PEAK_F16_MFMA_TFLOPS, 1.5
         elif args.precision in ("h3", "h3f8"):
-            kname = ("conv3d_igemm_h3v3<3, 1, 8> (k3 stride-1 Conv3d with the fused norm+SiLU prologue, 8-slice bricks, free-running "
+            kname = ("conv3d_igemm_h3v3<3, 1, 8, 4> (k3 stride-1 Conv3d with the fused norm+SiLU prologue, 8-slice bricks, free-running "
                      "software-pipelined waves; float16 hi+lo split, 3 x v_mfma_f32_16x16x32_f16 per algorithmic product, fp32 accumulate; "
-                     "its 4-slice form <3, 1, 4> is listed as conv_k3s1_td4, the MODE-2 twin that reads pre-activated DM3D_FMT_H2 input as "
+                     "its 4-slice form <3, 1, 4, 4> is listed as conv_k3s1_td4, the MODE-2 twin that reads pre-activated DM3D_FMT_H2 input as "
                      "conv_k3s1_h2in)") if wide else (
-                     "conv3d_igemm_h3v3<3, 1, 4> (k3 stride-1 Conv3d with the fused norm+SiLU prologue, 4-slice bricks: this batch is "
+                     "conv3d_igemm_h3v3<3, 1, 4, 4> (k3 stride-1 Conv3d with the fused norm+SiLU prologue, 4-slice bricks: this batch is "
                      "too small for the 8-slice form; float16 hi+lo split, 3 x v_mfma_f32_16x16x32_f16, fp32 accumulate)")
             peak, passes = PEAK_F16_MFMA_TFLOPS, 3
         else:
@@ -294,7 +294,7 @@ def main():
         import csv
         import glob
         want = "conv3d_igemm_h3f8<3, 1>" if "conv_f8" in per_kind else \
-            ("conv3d_igemm_h3v3<3, 1, 8>" if "conv_k3s1" in per_kind else "conv3d_igemm_h3v3<3, 1, 4>") if args.precision != "fp32" \
+            ("conv3d_igemm_h3v3<3, 1, 8, 4>" if "conv_k3s1" in per_kind else "conv3d_igemm_h3v3<3, 1, 4, 4>") if args.precision != "fp32" \
             else "conv3d_igemm_f32<4, 8, 8, 1, 3, 4, 1>"
         sig = f"batch={B} size={S} channels={Cc} norm={args.norm} precision={args.precision} csrc={csrc_digest()}"
         reason = "no profiles/*_pmc_hbm.csv records this workload and these kernel sources: " + sig
