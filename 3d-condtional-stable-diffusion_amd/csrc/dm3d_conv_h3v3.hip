@@ -466,11 +466,9 @@ int dm3d_conv_h3v3_td(const ConvArgs& a) {
     return wgs >= (w ? atol(w) : 512L) ? 8 : 4;
 }
 
-// The free-running form serves every launch the v2 kernel serves except the float8 cross-term arithmetic (precision "h3f8").
-// DM3D_CONV_V3 (A/B knob, read per call): 1 (default) on, 0 off (the v2 kernel).
+// The free-running form serves every DM3D_WL_PAIR launch except the float8 cross-term arithmetic (precision "h3f8": dm3d_conv_h3v2.hip).
 bool dm3d_conv_h3v3_serves(const ConvArgs& a, int which) {
-    const char* e = getenv("DM3D_CONV_V3");
-    if (e && e[0] == '0') return false;
+    (void)which;
     return !dm3d_conv_h3v2_f8(a);
 }
 

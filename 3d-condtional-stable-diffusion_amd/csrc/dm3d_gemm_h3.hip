@@ -439,14 +439,14 @@ static int launch_group_mr(GemmGroup& g, bool af, bool bf, hipStream_t st) {
 }
 
 // Tile form of a launch: 64 x 64 tiles with eight chunks in flight when the 128 x 128 form would give fewer workgroups than
-// DM3D_GEMM_SMALL_TILES (default 512 = two per CU), else 128 x 128.  DM3D_GEMM_MR = 1 | 2 forces one form (A/B knob, read per call).
+// DM3D_GEMM_SMALL_TILES (default 256 = one per CU: at 256 tiles — the proj GEMMs at B = 32 — the 128 x 128 form measured faster, 1.25 vs 1.35 ms per step), else 128 x 128.  DM3D_GEMM_MR = 1 | 2 forces one form (A/B knob, read per call).
 static int launch_group(GemmGroup& g, bool af, bool bf, hipStream_t st) {
     long t128 = 0;
     for (int i = 0; i < g.count; ++i) t128 += (long)((g.prob[i].m + 127) / 128) * ((g.prob[i].n + 127) / 128) * g.prob[i].batch;
     const char* e = getenv("DM3D_GEMM_MR");
     const char* th = getenv("DM3D_GEMM_SMALL_TILES");
     const int force = e ? atoi(e) : 0;
-    const bool small = force == 1 || (force != 2 && t128 < (th ? atol(th) : 512L));
+    const bool small = force == 1 || (force != 2 && t128 < (th ? atol(th) : 256L));
     return small ? launch_group_mr<1>(g, af, bf, st) : launch_group_mr<2>(g, af, bf, st);
 }
 

@@ -1,5 +1,5 @@
 """Interleaved A/B of launch-time knobs (environment variables the library reads per call) on k3 conv shapes, one process, one device
-(cdna_hip_programming.md rule 24).  usage: python tools/env_ab.py DM3D_CONV_RING 3 4 5 [rounds]"""
+(cdna_hip_programming.md rule 24).  usage: python tools/env_ab.py DM3D_CONV_V3_TD 4 8 [r=rounds]   (AB_BATCH=n, AB_SMALL=1 select the shapes)"""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -14,7 +14,7 @@ from dm3d_amd import ops, _lib
 dev = torch.device("cuda:0")
 raw = C.CDLL(_lib.LIB_PATH)
 what = sys.argv[1] if len(sys.argv) > 1 else "conv"
-B = 32
+B = int(os.environ.get("CLOCK_BATCH", "32"))
 SECONDS = float(os.environ.get("CLOCK_SECONDS", "2.0"))
 
 
