@@ -23,6 +23,19 @@
 #include <cstdlib>
 #include <type_traits>
 
+// Diagnostic build only (-DDM3D_GEMM_STAMPS, tools/mk_stamp_variants.py -> variants/gst.so; the product library carries none of it): thread 0 of
+// the first 2048 workgroups writes s_memtime at phase boundaries (0 entry, 1 first fetch, 2.. chunk steps, 10 epilogue, 11 end) and
+// s_memrealtime beside stamps 1 and 10 into a buffer of its own (tools/gemm_stamps.py, tools/kernel_clock.py gemm).
+#ifdef DM3D_GEMM_STAMPS
+__device__ unsigned long long* g_dbg_stamps = nullptr;
+extern "C" int dm3d_debug_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_stamps), &p, sizeof(p)); }
+#define GSTAMP(i) do { if (g_dbg_stamps && threadIdx.x == 0 && blockIdx.x < 2048) { g_dbg_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if ((i) == 1) g_dbg_stamps[blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime(); \
+    if ((i) == 10) g_dbg_stamps[blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 struct GemmH3Args {
@@ -57,6 +70,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
     constexpr int NS = MR == 2 ? 2 : 8;                           // register sets = chunks in flight behind the one being multiplied
     // problem selection (uniform): flat tile index -> (problem, batch, tile_m, tile_n); m tiles vary fastest so that
     // consecutive workgroups share the B tile (the weight operand) through L2
+    GSTAMP(0);
     int which = 0;
 #pragma unroll
     for (int i = 1; i < MAX_GROUP; ++i) which += (i < grp.count && (int)blockIdx.x >= grp.tstart[i]) ? 1 : 0;
@@ -237,6 +251,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
             f(std::integral_constant<int, 5>{}); f(std::integral_constant<int, 6>{}); f(std::integral_constant<int, 7>{});
         }
     };
+    GSTAMP(1);
     for_sets([&](auto J) { fetch(J, clampk(decltype(J)::value)); });
     __builtin_amdgcn_sched_barrier(0);
     for (int it = 0; it < nchunks; it += NS) {
@@ -245,6 +260,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
             const int c = it + j;
             publish(J, j & 1, c * KC + 16 < p.k, c < nchunks);
             __syncthreads();                    // chunk c visible; everyone has left chunk c-1 (other buffer)
+            if (c < 8) GSTAMP(2 + c);
             fetch(J, clampk(c + NS));
             __builtin_amdgcn_sched_barrier(0);
             compute(j & 1);
@@ -257,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
     // latency: every option is a uniform select (no per-element branch — hipcc waits vmcnt(0) behind each load that sits under
     // one), the residual / row-bias loads of a 64-column half are all issued before the first is used (absent operands read
     // element 0 of A instead and are discarded), and the H2 pair exchange is one DPP move.
+    GSTAMP(10);
     const bool full = m0 + TM <= p.m && n0 + NT <= p.n;
     char* O = static_cast<char*>(p.out) + ((size_t)bz * p.so + (size_t)m0 * p.ldo) * 4;
     const bool has_r = p.res != nullptr, has_r2 = p.res2 != nullptr, has_bm = p.bias && p.bias_m, has_bn = p.bias && !p.bias_m;
@@ -356,6 +373,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
         if (p.out_h2) epilogue(no, yes); else epilogue(no, no);
     }
     if (p.range_flag && amax > p.range_limit) *p.range_flag = 1;
+    GSTAMP(11);
 }
 
 // float32 [rows][k] (ld_src) -> DM3D_FMT_H2 [rows][ld_dst], scaled by 2^exp2, zero filled up to round_up(k, 16)

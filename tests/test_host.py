@@ -68,7 +68,7 @@ int main(void) {
 
 
 def test_stamp_variant_tool_still_patches_the_kernels(built_library):
-    """tools/mk_stamp_variants.py builds the diagnostic libraries (conv: -DDM3D_CLOCK_STAMPS; GEMM: exact-match source patches, each asserted)."""
+    """tools/mk_stamp_variants.py builds the diagnostic libraries (conv: -DDM3D_CLOCK_STAMPS; GEMM: -DDM3D_GEMM_STAMPS; no source patching)."""
     import shutil
     import sys
     vdir = os.path.join(os.path.dirname(built_library), "variants")
