@@ -259,3 +259,19 @@ def test_weight_broadcast_and_sharded_generate_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "ok 0" in outs[0] and "ok 1" in outs[1]
+
+
+def test_bench_self_launch_fails_fast_when_a_rank_dies(built_library):
+    """`python bench.py --gpus 2` started plainly supervises its ranks: on a box without a GPU every rank dies in require_device(); the
+    parent must notice, terminate what is left and return non-zero at once instead of waiting out a collective timeout."""
+    import time
+    if torch.cuda.is_available():
+        pytest.skip("needs a box where the ranks fail: no GPU")
+    env = dict(os.environ, DM3D_BENCH_NO_RETRY="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "ranks failed" in r.stderr, r.stderr[-2000:]
+    assert r.stdout.strip() == "" and time.time() - t0 < 120
