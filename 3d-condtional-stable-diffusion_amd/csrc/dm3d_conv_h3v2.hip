@@ -613,11 +613,15 @@ int dm3d_conv_h3v2_ksplit(const ConvArgs& a, bool with_scratch) {
         const bool linear = !a.relu && !a.prelu && !a.relu_out && a.res != a.out && a.x1 != a.out && a.x2 != a.out;
         return (linear && a.nchunks >= 8 && a.nchunks % 2 == 0) ? 2 : 1;
     }
+    // A/B knobs (read once: dm3d_conv_scratch_bytes and the launch must agree): least chunks per part, workgroups to aim for, most parts
+    static const int min_chunks = [] { const char* e = getenv("DM3D_CONV_SPLIT_MINCHUNKS"); return e ? atoi(e) : 2; }();
+    static const long target = [] { const char* e = getenv("DM3D_CONV_SPLIT_TARGET"); return e ? atol(e) : 512L; }();
+    static const int max_parts = [] { const char* e = getenv("DM3D_CONV_SPLIT_MAXPARTS"); return e ? atoi(e) : 16; }();
     int best = 1;                                             // smallest divisor that fills the chip, else the largest allowed
-    for (int d = 2; d <= 16; ++d) {
-        if (a.nchunks % d != 0 || a.nchunks / d < 2) continue;
+    for (int d = 2; d <= max_parts; ++d) {
+        if (a.nchunks % d != 0 || a.nchunks / d < min_chunks) continue;
         best = d;
-        if (wgs * d >= 512) break;
+        if (wgs * d >= target) break;
     }
     return best;
 }
