@@ -259,7 +259,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_h3(const GemmGroup grp) {
             constexpr int j = decltype(J)::value;
             const int c = it + j;
             publish(J, j & 1, c * KC + 16 < p.k, c < nchunks);
-            __syncthreads();                    // chunk c visible; everyone has left chunk c-1 (other buffer)
+            // chunk c visible; everyone has left chunk c-1 (other buffer).  A raw barrier behind this wave's LDS traffic only: __syncthreads()
+            // also drains the vector-memory counter, i.e. it waited out the prefetches that are meant to stay in flight across it — rounds 1-2
+            // ran with ONE chunk of lookahead in effect (in-kernel stamps, round 3: 2 250 cycles per chunk for 768 of MFMA)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
             if (c < 8) GSTAMP(2 + c);
             fetch(J, clampk(c + NS));
             __builtin_amdgcn_sched_barrier(0);
