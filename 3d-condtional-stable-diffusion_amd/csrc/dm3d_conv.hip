@@ -286,8 +286,9 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
                  "conv: unknown x1_fmt / out_fmt");
     DM3D_REQUIRE((d->post_scale == nullptr) == (d->post_shift == nullptr), "conv: post_scale and post_shift go together");
     if (d->x1_fmt == DM3D_FMT_H2 || d->out_fmt == DM3D_FMT_H2 || d->post_scale) {
-        DM3D_REQUIRE(d->precision == DM3D_PREC_H3 && d->ksize == 3 && d->stride == 1 && !d->upsample && !d->transpose && d->cout > 32,
-                     "conv: x1_fmt / out_fmt / post_* need precision H3, ksize 3, stride 1, no upsample / transpose, cout > 32");
+        DM3D_REQUIRE(d->precision == DM3D_PREC_H3 && d->ksize == 3 && d->stride == 1 && !d->upsample && !d->transpose,
+                     "conv: x1_fmt / out_fmt / post_* need precision H3, ksize 3, stride 1, no upsample / transpose");
+        DM3D_REQUIRE(d->cout > 32 || (d->out_fmt == DM3D_FMT_F32 && !d->post_scale), "conv: out_fmt H2 / post_* need cout > 32");
         DM3D_REQUIRE(d->x1_fmt != DM3D_FMT_H2 || (d->c2 == 0 && d->c1 % 16 == 0 && !d->pro_scale),
                      "conv: an H2 input needs c1 %% 16 == 0, no second input and no prologue");
         DM3D_REQUIRE(d->out_fmt != DM3D_FMT_H2 || (d->in_d % 4 == 0 && d->in_h % 8 == 0 && d->in_w % 8 == 0 && d->cout % 64 == 0 &&

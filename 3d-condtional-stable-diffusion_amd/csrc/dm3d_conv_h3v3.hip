@@ -438,7 +438,7 @@ int launch_v3(ConvArgs& a, hipStream_t st) {
 
 template <int KS, int MODE>
 int launch_td(ConvArgs& a, hipStream_t st) {
-    if constexpr (KS == 3 && MODE != 2) {           // the narrow column forms: k3 convs with few output channels
+    if constexpr (KS == 3) {                        // the narrow column forms: k3 convs with few output channels
         if (a.cout <= 32) {
             DM3D_REQUIRE(a.s_npairs == 0 && !a.out_h2, "conv: the fused skip conv / hand-off output need cout > 32");
             // (4-slice bricks: with 8-slice bricks conv_out / conv_in were 4 % / 11 % slower — these launches are bound by staging the input,

@@ -628,6 +628,14 @@ class Plan:
         self._conv(P["conv_in"], self.x, h, S)
         skips = [(h, cfg.first_conv_channels)]
         cur, cur_c, edge = h, cfg.first_conv_channels, S
+        # The last ResidualBlock's output has one consumer, BatchNormalization -> swish -> the output conv (conditional_dm3d.py:409-412):
+        # with the norm folded it leaves that block's conv2 already normalised, activated and split (DM3D_FMT_H2, as conv1 -> conv2 inside a
+        # block), and the output conv — 8 useful columns: bound by converting its input, not by its MFMAs — stages plain copies.
+        last = net.blocks[-1] if net.blocks else None
+        final_handoff = (last is not None and last.kind == "res" and net.h2_handoff and cfg.norm == "batch" and net.precision == "h3"
+                         and S % 8 == 0 and last.cout % 64 == 0 and B * (S ** 3 // 256) * (last.cout // 64) > 256
+                         and lib().dm3d_conv_weight_layout(3, 1, 0, 0, last.cout) == _lib.WL_PAIR
+                         and lib().dm3d_conv_weight_layout(3, 1, 0, 0, cfg.img_channels) == _lib.WL_PAIR)
         for blk in net.blocks:
             if blk.kind == "push":
                 skips.append((cur, cur_c))
@@ -637,7 +645,7 @@ class Plan:
                     x2, c2 = skips.pop()
                     if c2 != blk.cskip:
                         raise AssertionError("skip channel mismatch")
-                cur = self._res_block(blk, cur, blk.cin, x2, c2, edge)
+                cur = self._res_block(blk, cur, blk.cin, x2, c2, edge, final_post=P["out.norm"] if (final_handoff and blk is last) else None)
                 cur_c = blk.cout
             elif blk.kind == "attn":
                 cur = self._cross_block(blk, cur, edge) if cfg.conditional else self._self_block(blk, cur, edge)
@@ -649,11 +657,15 @@ class Plan:
                 out = self._buf(B, blk.edge, blk.edge, blk.edge, blk.cout)
                 self._conv(P[blk.name], cur, out, edge, upsample=1)
                 cur, edge = out, blk.edge
+        if final_handoff:
+            self._conv(P["out.conv"], cur, self.eps, edge, x1_h2=True)
+            return
         pro, bs = self._norm("out.norm", cur, cur_c, edge)
         self._conv(P["out.conv"], cur, self.eps, edge, pro=pro, pro_bstride=bs)
 
-    def _res_block(self, blk, x1, c1, x2, c2, edge):
-        """ResidualBlock (conditional_dm3d.py:238-271): three launches (two when the widths match)."""
+    def _res_block(self, blk, x1, c1, x2, c2, edge, final_post=None):
+        """ResidualBlock (conditional_dm3d.py:238-271): three launches (two when the widths match).  ``final_post``: the folded norm of
+        the block's only consumer; the block's output then leaves conv2 normalised, activated and split (DM3D_FMT_H2)."""
         P, B, n, w = self.net.P, self.B, blk.name, blk.cout
         skip = None
         if f"{n}.skip_fused" in P:
@@ -672,14 +684,15 @@ class Plan:
         handoff = (self.net.h2_handoff and self.net.cfg.norm == "batch" and self.net.precision == "h3" and edge % 8 == 0
                    and w % 64 == 0 and B * (edge ** 3 // 256) * (w // 64) > 256
                    and lib().dm3d_conv_weight_layout(3, 1, 0, 0, w) == _lib.WL_PAIR)
+        tail = dict(post=final_post, out_h2=True) if final_post is not None else {}
         if handoff:
             self._conv(P[f"{n}.conv1"], x1, hmid, edge, x2=x2, c1=c1, c2=c2, pro=pro, pro_bstride=bs, vec_off=self.net.temb_off[n],
                        post=P[f"{n}.norm2"], out_h2=True)
-            self._conv(P[f"{n}.conv2"], hmid, out, edge, res=res, skip=skip, x1_h2=True)
+            self._conv(P[f"{n}.conv2"], hmid, out, edge, res=res, skip=skip, x1_h2=True, **tail)
             return out
         self._conv(P[f"{n}.conv1"], x1, hmid, edge, x2=x2, c1=c1, c2=c2, pro=pro, pro_bstride=bs, vec_off=self.net.temb_off[n])
         pro, bs = self._norm(f"{n}.norm2", hmid, w, edge)
-        self._conv(P[f"{n}.conv2"], hmid, out, edge, pro=pro, pro_bstride=bs, res=res, skip=skip)
+        self._conv(P[f"{n}.conv2"], hmid, out, edge, pro=pro, pro_bstride=bs, res=res, skip=skip, **tail)
         return out
 
     def _group_normed(self, n, x, u, edge):

@@ -93,7 +93,7 @@ int     dm3d_pack_weights_up_h3(const float* keras_kernel, int32_t cin, int32_t 
 int     dm3d_pack_weights_convt(const float* keras_kernel, int32_t cin, int32_t cout, float* packed, void* stream);
 int     dm3d_pack_weights_convt_h3(const float* keras_kernel, int32_t cin, int32_t cout, int32_t w_exp, void* packed, void* stream);
 
-/* Second H3 weight layout, DM3D_WL_PAIR: the image read by the v_mfma_f32_16x16x32_f16 conv kernel (k3/s1 with cout > 32,
+/* Second H3 weight layout, DM3D_WL_PAIR: the image read by the v_mfma_f32_16x16x32_f16 conv kernels (every k3/s1 conv — round 3: also cout <= 32, the narrow column forms —,
  * UpSample, Conv3DTranspose): taps padded to a multiple of 4 with zeros and consumed two at a time, rows permuted inside each
  * group of 16 output channels so that the operand reads are bank-conflict free.  mode 0: plain [taps,Cin,Cout] kernel;
  * mode 1: UpSample [3,3,3,Cin,Cout] -> 8 parity images of 8 taps; mode 2: Conv3DTranspose [4,4,4,Cout,Cin] -> 8 parity images.
