@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256, MINW) void conv3d_igemm_h3(const ConvArgs p) {
                         acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mr], bh[nr], acc[mr][nr], 0, 0, 0);
                     }
 #else
-                // pass-major: the three MFMAs into one accumulator are MR*NR issue slots apart (see dm3d_conv_h3v2.hip)
+                // pass-major: the three MFMAs into one accumulator are MR*NR issue slots apart (round 2: measured neutral here, two waves per SIMD fill the slots either way)
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr)
 #pragma unroll

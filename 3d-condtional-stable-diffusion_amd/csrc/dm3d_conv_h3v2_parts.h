@@ -1,6 +1,6 @@
-// dm3d_conv_h3v2_parts.h — pieces shared by the two 16x16x32 split-float16 Conv3d kernels (dm3d_conv_h3v2.hip: the per-segment
-// ping-pong / float8 forms; dm3d_conv_h3v3.hip: the free-running software-pipelined form): operand geometry helpers, the fused 1x1
-// skip-conv tail phase and the epilogue.  Both kernels own a [4 patches][4 column tiles] accumulator per wave, one 8 x 8 z-slice each.
+// dm3d_conv_h3v2_parts.h — pieces shared by the two 16x16x32 split-float16 Conv3d kernels (dm3d_conv_h3v3.hip: the free-running
+// software-pipelined three-pass kernel, the default; dm3d_conv_h3v2.hip: the opt-in float8 cross-term form): operand geometry helpers, the
+// fused 1x1 skip-conv tail phase and the epilogue.  Both kernels own a [4 patches][column tiles] accumulator per wave, one 8 x 8 z-slice each.
 #pragma once
 #include "dm3d_conv_args.h"
 #include "dm3d_h3.h"

@@ -3,13 +3,14 @@
 // reference op: Conv3D(width, 3, padding="same") behind BatchNormalization + swish, + time-embedding / bias / residual adds
 // (networks/conditional_dm3d.py:254-268), UpSampling3D + Conv3D (:288-296), Concatenate + ResidualBlock on the up path (:394-404).
 //
-// Same arithmetic, operand geometry, LDS images, packed weight image (DM3D_WL_PAIR), skip-conv tail phase and epilogue as
-// dm3d_conv_h3v2.hip (shared through dm3d_conv_h3v2_parts.h).  What changed is the skeleton.  Round 3 measured the v2 kernel with one
-// stamp pair around its chunk loop (tools/kernel_clock.py, profiles/r03_v2_clocks.log): the chip holds 1.93-2.02 GHz under it and the
-// matrix pipe is busy 72-75 % of the loop — against 87 % at 1.87 GHz for a bare LDS-fed MFMA loop (tools/micro/mfma_shapes) — and 67 %
-// of the launch (SQ_VALU_MFMA_BUSY_CYCLES, profiles/r03_v2_sq_conv_pro192.csv).  v2 alternates a LOAD and a COMPUTE segment between the
-// two waves of a SIMD with a workgroup barrier after every 48 MFMAs: ~990 cycles per segment for 768 of MFMA, plus a prologue and an
-// epilogue that nothing overlaps (one 512-thread workgroup per CU).  Here:
+// Same arithmetic, operand geometry, LDS images, packed weight image (DM3D_WL_PAIR), skip-conv tail phase and epilogue as the round-1/2
+// kernels (now only the float8 form is left of them, dm3d_conv_h3v2.hip; shared pieces in dm3d_conv_h3v2_parts.h).  What changed is the
+// skeleton.  Round 3 measured the round-2 kernel with one stamp pair around its chunk loop (tools/kernel_clock.py, profiles/
+// r03_v2_clocks.log): the chip held 1.93-2.02 GHz under it and the matrix pipe was busy 72-75 % of the loop — against 87 % at 1.87 GHz
+// for a bare LDS-fed MFMA loop (tools/micro/mfma_shapes) — and 67 % of the launch (SQ_VALU_MFMA_BUSY_CYCLES, profiles/
+// r03_v2_sq_conv_pro192.csv).  That kernel alternated a LOAD and a COMPUTE segment between the two waves of a SIMD with a workgroup barrier
+// after every 48 MFMAs: ~990 cycles per segment for 768 of MFMA, plus a prologue and an epilogue that nothing overlapped (one 512-thread
+// workgroup per CU).  Here:
 //   * every wave runs its own pipeline.  A tap pair is three passes of 16 MFMAs on registers — A: al.bh, B: ah.bh, C: ah.bl — and each
 //     pass requests the fragments of a LATER pass into the registers the previous pass released: A(p) requests ah(p), bl(p); B(p)
 //     requests al(p+1); C(p) requests bh(p+1).  No fragment is double-buffered (64 VGPRs of fragments as before) and every ds_read has
@@ -24,7 +25,11 @@
 //     chunk's image (converted in registers during passes C(8..)) is stored during B/C of that pair, one more barrier publishes it.
 //   * workgroups are renumbered so that the 8 XCDs each take a contiguous range of (brick, column tile) work: neighbouring bricks
 //     share halo voxels and the column tiles of one brick share all of them — served by that XCD's L2 instead of from beyond it.
-// Per accumulator the order is al.bh, ah.bh, ah.bl (v2: al.bh, ah.bl, ah.bh): float32 accumulation, same error bound, not the same bits.
+// Per accumulator the order is al.bh, ah.bh, ah.bl (rounds 1-2: al.bh, ah.bl, ah.bh): float32 accumulation, same error bound, not the same bits.
+// What it bought: matrix-pipe duty in the loop 0.73 -> 0.82 with two workgroups per CU — and an in-kernel clock of
+// 1.85 instead of 1.95 GHz, i.e. the same wall time; on all-zero operands the same stream runs at 2.39 GHz, 30 % faster.  The split-float16
+// conv is bound by what the MFMA array draws on random data, not by its schedule; this kernel is kept because it is one loop for every
+// form (k3, parity, 4 / 8 slices, 16 / 32 / 64 columns) and because its work assignment halves the HBM traffic.
 #include <cstdlib>
 #include "dm3d_conv_h3v2_parts.h"
 

@@ -196,10 +196,10 @@ typedef struct dm3d_conv_desc {
 
 int     dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream);
 int64_t dm3d_conv_scratch_bytes(const dm3d_conv_desc* d);
-/* Which tile form of the 16x16x32 conv kernel serves this descriptor: 8 (8 z-slices per brick, 512 threads, three weight buffers — launches
- * with enough bricks to fill the chip at one workgroup per CU), 9 (the 8-slice form in H3F8 arithmetic: wpk_f8 given and eligible),
- * 4 (4 slices, 256 threads, two buffers), 0 (another kernel).  Profiling
- * harnesses use it to name the instantiation a launch runs (rocprofv3 lists conv3d_igemm_h3v3<KS, MODE, 8> and <KS, MODE, 4>; 9: conv3d_igemm_h3f8<KS, MODE>). */
+/* Which tile form of the 16x16x32 conv kernels serves this descriptor: 8 (8 z-slices per brick, 512 threads, one workgroup per CU — launches
+ * with enough bricks to give every CU two such workgroups in turn), 4 (4 slices, 256 threads, two workgroups per CU: small grids, the parity
+ * form, launches with a fused skip conv, Cout <= 32), 9 (the 8-slice H3F8 form: wpk_f8 given and eligible), 0 (another kernel).  Profiling
+ * harnesses use it to name the instantiation a launch runs (rocprofv3 lists conv3d_igemm_h3v3<KS, MODE, TD, NCT>; 9: conv3d_igemm_h3f8<KS, MODE>). */
 int32_t dm3d_conv_tile_form(const dm3d_conv_desc* d);
 
 /* ---- Dense / einsum contractions: out[b][m][n] = act(alpha * sum_k A[b][m][k]*B[b][n][k] + bias) + res -------
