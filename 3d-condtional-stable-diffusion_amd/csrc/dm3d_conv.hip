@@ -282,6 +282,10 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
         DM3D_REQUIRE(d->precision == DM3D_PREC_H3 && dm3d_aligned16(d->wpk_f8), "conv: wpk_f8 needs precision H3 and 16-byte alignment");
         a.wpk_f8 = d->wpk_f8;
     }
+    if (d->wpk_wino) {
+        DM3D_REQUIRE(d->precision == DM3D_PREC_H3 && dm3d_aligned16(d->wpk_wino), "conv: wpk_wino needs precision H3 and 16-byte alignment");
+        a.wpk_wino = d->wpk_wino;
+    }
     DM3D_REQUIRE((d->x1_fmt == DM3D_FMT_F32 || d->x1_fmt == DM3D_FMT_H2) && (d->out_fmt == DM3D_FMT_F32 || d->out_fmt == DM3D_FMT_H2),
                  "conv: unknown x1_fmt / out_fmt");
     DM3D_REQUIRE((d->post_scale == nullptr) == (d->post_shift == nullptr), "conv: post_scale and post_shift go together");
@@ -323,7 +327,9 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
     const int layout = dm3d_conv_weight_layout(d->ksize, d->stride, d->upsample, d->transpose, d->cout);
     DM3D_REQUIRE(d->w_layout == layout, "conv: w_layout %d but this geometry reads layout %d (dm3d_conv_weight_layout)", d->w_layout, layout);
     if (layout != DM3D_WL_PAIR) return dm3d_conv_launch_h3(a, which, st);
-    // same packed weights, arguments and epilogue; the free-running form (dm3d_conv_h3v3.hip) unless the float8 cross-term arithmetic was asked for
+    // same arguments and epilogue; the free-running form (dm3d_conv_h3v3.hip) unless the float8 cross-term arithmetic was asked for, or the
+    // Winograd-x form (dm3d_conv_h3w.hip, its own weight image) is eligible
+    if (dm3d_conv_h3v3_serves(a, which) && dm3d_conv_h3w_serves(a, which)) return dm3d_conv_launch_h3w(a, which, st);
     return dm3d_conv_h3v3_serves(a, which) ? dm3d_conv_launch_h3v3(a, which, st) : dm3d_conv_launch_h3v2(a, which, st);
 }
 
@@ -348,6 +354,10 @@ extern "C" int32_t dm3d_conv_tile_form(const dm3d_conv_desc* d) {
     a.s_npairs = d->skip_wpk ? 1 : 0;
     a.wpk_f8 = d->wpk_f8;
     if (dm3d_conv_h3v2_f8(a)) return 9;
+    a.wpk_wino = d->wpk_wino; a.cout = d->cout; a.c1 = d->c1; a.c2 = d->c2; a.ind = d->in_d; a.inh = d->in_h; a.inw = d->in_w;
+    a.nchunks = (int)(dm3d_round_up(d->c1 + d->c2, DM3D_CIN_PAD) / 16);
+    a.padz = a.pady = a.padx = (d->ksize == 3 && d->stride == 1 && !par_mode) ? 1 : 0;
+    if (dm3d_conv_h3w_serves(a, (d->ksize == 3 && d->stride == 1 && !par_mode) ? DM3D_CONV_K3S1 : DM3D_CONV_UP)) return 10;
     return dm3d_conv_h3v3_td(a);
 }
 
@@ -384,6 +394,19 @@ extern "C" int dm3d_pack_weights_h3p(const float* keras_kernel, int32_t taps, in
     DM3D_REQUIRE(w_exp >= -100 && w_exp <= 100, "pack_weights_h3p: w_exp %d out of range", w_exp);
     DM3D_REQUIRE(dm3d_aligned16(packed), "pack_weights_h3p: packed must be 16-byte aligned");
     return dm3d_pack_h3v2(keras_kernel, taps, cin, cout, w_exp, in_scale, packed, mode, 0, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int64_t dm3d_packed_weight_h3w_bytes(int32_t cin, int32_t cout) {
+    if (cin <= 0 || cout <= 0) return 0;
+    return dm3d_h3v2_image_bytes(40, cin, cout);          // 5 tap pairs x 4 transform terms x 2 taps
+}
+
+extern "C" int dm3d_pack_weights_h3w(const float* keras_kernel, int32_t cin, int32_t cout, int32_t w_exp, const float* in_scale, void* packed,
+                                     void* stream) {
+    DM3D_REQUIRE(keras_kernel && packed && cin > 0 && cout > 0, "pack_weights_h3w: bad arguments");
+    DM3D_REQUIRE(w_exp >= -100 && w_exp <= 100, "pack_weights_h3w: w_exp %d out of range", w_exp);
+    DM3D_REQUIRE(dm3d_aligned16(packed), "pack_weights_h3w: packed must be 16-byte aligned");
+    return dm3d_pack_h3v2(keras_kernel, 40, cin, cout, w_exp, in_scale, packed, 3, 0, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int64_t dm3d_packed_weight_h3f8_bytes(int32_t taps, int32_t cin, int32_t cout) {

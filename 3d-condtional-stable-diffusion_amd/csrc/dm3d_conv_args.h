@@ -33,6 +33,7 @@ struct ConvArgs {
     // h3v2 only: a 1x1 conv over a second (raw, un-normalised) input accumulated into the same tile (ResidualBlock skip path)
     const float* sx1; const float* sx2; int sc1, sc2; const void* swpk; int s_npairs;   // s_npairs = round_up(sc1+sc2, 32) / 32
     const void* wpk_f8;                      // optional second weight image: the float8 cross-term form (dm3d_h3.h "H3F8")
+    const void* wpk_wino;                    // optional weight image of the Winograd-x form (dm3d_conv_h3w.hip)
     int* range_flag; float range_limit;      // H3 range guard (include/dm3d.h): *range_flag = 1 if any |output| > range_limit
     int epi_vec4;                            // h3v2: every epilogue operand is 16-byte aligned (cout, vec_ld % 4 == 0): 16-byte epilogue accesses
 };
@@ -55,4 +56,6 @@ int dm3d_pack_skip_h3v2(const float* keras_kernel, int cin, int cout, int w_exp,
 int64_t dm3d_h3v2_image_bytes(int taps, int cin, int cout, int f8 = 0);
 int dm3d_pack_h3v2(const float* keras_kernel, int taps, int cin, int cout, int w_exp, const float* in_scale, void* packed, int mode,
                    int f8, hipStream_t st);
+bool dm3d_conv_h3w_serves(const ConvArgs& a, int which);    // true: the Winograd-x form (wpk_wino, dm3d_conv_h3w.hip) serves this launch
+int dm3d_conv_launch_h3w(ConvArgs& a, int which, hipStream_t st);
 bool dm3d_conv_h3v2_f8(const ConvArgs& a);               // true: the float8 cross-term form (wpk_f8) serves this launch

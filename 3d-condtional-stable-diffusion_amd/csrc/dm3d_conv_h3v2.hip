@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void pack_weights_h3v2_kernel(const float* __r
                                                                 int nchunks, int ntiles, float scale, const float* in_scale,
                                                                 _Float16* __restrict__ out, int mode, int f8) {
     const long nrec = (long)ntiles * nchunks * tapsp * 64;
-    const int npar = mode ? 8 : 1;
+    const int npar = (mode == 1 || mode == 2) ? 8 : 1;
     for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < nrec * 16 * npar; i0 += (long)gridDim.x * 256) {
         const int par = (int)(i0 / (nrec * 16));
         const long i = i0 % (nrec * 16);
@@ -541,6 +541,16 @@ __global__ __launch_bounds__(256) void pack_weights_h3v2_kernel(const float* __r
         const int ci = chunk * 16 + k, co = nt * 64 + (pos & ~15) + c;
         float v = 0.f;
         if (ci < cin && co < cout && tap < taps) {
+            if (mode == 3) {
+                // Winograd F(2,3) along x (dm3d_conv_h3w.hip): virtual tap = 2 * step + h, step = 5 * t + tappair; (dz, dy) tap 2 * tappair + h
+                // (the tenth is a zero pad), transform term t of its three x taps
+                const int step = tap >> 1, tq = (step % 5) * 2 + (tap & 1), t = step / 5;
+                if (tq < 9) {
+                    const float g0 = w[((long)(tq * 3 + 0) * cin + ci) * cout + co], g1 = w[((long)(tq * 3 + 1) * cin + ci) * cout + co],
+                                g2 = w[((long)(tq * 3 + 2) * cin + ci) * cout + co];
+                    v = t == 0 ? g0 : (t == 1 ? 0.5f * ((g0 + g2) + g1) : (t == 2 ? 0.5f * ((g0 + g2) - g1) : g2));
+                }
+            } else
             v = mode == 1 ? dm3d_up_weight(w, cin, cout, par, tap, ci, co)
               : mode == 2 ? dm3d_convt_weight(w, cin, cout, par, tap, ci, co) : w[((long)tap * cin + ci) * cout + co];
             if (in_scale) v *= in_scale[ci];

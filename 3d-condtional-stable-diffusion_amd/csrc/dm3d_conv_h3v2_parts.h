@@ -185,8 +185,10 @@ __device__ __forceinline__ void skip_phase(const ConvArgs& p, _Float16* smem, f3
 }
 
 // NCT = 16-column tiles per wave the caller computed (4: a whole 64-column tile; 1 / 2: the narrow forms for Cout <= 16 / 32)
+// zs: the z-slice of the brick these tiles belong to (-1: the wave index — one slice per wave); tile pi sits at brick column
+// xa * (pi & 1) + xb (xb < 0: the direct kernels' patch geometry, 4 * (pi & 1) + dx_of_row; the Winograd form passes 1, 2 * x-pair)
 template <int TD, int NCT = 4>
-__device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT], const Brick& br) {
+__device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT], const Brick& br, const int zs = -1, const int xa = 4, const int xb = -1) {
     constexpr int TH = 8, TW = 8, NT = 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = lane & 15, g4 = lane >> 4;
@@ -196,7 +198,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
     const int vrow = p.vec ? (p.vec_idx ? p.vec_idx[b] : b) : 0;
     const int n0 = ntile * NT;
     const bool full = oz0 + TD <= p.od && oy0 + TH <= p.oh && ox0 + TW <= p.ow && n0 + NT <= p.cout;
-    const int oz = oz0 + wave;
+    const int oz = oz0 + (zs < 0 ? wave : zs);
     const bool z_ok = oz < p.od;
     const size_t zbase = (((size_t)b * p.fd + (z_ok ? oz * p.os + ooz : 0)) * p.fh) * p.fw * p.cout;
     float* outz = p.out + zbase + (size_t)khalf * p.split_stride;
@@ -205,7 +207,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
     const bool split = p.split_atomic != 0, lead = khalf == 0 || !split;
     const float* resz = (p.res && lead) ? p.res + zbase : nullptr;
     const float* prz = p.prelu ? p.prelu + (zbase - (size_t)b * p.fd * p.fh * p.fw * p.cout) : nullptr;
-    const int dxl = dx_of_row(4 * g4);
+    const int dxl = xb < 0 ? dx_of_row(4 * g4) : xb;
     const int ystep = p.os * p.fw * p.cout;                              // one brick row further in the output
     float amax = 0.0f;                                                   // range guard: largest |value| this lane stores
     const float rlim = split ? 0.5f * p.range_limit : p.range_limit;     // two atomic halves: either may carry half the sum
@@ -228,7 +230,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
 #pragma unroll
                 for (int pi = 0; pi < 4; ++pi)
                     rv4[ni][pi] = *reinterpret_cast<const f32x4*>(resz + (((oy0 + 4 * (pi >> 1) + k) * p.os + ooy) * p.fw
-                                                                          + (ox0 + 4 * (pi & 1) + dxl) * p.os + oox) * p.cout + n0 + ni * 16 + c4);
+                                                                          + (ox0 + xa * (pi & 1) + dxl) * p.os + oox) * p.cout + n0 + ni * 16 + c4);
         }
 #pragma unroll
         for (int ni = 0; ni < NCT; ++ni) {
@@ -255,7 +257,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
                     r0 = xor2(s0); r1 = xor2(s1);
                     if (b1) { a[0] = r0; a[1] = r1; } else { a[2] = r0; a[3] = r1; }
                 }
-                const int o = (((oy0 + 4 * (pi >> 1) + k) * p.os + ooy) * p.fw + (ox0 + 4 * (pi & 1) + dxl) * p.os + oox) * p.cout + n;
+                const int o = (((oy0 + 4 * (pi >> 1) + k) * p.os + ooy) * p.fw + (ox0 + xa * (pi & 1) + dxl) * p.os + oox) * p.cout + n;
                 f32x4 al4 = zero;
                 if (prz) al4 = *reinterpret_cast<const f32x4*>(prz + o);
                 f32x4 v4;
@@ -297,7 +299,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         rv[ni][pi][r] = resz[((oy0 + 4 * (pi >> 1)) * p.os + ooy) * p.fw * p.cout
-                                             + ((ox0 + 4 * (pi & 1) + dxl) * p.os + oox) * p.cout + n0 + ni * 16 + row + r * ystep];
+                                             + ((ox0 + xa * (pi & 1) + dxl) * p.os + oox) * p.cout + n0 + ni * 16 + row + r * ystep];
         }
 #pragma unroll
         for (int ni = 0; ni < NCT; ++ni) {
@@ -310,7 +312,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
             const int h2col = (n >> 4) * 64 + ((n >> 3) & 1) * 16 + ((n & 7) >> 1) * 4 + (n & 1) * 32 - n * 4;
 #pragma unroll
             for (int pi = 0; pi < 4; ++pi) {
-                const int base = (((oy0 + 4 * (pi >> 1)) * p.os + ooy) * p.fw + (ox0 + 4 * (pi & 1) + dxl) * p.os + oox) * p.cout + n;
+                const int base = (((oy0 + 4 * (pi >> 1)) * p.os + ooy) * p.fw + (ox0 + xa * (pi & 1) + dxl) * p.os + oox) * p.cout + n;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int o = base + r * ystep;
@@ -347,7 +349,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
         if (!lead) add = 0.0f;
 #pragma unroll
         for (int pi = 0; pi < 4; ++pi) {
-            const int oyb = oy0 + 4 * (pi >> 1), ox = ox0 + 4 * (pi & 1) + dxl;
+            const int oyb = oy0 + 4 * (pi >> 1), ox = ox0 + xa * (pi & 1) + dxl;
             const int base = ((oyb * p.os + ooy) * p.fw + ox * p.os + oox) * p.cout + nc;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -1,0 +1,631 @@
+// dm3d_conv_h3w.hip — the k3 / stride-1 split-float16 Conv3d with a Winograd F(2,3) transform along x: 36 instead of 54 MFMA k-steps per
+// pair of output voxels (9 (dz, dy) taps x 4 transform terms against 27 taps x 2 voxels).
+//
+// reference op: Conv3D(width, 3, padding="same") behind BatchNormalization + swish, + time-embedding / bias / residual adds
+// (networks/conditional_dm3d.py:254-268) — the same launches the free-running kernel of dm3d_conv_h3v3.hip serves; this form takes them when
+// the caller supplied the transformed weight image (dm3d_conv_desc.wpk_wino) and the grid is large (dm3d_conv_h3w_serves below).
+//
+// Why.  Round 3 measured the three-pass split-float16 conv at the chip's power limit, not at a scheduling limit: the same instruction stream
+// runs 30 % faster on all-zero operands (2.39 against 1.85 GHz), no reordering of it moved the wall time, and no other
+// MFMA operand type is cheaper per product at the accuracy H3 keeps.  What is left is to execute fewer MFMAs.  For outputs y(2i), y(2i+1)
+// of a row and inputs d0..d3 = x(2i-1 .. 2i+2), with the three x taps g0, g1, g2 of one (dz, dy, cin, cout):
+//     v0 = d0 - d2, v1 = d1 + d2, v2 = d2 - d1, v3 = d1 - d3          (input transform, float32, before the hi / lo split)
+//     u0 = g0, u1 = (g0 + g1 + g2) / 2, u2 = (g0 - g1 + g2) / 2, u3 = g2    (weight transform, at pack time)
+//     m_t = sum over (dz, dy, cin) of u_t . v_t                         (FOUR implicit GEMMs over 9 taps — the MFMA work)
+//     y(2i) = m0 + m1 + m2,  y(2i+1) = m1 - m2 - m3                     (output transform, on the accumulators)
+// Every m_t is a float32-accumulated sum of split-float16 products exactly like the direct form's; the transforms add one float32 rounding
+// on each side and the output transform two more — the result differs from the direct kernel's in the last bits (same 2e-5 parity bound;
+// tests/test_gpu_wino.py), not in kind.  |v_t| <= 2 max|x|: the range the activations may use halves (the host passes range_limit / 2 to
+// the producers of such a conv).
+//
+// Geometry.  One workgroup = 4 waves = one 8 x 8 x 8 brick x 64 output channels; a wave owns TWO z-slices: per transform term t four
+// 16-row operand groups (slice s, row group g: rows = 4 y x 4 x-pairs) x four 16-column tiles = 16 accumulator tiles, 64 in all (256
+// registers: the kernel runs one wave per SIMD with the accumulators in the AGPR half of the file).  That is the point of the shape: an
+// MFMA step of 48 instructions reads 16 fragments, the same LDS bytes per MFMA as the direct kernel (a one-slice wave would read 12 per 24).
+// The LDS image holds, per halo row (z, y) of the brick, 16 records [t][x-pair] of 16 channels (hi / lo, 64 bytes) at a pitch of 17
+// records (100 rows = 106 KB), slots XOR-swizzled by the row's y: the 4 y x 4 x-pair reads of a fragment hit 16 different 16-byte bank
+// groups, and so do the stores of one record index by the 64 rows of a wave (pitch 16 would put them all into one 64-byte window).
+// A step = one pair of (dz, dy) taps (the lane half picks the tap; the tenth tap is a zero pad) x one transform term: 20 steps per
+// 16-channel chunk, TERM-MAJOR (t = step / 5), three passes of 16 MFMAs each (al.bh, ah.bh, ah.bl) on registers; weights by LDS-DMA
+// through a ring of four 8 KB buffers, one barrier per step.  Term-major order is what keeps the staging out of the register file: the
+// image's records of term t are dead five steps into the chunk's t-th block, so the NEXT chunk's records of t = 0, 1, 2 are stored as soon
+// as they are computed and only its t = 3 quarter (32 registers) waits for the last step's barrier.
+//
+// One wave per SIMD: what that costs and how the loop is written (measurements: DESIGN.md section 4, tools/micro/mfma_valu_overlap.hip).
+// A wave issues in order; an MFMA 16x16x32 holds the vector issue for 8 of its 16 cycles, so 8 cycles of other instructions ride in its
+// shadow (two plain VALU, or one transcendental; a ds_read_b128 ~2) — IF they sit between two MFMAs; a burst between passes, a third VALU
+// in a gap, an s_nop, a packed-float32 VALU all cost their full issue time, and there is no second wave to absorb them.  So a pass is 16
+// gaps of one MFMA plus at most a few instructions: the fragment reads go, one or two at a time, into the registers the last group of four
+// MFMAs released; the weight DMA, the halo requests and the staging arithmetic (norm + SiLU, transform, split — plain scalar float32, one
+// transcendental or two plain instructions per gap) are spread over the gaps by fixed tables (slot_gap below); finished records are stored
+// at pass heads, where the counted LDS waits can account for them.  The MFMAs are inline asm with the accumulator constrained to AGPRs (left
+// alone, hipcc's allocator shuffled accumulator tiles between AGPRs, VGPRs and scratch, and a scratch reload in this loop costs a vmcnt(0)).
+// First forms of this loop (staging in per-pass bursts; packed VALU; spills) ran at 0.54 MFMA duty and lost to the direct kernel; this one
+// holds 0.63-0.65 at 2.05-2.2 GHz — the chip is NOT at its power limit under it — and takes 7-17 % less time than the direct kernel from
+// 96 input channels up (profiles/r03_wino_*.log).  The prologue and the epilogue (the shared one, once per slice) run unoverlapped — one
+// workgroup per CU — and cost 18 % of a 12-chunk workgroup: the launcher keeps launches with few chunks on the direct kernel.
+#include <cstdlib>
+#include "dm3d_conv_h3v2_parts.h"
+
+using namespace h3v2;
+
+// Diagnostic build only (-DDM3D_CLOCK_STAMPS, tools/mk_stamp_variants.py -> variants/cck.so; the product library carries none of it): thread 0 of
+// every workgroup writes s_memtime / s_memrealtime at kernel entry (0), around the chunk loop (1, 28) and at the end (29) into a buffer of its own.
+#ifdef DM3D_CLOCK_STAMPS
+__device__ unsigned long long* g_dbg_stamps_w = nullptr;
+extern "C" int dm3d_debug_set_stamps_wino(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_stamps_w), &p, sizeof(p)); }
+#define STAMP(i) do { if (g_dbg_stamps_w && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) { \
+    g_dbg_stamps_w[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if ((i) == 1) g_dbg_stamps_w[blockIdx.x * 32 + 30] = __builtin_amdgcn_s_memrealtime(); \
+    if ((i) == 28) g_dbg_stamps_w[blockIdx.x * 32 + 31] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+namespace {
+
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+// MODE 0: float32 input as is; 1: float32 input through the fused norm + SiLU prologue; 2: x1 already activated and split (DM3D_FMT_H2)
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
+    constexpr int TD = 8, TH = 8, TW = 8, CK = 16, NT = 64, NW = 4;
+    constexpr int HD = TD + 2, HH = TH + 2, HROWS = HD * HH;
+    constexpr int RREC = 17;                                        // records per halo row: 16 + 1 (see the store side below)
+    constexpr int NS = 20;                                          // steps per chunk: 5 tap pairs x 4 transform terms
+    constexpr int WPAIR = 2 * NT * REC;                             // halfs per step's weights (8 KB)
+    constexpr int RING = 4;
+    constexpr int WSLOT = WPAIR * 2 / 1024 / NW;                    // 1 KB DMA pieces per wave and step: 2
+    constexpr int NLD = 5;                                          // steps whose pass B requests two halo voxels each
+    constexpr bool pro = MODE == 1, xh2 = MODE == 2;
+    constexpr int PLOADS = pro ? 4 : 0;
+
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_w[];
+    _Float16* lds_w = smem_w;                   // [RING][2 taps][NT][REC]
+    _Float16* lds_in = smem_w + RING * WPAIR;   // [HROWS][4 t][4 x-pairs (+ 1 pad)][REC]
+
+    STAMP(0);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform: DMA destinations, M0, stay in scalar registers)
+    const int half = lane >> 5, q = (lane >> 4) & 1, row = lane & 15;
+
+    // ---- XCD-aware work assignment (as dm3d_conv_h3v3.hip: a pure renumbering of the grid)
+    const int ny = gridDim.y;
+    int brick, ntile;
+    {
+        const unsigned total = gridDim.x * gridDim.y;
+        const unsigned d = blockIdx.x + gridDim.x * blockIdx.y;
+        unsigned w = d;
+        if ((total & 7u) == 0) w = (d & 7u) * (total >> 3) + (d >> 3);
+        brick = (int)(w / (unsigned)ny);
+        ntile = (int)(w - (unsigned)brick * (unsigned)ny);
+    }
+    const int bpv = p.bd * p.bh * p.bw;
+    const int b = brick / bpv;
+    brick -= b * bpv;
+    const int oz0 = (brick / (p.bh * p.bw)) * TD;
+    const int oy0 = ((brick / p.bw) % p.bh) * TH;
+    const int ox0 = (brick % p.bw) * TW;
+
+    // ---- staging: thread t owns 16-byte piece t >> 7 (8 channels) of halo row t & 127 = (hz, hy): ten voxels in, sixteen records out.
+    // The piece is the same for a whole wave: the chunk's scale / shift vectors and channel masks are scalar registers (loaded by
+    // s_load), not 16 vector registers per lane.
+    const int piece = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const bool s_act = (tid & 127) < HROWS;
+    const int srow = s_act ? (tid & 127) : HROWS - 1;
+    const int hz = srow / HH, hy = srow % HH;
+    const int iz = oz0 - 1 + hz, iy = oy0 - 1 + hy;
+    const bool row_in = iz >= 0 && iz < p.ind && iy >= 0 && iy < p.inh;
+    const bool x_lo = ox0 > 0, x_hi = ox0 + TW < p.inw;                 // is halo column 0 / 9 inside the volume
+    int gv0;                                                            // voxel index of halo column 0 (rows outside the volume: a clamped row, masked later)
+    {
+        const int izc = iz < 0 ? 0 : (iz >= p.ind ? p.ind - 1 : iz), iyc = iy < 0 ? 0 : (iy >= p.inh ? p.inh - 1 : iy);
+        gv0 = ((b * p.ind + izc) * p.inh + iyc) * p.inw + ox0 - 1;
+    }
+    const int st_base = srow * RREC * REC + ((piece ^ (hy & 3)) << 3);  // halfs: record k = t * 4 + xpair sits k * REC further; lo piece: ^ 16
+
+    // ---- operand addressing: lane (half, q, row): row = 4 * xpair + y inside a group, half = tap of the pair, q = 8-channel piece
+    const int ay = row & 3;
+    const unsigned in_addr = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)lds_in;
+    const unsigned w_addr = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)lds_w;
+    unsigned a_base = in_addr + (unsigned)((((2 * wave) * HH + ay) * RREC + (row >> 2)) * (REC * 2));
+    unsigned sl[3];                                                     // physical slot (bytes) of piece q in a row with y = ay + dy
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) sl[dy] = (unsigned)((q ^ ((ay + dy) & 3)) << 4);
+    const int b_pos = pi_pos(row);
+    const int b_hi = (half * NT + b_pos) * REC + ((q ^ swz(b_pos)) << 3);
+
+    f32x4v acc[4][4][4];                                                // [t][2 * slice + row group][column tile]
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[t][pi][ni] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    // weights: the packed image IS the LDS image, step sq of this column tile is a linear 8 KB copy; wave w moves the 1 KB pieces w, w + 4
+    const char* w_img = reinterpret_cast<const char*>(static_cast<const _Float16*>(p.wpk) + (size_t)ntile * p.nchunks * NS * WPAIR) + wave * 1024 + lane * 16;
+    const int sq_end = p.nchunks * NS;
+    auto fetch_w1 = [&](int sq, int slot, const int i) {              // unconditional (past the end the last step is fetched again): hipcc can count what is in flight
+        const char* src = w_img + (size_t)(sq < sq_end ? sq : sq_end - 1) * (WPAIR * 2);
+        char* dst = reinterpret_cast<char*>(lds_w) + slot * (WPAIR * 2) + wave * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * (NW * 1024)),
+                                         (__attribute__((address_space(3))) void*)(dst + i * (NW * 1024)), 16, 0, 0);
+    };
+    auto fetch_w = [&](int sq, int slot) { fetch_w1(sq, slot, 0); fetch_w1(sq, slot, 1); };
+    int sq = 0;                                          // running step number of the step being multiplied
+#pragma unroll
+    for (int i = 0; i < RING; ++i) fetch_w(i, i);        // the ring starts full; pass B of step s refills s's buffer with step s + 4  (NS % RING == 0: slot = step & 3)
+
+    f32x4 va[10][2];                                     // the row's ten voxels: raw -> activated float32, in place
+    u32x4 oh[4], ol[4];                                  // one transform term's four records (x-pairs), hi and lo pieces
+    u32x4 o3h[4], o3l[4];                                // the t = 3 records, kept until the chunk's last barrier
+    f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
+    bool km[3][2] = {{true, true}, {true, true}, {true, true}};     // keep masks [halo column 0 / 1-8 / 9][channels 0-3 / 4-7 of the piece]: inside the volume and a real channel
+    bool ok0 = true, ok1 = true;
+    // Loads are never behind a branch (clamped addresses, masked afterwards): a load under a divergent `if` makes hipcc wait vmcnt(0) on the spot.
+    auto load_voxel = [&](int ch, int hx) {
+        const int hxc = hx == 0 ? (x_lo ? 0 : 1) : (hx == 9 ? (x_hi ? 9 : 8) : hx);
+        const unsigned gv = (unsigned)(gv0 + hxc);
+        // (addresses = a uniform base + a 32-bit lane offset: the launcher admits tensors below 4 GB only — one register per voxel, nothing
+        // for hipcc to hoist out of the chunk loop as 64-bit pairs)
+        if (xh2) {                       // record ch of the voxel: hi piece at slot `piece`, lo piece at slot 2 + piece
+            const char* base = reinterpret_cast<const char*>(p.x1) + (size_t)ch * 64;
+            const unsigned off = gv * ((unsigned)p.c1 * 4u) + (unsigned)piece * 16u;
+            va[hx][0] = *reinterpret_cast<const f32x4*>(base + off);
+            va[hx][1] = *reinterpret_cast<const f32x4*>(base + off + 32u);
+            return;
+        }
+        const int c0 = ch * CK;
+        const float* src;
+        int ldc, cb;
+        if (c0 < p.c1) { src = p.x1; ldc = p.c1; cb = c0; } else { src = p.x2; ldc = p.c2; cb = c0 - p.c1; }
+        const int cpos = cb + piece * 8;
+        const int off0 = cpos < ldc ? cpos : 0, off1 = cpos + 4 < ldc ? cpos + 4 : 0;
+        const char* base = reinterpret_cast<const char*>(src);
+        const unsigned voff = gv * ((unsigned)ldc * 4u);
+        va[hx][0] = *reinterpret_cast<const f32x4*>(base + (voff + (unsigned)off0 * 4u));
+        va[hx][1] = *reinterpret_cast<const f32x4*>(base + (voff + (unsigned)off1 * 4u));
+    };
+    auto load_chunk_params = [&](int ch) {
+        if (xh2) return;
+        const int c0 = ch * CK;
+        const int ldc = c0 < p.c1 ? p.c1 : p.c2, cpos = (c0 < p.c1 ? c0 : c0 - p.c1) + piece * 8;
+        ok0 = cpos < ldc;
+        ok1 = cpos + 4 < ldc;
+        if (pro) {
+            const int s0 = ok0 ? c0 + piece * 8 : 0, s1 = ok1 ? c0 + piece * 8 + 4 : 0;
+            const size_t bo = (size_t)b * p.pro_bstride;
+            sc0 = *reinterpret_cast<const f32x4*>(p.pscale + bo + s0);
+            sh0 = *reinterpret_cast<const f32x4*>(p.pshift + bo + s0);
+            sc1 = *reinterpret_cast<const f32x4*>(p.pscale + bo + s1);
+            sh1 = *reinterpret_cast<const f32x4*>(p.pshift + bo + s1);
+        }
+    };
+    // vector-memory requests issued in pass B of step s beside its weight DMA (a negative s: a late step of the previous chunk)
+    auto halo_ops = [&](int s) {
+        if (s < 0) s += NS;
+        if (s >= NLD) return 0;
+        return 4 + (s == 0 ? PLOADS : 0);
+    };
+    // ---- the staging arithmetic, two channels at a time (packed float32 VALU: v_pk_fma / v_pk_mul / v_pk_add).  Instruction COUNT is what
+    // matters here: a wave alone on its SIMD issues strictly in order and an MFMA holds its issue port for all 16 cycles — in-kernel stamps
+    // put a chunk at 15 360 cycles of MFMA + 4 cycles x every other instruction, to the percent, however the two are interleaved.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    h8 g_hi, g_lo;
+#define DM3D_PIN(x) asm volatile("" :: "v"(x))        /* an ordered use: what feeds it cannot sink below this point (instruction selection
+                                                          otherwise sinks such arithmetic to its first use, ten steps later) */
+    // channels 4h .. 4h + 3 of halo voxel hx: norm + SiLU (the operations of dm3d_silu in its order), zero outside the volume / past the
+    // last channel (the prologue's form: the whole quad at once)
+    auto act_quad = [&](const int hx, const int h) {
+        const int col = hx == 0 ? 0 : (hx == 9 ? 2 : 1);
+        f32x4 v;
+        if (xh2) {                       // the split pair back to one float32 per channel
+            if (h == 0) { g_hi = __builtin_bit_cast(h8, va[hx][0]); g_lo = __builtin_bit_cast(h8, va[hx][1]); }    // (saved: the float32 values overwrite the halves)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const _Float16 a = g_hi[4 * h + e], b = g_lo[4 * h + e]; v[e] = (float)a + (float)b; }
+            if (!km[col][0]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            v = va[hx][h];
+            if (pro) {
+                const f32x4 y = __builtin_elementwise_fma(v, h ? sc1 : sc0, h ? sh1 : sh0);
+                const f32x4 z = y * -1.4426950408889634f;
+                f32x4 d;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = __builtin_amdgcn_exp2f(z[e]);
+                d = d + 1.0f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = __builtin_amdgcn_rcpf(d[e]);
+                v = y * d;
+            }
+            if (!km[col][h]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        DM3D_PIN(v);
+        va[hx][h] = v;
+    };
+    // channels 2j, 2j + 1 of transform term t of x-pair xt, and their float16 split (no clamp: |term| <= 2 max|x|, and the range guard of
+    // this form keeps |x| <= 32752 — include/dm3d.h)
+    auto split_pair = [&](const int t, const int xt, const int j) {
+        const int h = j >> 1, c = 2 * (j & 1);
+        auto d = [&](const int k) { return f32x2{va[2 * xt + k][h][c], va[2 * xt + k][h][c + 1]}; };
+        const f32x2 x = t == 0 ? d(0) - d(2) : (t == 1 ? d(1) + d(2) : (t == 2 ? d(2) - d(1) : d(1) - d(3)));
+        const float x0 = x[0], x1 = x[1];
+        unsigned int a, r;
+        float r0, r1;
+        // hi = f16(x) (RNE), lo = f16(x - hi): one asm statement (hipcc puts an s_nop between two asm statements that depend on each other)
+        asm volatile("v_cvt_pk_f16_f32 %0, %4, %5\n\tv_fma_mix_f32 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+                     "v_fma_mix_f32 %3, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_cvt_pk_f16_f32 %1, %2, %3"
+                     : "=&v"(a), "=&v"(r), "=&v"(r0), "=&v"(r1) : "v"(x0), "v"(x1));
+        if (t == 3) { o3h[xt][j] = a; o3l[xt][j] = r; } else { oh[xt][j] = a; ol[xt][j] = r; }
+    };
+    auto chunk_masks = [&]() {
+        km[0][0] = row_in && x_lo && ok0; km[0][1] = row_in && x_lo && ok1; km[1][0] = row_in && ok0; km[1][1] = row_in && ok1;
+        km[2][0] = row_in && x_hi && ok0; km[2][1] = row_in && x_hi && ok1;
+    };
+    auto store_record = [&](const int t, const int xt) {
+        if (s_act) {
+            *reinterpret_cast<u32x4*>(lds_in + st_base + (t * 4 + xt) * REC) = t == 3 ? o3h[xt] : oh[xt];
+            *reinterpret_cast<u32x4*>(lds_in + ((st_base + (t * 4 + xt) * REC) ^ 16)) = t == 3 ? o3l[xt] : ol[xt];
+        }
+    };
+    // raw barrier behind this wave's own LDS traffic (never drains the vector-memory counter: the DMA fills stay in flight across it)
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // ---- prologue: the first chunk's image
+#pragma unroll
+    for (int hx = 0; hx < 10; ++hx) load_voxel(0, hx);
+    load_chunk_params(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0) (with an instruction hipcc's wait-count pass sees): halo and the first four weight steps
+    chunk_masks();
+#pragma unroll
+    for (int hx = 0; hx < 10; ++hx) { act_quad(hx, 0); act_quad(hx, 1); }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) split_pair(t, u >> 2, u & 3);
+#pragma unroll
+        for (int xt = 0; xt < 4; ++xt) store_record(t, xt);
+    }
+    lds_barrier();
+
+    // ---- the step loop.  A wave alone on its SIMD has only its own MFMAs to hide its other instructions behind: an MFMA takes 4 cycles to
+    // issue and holds the matrix pipe for 16, so up to three other instructions ride in its shadow — if they are THERE, between two MFMAs,
+    // and independent of the neighbours (in-kernel stamps of the first forms of this loop, which issued reads, DMA and staging arithmetic in
+    // bursts between the passes: 28 000 cycles per chunk for 15 360 of MFMA, at 2.15 GHz — the chip is not at its power limit here, unlike
+    // under the two-waves-per-SIMD direct kernel).  So a pass is 16 GAPS, each one MFMA plus at most a few instructions:
+    //   * fragment reads, one or two per group of four MFMAs, into registers the group just released.  Pass A (al.bh, row-group major)
+    //     re-requests bl for this step's pass C behind groups 0-1 and al of the NEXT step behind groups 1-3; pass B (ah.bh, column-tile
+    //     major) requests bh of the next step behind each group; pass C (ah.bl, row-group major) ah of the next step.  LDS returns in order:
+    //     the head of pass A waits lgkmcnt(4 + stores) (the four ah reads of the previous pass C may be out), the head of pass B — the step's
+    //     one barrier — lgkmcnt(4) (al of the next step) and vmcnt(N) as before, pass C nothing.  Addresses cost nothing: five per-lane
+    //     bases (one per tap pair, the lane half picks the tap) + immediates for term / row group / slice / ring slot.
+    //   * the weight DMA right behind the barrier, the halo requests behind groups 0-1 of pass B, the chunk parameters behind group 2.
+    //   * the staging arithmetic, one or two instructions per gap (the tables at slot_gap below); finished records are stored at the head
+    //     of the next pass (the waits above count them).
+    // The fragment reads are inline asm: behind a `global_load_lds` hipcc guards every visible ds_read result with lgkmcnt(0) (see
+    // dm3d_conv_h3v3.hip).  The MFMAs are inline asm with the accumulator constrained to the AGPR file: left to itself hipcc's allocator
+    // moved accumulator tiles between AGPRs, VGPRs and scratch around the term blocks, and every scratch reload inside the loop is
+    // followed by vmcnt(0), which drains the weight DMA and halo requests in flight.
+    h8 ah[4], al[4], bh[4], bl[4];
+    // per-lane operand bases: tap pair tp = taps 2tp, 2tp + 1 of the nine (dz, dy) (the pad tap re-reads the last real tap's voxels against
+    // zero weights), the lane half picks the tap; hi piece (lo: ^ 32)
+    unsigned a_tp[5];
+#pragma unroll
+    for (int tp = 0; tp < 5; ++tp) {
+        const int ta = 2 * tp, tb = ta + 1 < 9 ? ta + 1 : 8;
+        const unsigned ka = (unsigned)((((ta / 3) * HH + ta % 3) * RREC) * (REC * 2)), kb = (unsigned)((((tb / 3) * HH + tb % 3) * RREC) * (REC * 2));
+        a_tp[tp] = a_base + (half ? kb + sl[tb % 3] : ka + sl[ta % 3]);
+    }
+    const unsigned wb_hi = w_addr + (unsigned)b_hi * 2u, wb_lo = w_addr + (unsigned)(b_hi ^ 16) * 2u;
+#define DM3D_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    constexpr int GOFF = 4 * RREC * REC * 2, SOFF = HH * RREC * REC * 2;    // bytes to the second row group / the second slice
+    // fragment i (0 .. 3: slice i >> 1, row group i & 1) of step s (term s / 5: 256 bytes per term inside a halo row)
+    auto read_a = [&](h8 (&dst)[4], const int s, const int i, const bool lo) {
+        const unsigned a0 = lo ? a_tp[s % 5] ^ 32u : a_tp[s % 5];
+        switch ((s / 5) * 4 + i) {
+#define DM3D_RA(t_, i_) case (t_) * 4 + (i_): DM3D_DSR(dst[i_], a0, (t_) * 4 * REC * 2 + ((i_) >> 1) * SOFF + ((i_) & 1) * GOFF); break;
+            DM3D_RA(0, 0) DM3D_RA(0, 1) DM3D_RA(0, 2) DM3D_RA(0, 3) DM3D_RA(1, 0) DM3D_RA(1, 1) DM3D_RA(1, 2) DM3D_RA(1, 3)
+            DM3D_RA(2, 0) DM3D_RA(2, 1) DM3D_RA(2, 2) DM3D_RA(2, 3) DM3D_RA(3, 0) DM3D_RA(3, 1) DM3D_RA(3, 2) DM3D_RA(3, 3)
+#undef DM3D_RA
+        }
+    };
+    // column tile i of the weights in ring slot `slot`
+    auto read_b = [&](h8 (&dst)[4], const int slot, const int i, const bool lo) {
+        const unsigned wa = lo ? wb_lo : wb_hi;
+        switch (slot * 4 + i) {
+#define DM3D_RB(k_, i_) case (k_) * 4 + (i_): DM3D_DSR(dst[i_], wa, (k_) * WPAIR * 2 + (i_) * 16 * REC * 2); break;
+            DM3D_RB(0, 0) DM3D_RB(0, 1) DM3D_RB(0, 2) DM3D_RB(0, 3) DM3D_RB(1, 0) DM3D_RB(1, 1) DM3D_RB(1, 2) DM3D_RB(1, 3)
+            DM3D_RB(2, 0) DM3D_RB(2, 1) DM3D_RB(2, 2) DM3D_RB(2, 3) DM3D_RB(3, 0) DM3D_RB(3, 1) DM3D_RB(3, 2) DM3D_RB(3, 3)
+#undef DM3D_RB
+        }
+    };
+    // ---- staging work by gap G = 16 * (3 * step + pass) + g (0 .. 959), at most 8 cycles of vector issue per gap (MI355X_MICROARCH.md,
+    // 'vector-instruction ISSUE cost': an MFMA holds the vector issue for 8 of its 16 cycles, a plain VALU for 4, a transcendental for 8,
+    // packed float32 VALU far more beside MFMAs — so plain scalar arithmetic, two plain instructions or one transcendental per gap):
+    //   207            the next chunk's keep masks
+    //   208 .. 567     norm + SiLU, 18 gaps per 4 channels (channels 0-3 / 4-7 of halo voxel hx: quad i = 2 hx + h at 208 + 18 i; voxel pair
+    //                  i >> 2 was requested in pass B of step i >> 2, the barrier heads since have waited past it): y = x * scale + shift
+    //                  (2 gaps), z = -y log2 e (2), 2^z (4), + 1 (2), 1 / . (4), y * . (2), the mask (2)
+    //   576 .. 623     term 0: unit u = x-pair u >> 2, channel pair u & 3 at 576 + 3 u: the term, hi = f16(x) and x0 - hi, x1 - hi and lo.
+    //   624 .. 671     term 1                The steps are term-major, so the image's records of term t are dead once every wave is past
+    //   688 .. 735     term 2 (pass 43 on)   the barrier of step 5t + 4: a finished record goes to LDS at the head of the next pass (one or
+    //   736 .. 783     term 3 (kept)         two transient records in registers, not the whole image); only the four t = 3 records wait in
+    //                                        registers for the barrier of the last step (pass 58).
+    f32x4 g_y, g_z;
+    float g_x0 = 0.f, g_x1 = 0.f, g_r0 = 0.f;
+    unsigned int g_a = 0u;
+    // ds_write_b128 issued at the head of pass p (the waits count them): the records finished in pass p - 1
+    auto stores_at_head = [&](int p) {
+        p = (p + 60) % 60;
+        if (p == 37 || p == 38 || p == 40 || p == 41 || p == 44 || p == 45) return 2;
+        if (p == 39 || p == 42 || p == 46) return 4;
+        return p == 58 ? 8 : 0;
+    };
+    auto head_stores = [&](const int p) {
+        if (p == 37) store_record(0, 0); else if (p == 38) store_record(0, 1); else if (p == 39) { store_record(0, 2); store_record(0, 3); }
+        else if (p == 40) store_record(1, 0); else if (p == 41) store_record(1, 1); else if (p == 42) { store_record(1, 2); store_record(1, 3); }
+        else if (p == 44) store_record(2, 0); else if (p == 45) store_record(2, 1); else if (p == 46) { store_record(2, 2); store_record(2, 3); }
+        else if (p == 58) {
+#pragma unroll
+            for (int xt = 0; xt < 4; ++xt) store_record(3, xt);
+        }
+    };
+    auto slot_gap = [&](const int G) {
+        if (G == 207) { chunk_masks(); return; }
+        if (G >= 208 && G < 568) {
+            const int i = (G - 208) / 18, r = (G - 208) % 18;
+            const int hx = i >> 1, h = i & 1, col = hx == 0 ? 0 : (hx == 9 ? 2 : 1);
+            if (xh2) {                   // the split pair back to one float32 per channel
+                if (r == 0 && h == 0) { g_hi = __builtin_bit_cast(h8, va[hx][0]); g_lo = __builtin_bit_cast(h8, va[hx][1]); }
+                if (r < 4) { const _Float16 a = g_hi[4 * h + r], b = g_lo[4 * h + r]; g_y[r] = (float)a; g_z[r] = (float)b; DM3D_PIN(g_y[r]); DM3D_PIN(g_z[r]); }
+                else if (r < 6) { const int c = 2 * (r - 4); g_y[c] += g_z[c]; g_y[c + 1] += g_z[c + 1]; DM3D_PIN(g_y[c]); DM3D_PIN(g_y[c + 1]); }
+                else if (r < 8) {
+                    const int c = 2 * (r - 6);
+                    float v0 = km[col][0] ? g_y[c] : 0.0f, v1 = km[col][0] ? g_y[c + 1] : 0.0f;
+                    DM3D_PIN(v0); DM3D_PIN(v1);
+                    va[hx][h][c] = v0; va[hx][h][c + 1] = v1;
+                }
+                return;
+            }
+            if (!pro) {
+                if (r < 2) {
+                    const int c = 2 * r;
+                    float v0 = km[col][h] ? va[hx][h][c] : 0.0f, v1 = km[col][h] ? va[hx][h][c + 1] : 0.0f;
+                    DM3D_PIN(v0); DM3D_PIN(v1);
+                    va[hx][h][c] = v0; va[hx][h][c + 1] = v1;
+                }
+                return;
+            }
+            const f32x4 sc = h ? sc1 : sc0, sh = h ? sh1 : sh0;
+            if (r < 2) {                 // y = x * scale + shift
+                const int c = 2 * r;
+                g_y[c] = fmaf(va[hx][h][c], sc[c], sh[c]); g_y[c + 1] = fmaf(va[hx][h][c + 1], sc[c + 1], sh[c + 1]);
+                DM3D_PIN(g_y[c]); DM3D_PIN(g_y[c + 1]);
+            } else if (r < 4) {          // z = -y log2 e
+                const int c = 2 * (r - 2);
+                g_z[c] = g_y[c] * -1.4426950408889634f; g_z[c + 1] = g_y[c + 1] * -1.4426950408889634f;
+                DM3D_PIN(g_z[c]); DM3D_PIN(g_z[c + 1]);
+            } else if (r < 8) {          // 2^z
+                g_z[r - 4] = __builtin_amdgcn_exp2f(g_z[r - 4]);
+                DM3D_PIN(g_z[r - 4]);
+            } else if (r < 10) {         // 1 + 2^z
+                const int c = 2 * (r - 8);
+                g_z[c] = 1.0f + g_z[c]; g_z[c + 1] = 1.0f + g_z[c + 1];
+                DM3D_PIN(g_z[c]); DM3D_PIN(g_z[c + 1]);
+            } else if (r < 14) {         // 1 / (1 + 2^z)
+                g_z[r - 10] = __builtin_amdgcn_rcpf(g_z[r - 10]);
+                DM3D_PIN(g_z[r - 10]);
+            } else if (r < 16) {         // y / (1 + 2^z): the operations of dm3d_silu in its order
+                const int c = 2 * (r - 14);
+                g_y[c] = g_y[c] * g_z[c]; g_y[c + 1] = g_y[c + 1] * g_z[c + 1];
+                DM3D_PIN(g_y[c]); DM3D_PIN(g_y[c + 1]);
+            } else {                     // zero outside the volume / past the last channel
+                const int c = 2 * (r - 16);
+                float v0 = km[col][h] ? g_y[c] : 0.0f, v1 = km[col][h] ? g_y[c + 1] : 0.0f;
+                DM3D_PIN(v0); DM3D_PIN(v1);
+                va[hx][h][c] = v0; va[hx][h][c + 1] = v1;
+            }
+            return;
+        }
+        if ((G >= 576 && G < 672) || (G >= 688 && G < 784)) {
+            const int t = G < 624 ? 0 : (G < 672 ? 1 : (G < 736 ? 2 : 3));
+            const int q = G - (t == 0 ? 576 : (t == 1 ? 624 : (t == 2 ? 688 : 736)));
+            const int u = q / 3, st = q % 3, xt = u >> 2, j = u & 3, h = j >> 1, c = 2 * (j & 1);
+            if (st == 0) {
+                auto d = [&](const int k, const int e) { return va[2 * xt + k][h][c + e]; };
+                g_x0 = t == 0 ? d(0, 0) - d(2, 0) : (t == 1 ? d(1, 0) + d(2, 0) : (t == 2 ? d(2, 0) - d(1, 0) : d(1, 0) - d(3, 0)));
+                g_x1 = t == 0 ? d(0, 1) - d(2, 1) : (t == 1 ? d(1, 1) + d(2, 1) : (t == 2 ? d(2, 1) - d(1, 1) : d(1, 1) - d(3, 1)));
+                DM3D_PIN(g_x0); DM3D_PIN(g_x1);
+            } else if (st == 1) {        // hi = f16(x) (RNE), x0 - hi0
+                asm volatile("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_fma_mix_f32 %1, %0, -1.0, %2 op_sel_hi:[1,0,0]" : "=&v"(g_a), "=&v"(g_r0) : "v"(g_x0), "v"(g_x1));
+            } else {                     // x1 - hi1, lo = f16(x - hi)
+                unsigned int r;
+                float r1;
+                asm volatile("v_fma_mix_f32 %1, %2, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_cvt_pk_f16_f32 %0, %4, %1" : "=&v"(r), "=&v"(r1) : "v"(g_a), "v"(g_x1), "v"(g_r0));
+                if (t == 3) { o3h[xt][j] = g_a; o3l[xt][j] = r; } else { oh[xt][j] = g_a; ol[xt][j] = r; }
+            }
+        }
+    };
+#define DM3D_MFMA(T, PI, NI, A, B) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[T][PI][NI]) : "v"(A[PI]), "v"(B[NI]))
+#define DM3D_WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(n) : "memory")
+
+    read_a(al, 0, 0, true); read_a(al, 0, 1, true); read_a(al, 0, 2, true); read_a(al, 0, 3, true);
+    read_b(bh, 0, 0, false); read_b(bh, 0, 1, false); read_b(bh, 0, 2, false); read_b(bh, 0, 3, false);
+    read_a(ah, 0, 0, false); read_a(ah, 0, 1, false); read_a(ah, 0, 2, false); read_a(ah, 0, 3, false);
+    STAMP(1);
+
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        // keeps the per-voxel offsets from being hoisted out of the chunk loop as 64-bit pairs
+        asm volatile("" : "+v"(gv0));
+        const int ch_next = ch + 1 < p.nchunks ? ch + 1 : ch;       // (past the end: the last chunk again, unconditional like the DMAs)
+        // (a generic lambda over integral constants, not `#pragma unroll`: hipcc unrolls a 20-step body of this size only in part, and a step
+        // index that is not a constant turns acc[t] into scratch memory)
+        static_for<NS>([&](auto S_) {
+            constexpr int s = decltype(S_)::value, sn = (s + 1) % NS;
+            constexpr int t = s / 5, ws = s & (RING - 1), ws1 = (s + 1) & (RING - 1);
+            // ---- pass A: al(s).bh(s), row-group major.  al(s) (requested in pass A of the step before) and bh(s) (in its pass B) are back
+            // once at most the four ah reads of its pass C — and the stores at that pass's head — are out.
+            {
+                constexpr int n_out = 4;
+                switch (stores_at_head(3 * s - 1)) {
+                case 0: DM3D_WAIT_LGKM(n_out); break;
+                case 2: DM3D_WAIT_LGKM(n_out + 2); break;
+                case 4: DM3D_WAIT_LGKM(n_out + 4); break;
+                default: DM3D_WAIT_LGKM(n_out + 8); break;
+                }
+            }
+            head_stores(3 * s);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                DM3D_MFMA(t, g >> 2, g & 3, al, bh);
+                slot_gap(16 * (3 * s) + g);
+                if (g == 3) { read_b(bl, ws, 0, true); read_b(bl, ws, 1, true); }
+                if (g == 7) { read_b(bl, ws, 2, true); read_b(bl, ws, 3, true); read_a(al, sn, 0, true); }
+                if (g == 11) { read_a(al, sn, 1, true); read_a(al, sn, 2, true); }
+                if (g == 15) read_a(al, sn, 3, true);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- pass B: ah(s).bh(s), column-tile major.  Its head is the step's one barrier: behind this wave's lgkmcnt(4) (its reads of
+            // step s's buffer — bh, bl — are back; al of the next step may be out) and vmcnt(N) (its pieces of step s + 1 have landed) it
+            // frees step s's buffer for the DMA of step s + 4 and makes step s + 1 visible to everyone.  Newer than this wave's pieces of
+            // step s + 1 (issued in B(s - 3)): the pieces of steps s + 2, s + 3 and the halo requests of B(s - 3) .. B(s - 1).
+            {
+                constexpr int DMA_BEHIND = 2 * WSLOT;
+                const int extra = halo_ops(s - 3) + halo_ops(s - 2) + halo_ops(s - 1);
+                // (the builtin, not inline asm: hipcc's own wait-count pass must see it.)  simm16 = vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 4 << 8 | vmcnt[5:4] << 14
+#define DM3D_WAIT_VM_LGKM4(n) __builtin_amdgcn_s_waitcnt((((n) & 15) | (7 << 4) | (4 << 8) | ((((n) >> 4) & 3) << 14)))
+                switch (extra) {
+                case 0:  DM3D_WAIT_VM_LGKM4(DMA_BEHIND); break;
+                case 4:  DM3D_WAIT_VM_LGKM4(DMA_BEHIND + 4); break;
+                case 8:  DM3D_WAIT_VM_LGKM4(DMA_BEHIND + 8); break;
+                case 12: DM3D_WAIT_VM_LGKM4(DMA_BEHIND + 12); break;
+                case 16: DM3D_WAIT_VM_LGKM4(DMA_BEHIND + 16); break;
+                default: DM3D_WAIT_VM_LGKM4(0); break;
+                }
+#undef DM3D_WAIT_VM_LGKM4
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_w1(sq + RING, ws, 0);              // into the buffer step s just left (an LDS-DMA piece costs ~60 cycles of issue: the second one two gaps on)
+            head_stores(3 * s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                DM3D_MFMA(t, g & 3, g >> 2, ah, bh);
+                slot_gap(16 * (3 * s + 1) + g);
+                if ((g & 3) == 3) read_b(bh, ws1, g >> 2, false);
+                if (g == 1) fetch_w1(sq + RING, ws, 1);
+                if (s < NLD && g == 5) load_voxel(ch_next, 2 * s);
+                if (s < NLD && g == 9) load_voxel(ch_next, 2 * s + 1);
+                if (s == 0 && g == 13) load_chunk_params(ch_next);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- pass C: ah(s).bl(s), row-group major; requests ah of the next step
+            head_stores(3 * s + 2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                DM3D_MFMA(t, g >> 2, g & 3, ah, bl);
+                slot_gap(16 * (3 * s + 2) + g);
+                if ((g & 3) == 3) read_a(ah, sn, g >> 2, false);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ++sq;
+        });
+    }
+#undef DM3D_MFMA
+#undef DM3D_WAIT_LGKM
+#undef DM3D_PIN
+#undef DM3D_DSR
+    STAMP(28);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // the redundant tail fetches / reads
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // ---- output transform, then the shared epilogue once per slice: tile (2g + parity, ni) of slice s = rows 4g .. 4g+3, x = 2 * xpair + parity
+    const Brick br = {b, oz0, oy0, ox0, p.ooz, p.ooy, p.oox, ntile, 0};
+    // The transformed outputs go through LDS (free now; each thread reads back only what it wrote: no barrier): with 256 accumulator
+    // registers, 128 of outputs and the epilogue's own operands (64 registers of residual per slice) alive together hipcc spilled
+    // registers INSIDE the step loop — and every scratch reload there waits vmcnt(0), i.e. for the weight DMA and halo requests in flight.
+    f32x4v* lds_e = reinterpret_cast<f32x4v*>(smem_w);                    // [32 tiles][256 threads] x 16 bytes = 128 KB
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const f32x4v m0 = acc[0][2 * s + g][ni], m1 = acc[1][2 * s + g][ni], m2 = acc[2][2 * s + g][ni], m3 = acc[3][2 * s + g][ni];
+                lds_e[((s * 4 + 2 * g) * 4 + ni) * 256 + tid] = (m0 + m1) + m2;
+                lds_e[((s * 4 + 2 * g + 1) * 4 + ni) * 256 + tid] = (m1 - m2) - m3;
+            }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4v e[4][4];
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) e[pi][ni] = lds_e[((s * 4 + pi) * 4 + ni) * 256 + tid];
+        epilogue<TD, 4>(p, e, br, 2 * wave + s, 1, 2 * (lane >> 4));
+    }
+    STAMP(29);
+}
+
+template <int MODE>
+int launch_w(ConvArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)(4 * 2 * 64 * REC + 10 * 10 * 17 * REC) * sizeof(_Float16);      // 32 KB of weights + 106 KB of image
+    static_assert(lds <= 160 * 1024, "one workgroup per CU");
+    static bool attr_set = false;
+    if (!attr_set) {
+        DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3w<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    H3v2Launch L;
+    if (int rc = dm3d_h3v2_pre_launch(a, 8, false, L, st)) return rc;
+    DM3D_REQUIRE(L.k.ksplit == 1 && !L.reduce, "conv: the Winograd form does not split Cin");
+    L.k.wpk = a.wpk_wino;
+    dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64), 1u);
+    hipLaunchKernelGGL((conv3d_igemm_h3w<MODE>), grid, dim3(256), lds, st, L.k);
+    if (int rc = dm3d_launch_check("conv3d_igemm_h3w")) return rc;
+    return dm3d_h3v2_post_launch(a, L, st);
+}
+
+}  // namespace
+
+// The Winograd form serves a k3 / stride-1 launch when the caller supplied the transformed image (wpk_wino), the volume is whole 8 x 8 x 8
+// bricks, there is no fused skip conv (its tail phase is written for one slice per wave), the grid gives every CU two workgroups in turn
+// (the same threshold as the 8-slice bricks of the direct kernel: DM3D_CONV_WIDE_WGS) and Cin is at least 96 (six 16-channel chunks,
+// DM3D_CONV_WINO_MINCHUNKS: its unoverlapped prologue and epilogue cost as much as four chunks; at 64 input channels the two kernels
+// tie, profiles/r03_wino_ab.log).  The input tensors must be below 4 GB (32-bit lane offsets).  DM3D_CONV_WINO=0 (A/B knob, read per
+// call): never.
+bool dm3d_conv_h3w_serves(const ConvArgs& a, int which) {
+    if (!a.wpk_wino || which != DM3D_CONV_K3S1 || a.parity || a.s_npairs > 0 || a.cout <= 32) return false;
+    if (a.od % 8 != 0 || a.oh % 8 != 0 || a.ow % 8 != 0 || a.padz != 1 || a.pady != 1 || a.padx != 1) return false;
+    const char* e = getenv("DM3D_CONV_WINO");
+    if (e && e[0] == '0') return false;
+    const char* mc = getenv("DM3D_CONV_WINO_MINCHUNKS");
+    if (a.nchunks < (mc ? atoi(mc) : 6)) return false;
+    const long long vox = (long long)a.batch * a.ind * a.inh * a.inw;
+    if (vox * (a.c1 > a.c2 ? a.c1 : a.c2) * 4 >= (1ll << 32)) return false;
+    const long wgs = (long)a.batch * (a.od / 8) * (a.oh / 8) * (a.ow / 8) * (a.coutpad / 64);
+    const char* w = getenv("DM3D_CONV_WIDE_WGS");
+    return wgs >= (w ? atol(w) : 512L);
+}
+
+int dm3d_conv_launch_h3w(ConvArgs& a, int which, hipStream_t st) {
+    (void)which;
+    if (a.x_h2) return launch_w<2>(a, st);
+    return a.pscale ? launch_w<1>(a, st) : launch_w<0>(a, st);
+}

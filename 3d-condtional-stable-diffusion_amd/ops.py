@@ -94,6 +94,18 @@ def pack_weights_h3f8(kernel: torch.Tensor, w_exp: int, mode: int = 0) -> torch.
     return out
 
 
+def pack_weights_h3w(kernel: torch.Tensor, w_exp: int, in_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Weight image of a k3 / stride-1 conv ([3,3,3,cin,cout]) for the Winograd-x form (conv3d(wpk_wino=...)): the x taps of every
+    (dz, dy, cin, cout) become the four F(2,3) terms; packed with the w_exp of the conv's main image."""
+    _f32c(kernel, "kernel")
+    if kernel.dim() != 5 or tuple(kernel.shape[:3]) != (3, 3, 3):
+        raise ValueError("kernel must be [3,3,3,cin,cout]")
+    cin, cout = kernel.shape[-2], kernel.shape[-1]
+    out = torch.empty(lib().dm3d_packed_weight_h3w_bytes(cin, cout) // 2, dtype=torch.float16, device=kernel.device)
+    check(lib().dm3d_pack_weights_h3w(kernel.data_ptr(), cin, cout, w_exp, _p(in_scale), out.data_ptr(), _st()), "pack_weights_h3w")
+    return out
+
+
 def pack_weights_up(kernel: torch.Tensor, h3: bool = False):
     """[3,3,3,Cin,Cout] kernel of an UpSample conv -> the 8 parity images dm3d_conv3d_ndhwc(upsample=1) expects.
     Returns wpk (fp32) or (wpk, w_exp) (h3)."""
@@ -135,7 +147,7 @@ def pack_weights_convt(kernel: torch.Tensor, h3: bool = False):
 
 def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False, pro_scale=None, pro_shift=None,
            vec=None, vec_idx=None, relu=False, res=None, precision=_lib.PREC_F32, w_exp=0, prelu_alpha=None,
-           relu_out=False, transpose=False, skip=None, x1_h2_channels=None, out_h2=False, post=None, wpk_f8=None) -> torch.Tensor:
+           relu_out=False, transpose=False, skip=None, x1_h2_channels=None, out_h2=False, post=None, wpk_f8=None, wpk_wino=None) -> torch.Tensor:
     """Conv3D(padding="same") on NDHWC with the fused prologue / concat / upsample / epilogue of dm3d_conv3d_ndhwc.
     ``skip=(sx1, sx2_or_None, skip_wpk)``: also accumulate Conv3D(cout, 1) of the raw concat(sx1, sx2) (H3, k3, stride 1).
     ``post=(scale, shift)``: out = silu(out*scale[c] + shift[c]) at the very end; ``out_h2``: store DM3D_FMT_H2;
@@ -178,6 +190,8 @@ def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False
         d.post_scale, d.post_shift = post[0].data_ptr(), post[1].data_ptr()
     if wpk_f8 is not None:
         d.wpk_f8 = wpk_f8.data_ptr()
+    if wpk_wino is not None:
+        d.wpk_wino = wpk_wino.data_ptr()
     if skip is not None:
         sx1, sx2, swpk = skip
         _f32c(sx1, "skip x1")

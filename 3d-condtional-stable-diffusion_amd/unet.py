@@ -17,6 +17,7 @@ What is hoisted out of the per-step work (none of it changes results, SURVEY.md 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -56,6 +57,7 @@ class _Conv:
         self.cin_pad = -(-cin // _lib.CIN_PAD) * _lib.CIN_PAD
         self.h2 = None              # DM3D_FMT_H2 copy of wpk ([cout_pad][cin_pad]) for the H3 GEMM
         self.wpk_f8 = None          # second image for the float8 cross-term form (precision "h3f8")
+        self.wpk_wino = None        # weight image of the Winograd-x form (dm3d_conv_desc.wpk_wino)
 
 
 class UNet:
@@ -74,6 +76,9 @@ class UNet:
         # (dm3d_conv_desc.wpk_f8; eps error 5-9e-5 instead of 5-8e-6, activations clamped at 448 instead of 65504).  Everything else
         # (GEMMs, attention, small grids) is plain "h3", which is what self.precision says from here on.
         self.f8 = precision == "h3f8"
+        # precision "h3": k3 / stride-1 convs with Cout > 32 also carry the Winograd-x image; the library uses it where that form is faster
+        # (large grids, Cin >= 96: dm3d_conv_tile_form() == 10).  DM3D_CONV_WINO=0 in the environment at construction: no second image.
+        self.wino = precision == "h3" and os.environ.get("DM3D_CONV_WINO", "1") != "0"
         self.precision_name = precision
         self.precision = "h3" if self.f8 else precision
         self.fuse_skip = os.environ.get("DM3D_FUSE_SKIP", "1") != "0"      # A/B switch: ResidualBlock 1x1 skip conv inside conv2's launch
@@ -157,6 +162,11 @@ class UNet:
                 wpk = torch.empty(lib().dm3d_packed_weight_h3p_bytes(taps, cin, cout) // 2, dtype=torch.float16, device=self.device)
                 check(lib().dm3d_pack_weights_h3p(raw.data_ptr(), taps, cin, cout, w_exp, _ptr(in_scale), wpk.data_ptr(), 0,
                                                   _stream()), "pack_weights_h3p")
+                if self.wino and taps == 27 and stride == 1 and cout > 32:
+                    cv = _Conv(wpk, self._dev(bias) if bias is not None else None, taps, cin, cout, _lib.PREC_H3, w_exp)
+                    cv.wpk_wino = torch.empty(lib().dm3d_packed_weight_h3w_bytes(cin, cout) // 2, dtype=torch.float16, device=self.device)
+                    check(lib().dm3d_pack_weights_h3w(raw.data_ptr(), cin, cout, w_exp, _ptr(in_scale), cv.wpk_wino.data_ptr(), _stream()), "pack_weights_h3w")
+                    return cv
                 if self.f8 and taps == 27:
                     f8img = torch.empty(lib().dm3d_packed_weight_h3f8_bytes(taps, cin, cout) // 2, dtype=torch.float16, device=self.device)
                     check(lib().dm3d_pack_weights_h3f8(raw.data_ptr(), taps, cin, cout, w_exp, _ptr(in_scale), f8img.data_ptr(), 0,
@@ -250,7 +260,8 @@ class UNet:
         """Bound on |activation| below which no H3 operand path can leave the float16 range (include/dm3d.h, range_flag): a raw
         consumer clamps at 65504; a consumer behind a folded BatchNormalization sees silu(x*scale + shift), |.| <= |x| max|scale| +
         max|shift|.  (GroupNormalization normalises per sample: |x_hat| <= sqrt(group size), no bound on x is needed.)"""
-        top = 448.0 if self.f8 else 65504.0          # the float8 cross-term form clamps activations at 448 (dm3d_h3.h)
+        # the float8 cross-term form clamps activations at 448 (dm3d_h3.h); the Winograd-x form splits sums of two activations (dm3d.h, wpk_wino)
+        top = 448.0 if self.f8 else (32752.0 if self.wino else 65504.0)
         lim = top
         if self.cfg.norm == "batch":
             s = self.state
@@ -556,6 +567,8 @@ class Plan:
         d.x1_fmt = _lib.FMT_H2 if x1_h2 else _lib.FMT_F32
         if w.wpk_f8 is not None:
             d.wpk_f8 = w.wpk_f8.data_ptr()
+        if w.wpk_wino is not None:
+            d.wpk_wino = w.wpk_wino.data_ptr()
         if self.range_flag is not None and w.precision == _lib.PREC_H3:
             d.range_flag, d.range_limit = self.range_flag.data_ptr(), self.net.range_limit
         skip_flops = 0.0
@@ -574,6 +587,8 @@ class Plan:
             kind = "conv_k3s2"
         elif form == 9:
             kind = "conv_f8_up" if upsample else ("conv_f8_h2in" if x1_h2 else "conv_f8")    # conv3d_igemm_h3f8<KS, MODE>: float8 cross terms
+        elif form == 10:
+            kind = "conv_wino_h2in" if x1_h2 else "conv_wino"                                # conv3d_igemm_h3w<MODE>: Winograd F(2,3) along x
         elif upsample:
             kind = "conv_up"            # 8 parity 2x2x2 convs
         elif w.cout <= 32 and w.precision == _lib.PREC_H3:
@@ -590,9 +605,10 @@ class Plan:
                           # algorithmic; a fused 1x1 skip conv counts its own FLOPs here
                           "flops": 2.0 * w.taps * w.cin * w.cout * self.B * eo ** 3 + skip_flops,
                           # MFMA work actually issued: the upsample conv runs as 8 parity convs of 8 taps on the low-res grid
-                          # (float8 form: 1 float16 + 2/2.25 float8-rate units per product, counted in float16-MFMA-equivalent FLOPs)
+                          # (float8 form: 1 float16 + 2/2.25 float8-rate units per product, counted in float16-MFMA-equivalent FLOPs;
+                          #  Winograd-x form: 40 k-steps per output pair — 36 + the zero pad tap — against 54, three passes each)
                           "exec_flops": (2.0 * (8 if upsample else w.taps) * w.cin * w.cout * self.B * eo ** 3 + skip_flops)
-                                        * ((1 + 2 / 2.25 if form == 9 else 3) if w.precision == _lib.PREC_H3 else 1),
+                                        * ((1 + 2 / 2.25 if form == 9 else (3 * 40 / 54 if form == 10 else 3)) if w.precision == _lib.PREC_H3 else 1),
                           "bytes": 4.0 * self.B * (edge_in ** 3 * (w.cin + (skip[2] + skip[3] if skip is not None else 0))
                                                    + eo ** 3 * w.cout)}))
 
@@ -895,7 +911,7 @@ class Plan:
                 check(lib().dm3d_gather_rows(tab.data_ptr(), tab.shape[0], ids.data_ptr(), buf.data_ptr(), buf.shape[0],
                                              buf.shape[1], st), "gather_rows")
 
-    _RANGE_OF = {"conv_f8": "conv", "conv_f8_h2in": "conv", "conv_f8_up": "conv", "conv_k3s1_td4": "conv", "conv_k1": "conv", "conv_k3s2": "conv", "conv_up": "conv", "conv_k3s1_n32": "conv", "conv_k3s1_h2in": "conv", "conv_k3s1": "conv",
+    _RANGE_OF = {"conv_wino": "conv", "conv_wino_h2in": "conv", "conv_f8": "conv", "conv_f8_h2in": "conv", "conv_f8_up": "conv", "conv_k3s1_td4": "conv", "conv_k1": "conv", "conv_k3s2": "conv", "conv_up": "conv", "conv_k3s1_n32": "conv", "conv_k3s1_h2in": "conv", "conv_k3s1": "conv",
                  "gemm": "attn", "gemm_h3": "attn", "attn_fused": "attn", "softmax": "attn", "layernorm": "attn", "groupnorm": "norm", "affine": "norm",
                  "range": "guard"}
 

@@ -21,9 +21,9 @@
 extern "C" {
 #endif
 
-#define DM3D_VERSION 107          /* major*100 + minor; the descriptor structs grew in 101 (w_layout), 102 (scratch), 103 (skip_*),
+#define DM3D_VERSION 108          /* major*100 + minor; the descriptor structs grew in 101 (w_layout), 102 (scratch), 103 (skip_*),
                                      104 (dm3d_attention), 105 (x1_fmt / out_fmt / post_*), 106 (ddpm seed_dev; conv/gemm range_flag; the
-                                     training entries), 107 (conv wpk_f8: the float8 cross-term form): a host built against an older header must be rebuilt */
+                                     training entries), 107 (conv wpk_f8: the float8 cross-term form), 108 (conv wpk_wino: the Winograd-x form): a host built against an older header must be rebuilt */
 
 #define DM3D_OK            0
 #define DM3D_EINVAL       -1      /* bad argument (shape, alignment, null pointer) */
@@ -108,6 +108,11 @@ int     dm3d_pack_weights_h3p(const float* keras_kernel, int32_t taps, int32_t c
 int64_t dm3d_packed_weight_h3f8_bytes(int32_t taps, int32_t cin, int32_t cout);
 int     dm3d_pack_weights_h3f8(const float* keras_kernel, int32_t taps, int32_t cin, int32_t cout, int32_t w_exp,
                                const float* in_scale, void* packed, int32_t mode, void* stream);
+/* image for dm3d_conv_desc.wpk_wino from a [3,3,3,Cin,Cout] kernel: the DM3D_WL_PAIR record format, per 16-channel chunk 20 steps
+ * (5 pairs of (dz, dy) taps, the tenth tap zero) x 4 transform terms u0 = g0, u1 = (g0+g1+g2)/2, u2 = (g0-g1+g2)/2, u3 = g2 of the x taps */
+int64_t dm3d_packed_weight_h3w_bytes(int32_t cin, int32_t cout);
+int     dm3d_pack_weights_h3w(const float* keras_kernel, int32_t cin, int32_t cout, int32_t w_exp, const float* in_scale, void* packed,
+                              void* stream);
 /* the layout dm3d_conv3d_ndhwc wants in wpk for a DM3D_PREC_H3 conv of this geometry (what w_layout must say) */
 int32_t dm3d_conv_weight_layout(int32_t ksize, int32_t stride, int32_t upsample, int32_t transpose, int32_t cout);
 /* image of a 1x1 kernel [cin, cout] for dm3d_conv_desc.skip_wpk (two 16-channel chunks per MFMA k-step) */
@@ -192,13 +197,20 @@ typedef struct dm3d_conv_desc {
        Packed by dm3d_pack_weights_h3f8 with THIS conv's w_exp.  The kernel uses it when the launch has enough bricks for its 8-slice form
        (dm3d_conv_tile_form() == 9) and no fused skip conv / hand-off output; otherwise wpk serves the launch as before.  NULL: never. */
     const void* wpk_f8;
+    /* Optional weight image of the Winograd F(2,3)-along-x form of a DM3D_PREC_H3 k3 / stride-1 conv with cout > 32 (dm3d_pack_weights_h3w,
+       packed with THIS conv's w_exp): two neighbouring outputs of a row from four transformed inputs — 36 instead of 54 MFMA k-steps per
+       output pair, same split-float16 products and float32 accumulation (results differ from the direct form in the last bits only).
+       The kernel uses it when the volume is whole 8x8x8 bricks, the launch has no fused skip conv and enough bricks
+       (dm3d_conv_tile_form() == 10); otherwise wpk serves the launch as before.  The transformed inputs are up to 2 max|x|: producers of
+       such a conv must keep |x| <= 32752 (pass range_limit <= 32752 to them).  NULL: never. */
+    const void* wpk_wino;
 } dm3d_conv_desc;
 
 int     dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream);
 int64_t dm3d_conv_scratch_bytes(const dm3d_conv_desc* d);
 /* Which tile form of the 16x16x32 conv kernels serves this descriptor: 8 (8 z-slices per brick, 512 threads, one workgroup per CU — launches
  * with enough bricks to give every CU two such workgroups in turn), 4 (4 slices, 256 threads, two workgroups per CU: small grids, the parity
- * form, launches with a fused skip conv, Cout <= 32), 9 (the 8-slice H3F8 form: wpk_f8 given and eligible), 0 (another kernel).  Profiling
+ * form, launches with a fused skip conv, Cout <= 32), 9 (the 8-slice H3F8 form: wpk_f8 given and eligible), 10 (the Winograd-x form: wpk_wino given and eligible; conv3d_igemm_h3w<MODE>), 0 (another kernel).  Profiling
  * harnesses use it to name the instantiation a launch runs (rocprofv3 lists conv3d_igemm_h3v3<KS, MODE, TD, NCT>; 9: conv3d_igemm_h3f8<KS, MODE>). */
 int32_t dm3d_conv_tile_form(const dm3d_conv_desc* d);
 

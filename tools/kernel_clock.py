@@ -34,7 +34,8 @@ def sustained(fn):
 rows_out = []
 if what == "conv":
     st = torch.zeros(4096 * 32, dtype=torch.int64, device=dev)
-    raw.dm3d_debug_set_stamps_conv(C.c_void_p(st.data_ptr()))
+    wino = os.environ.get("CLOCK_WINO") == "1"           # the Winograd-x form (dm3d_conv_h3w.hip): one wave per SIMD, 20 steps of 48 MFMAs per chunk
+    (raw.dm3d_debug_set_stamps_wino if wino else raw.dm3d_debug_set_stamps_conv)(C.c_void_p(st.data_ptr()))
     for name, e, cin, cout, res in (("32^3 64->64", 32, 64, 64, 1), ("32^3 192->64", 32, 192, 64, 0), ("16^3 128->128", 16, 128, 128, 1),
                                     ("16^3 384->128", 16, 384, 128, 0)):
         x = torch.randn(B, e, e, e, cin, device=dev)
@@ -44,6 +45,7 @@ if what == "conv":
         wpk, w_exp = ops.pack_weights_h3(k)
         kw = dict(bias=torch.randn(cout, device=dev), pro_scale=torch.rand(cin, device=dev) + 0.5, pro_shift=torch.randn(cin, device=dev) * 0.1,
                   res=torch.randn(B, e, e, e, cout, device=dev) if res else None, precision=_lib.PREC_H3, w_exp=w_exp)
+        if wino: kw["wpk_wino"] = ops.pack_weights_h3w(k, w_exp)
         st.zero_()
         ms = sustained(lambda: ops.conv3d(x, wpk, cout, 3, **kw))
         s = st.view(4096, 32).cpu().double()
@@ -52,13 +54,14 @@ if what == "conv":
         ok = dr > 0
         ghz = (dt[ok] / dr[ok] * 0.1)
         nch = cin // 16
-        mfma_cycles = 2 * nch * 14 * 48 * 16          # two waves per SIMD
+        mfma_cycles = nch * 20 * 48 * 16 if wino else 2 * nch * 14 * 48 * 16          # (direct form: two waves per SIMD)
         fl = 2.0 * 27 * cin * cout * B * e ** 3
         print(f"{name}: {ms:.3f} ms {fl / ms / 1e9:.0f} TF/s algorithmic | in-kernel clock median {ghz.median():.3f} GHz (p10 {ghz.quantile(0.1):.3f}, p90 {ghz.quantile(0.9):.3f}) "
               f"| chunk loop {dt.median():.0f} ticks = {dr.median() / 100:.1f} us, MFMA duty in the loop {mfma_cycles / dt.median():.3f} "
-              f"| {s.shape[0]} workgroups stamped; whole workgroup {((s[:, 29] - s[:, 0])[s[:, 29] > 0]).median() if (s[:, 29] > 0).any() else 0:.0f} ticks", flush=True)
+              f"| {s.shape[0]} workgroups stamped; whole workgroup {((s[:, 29] - s[:, 0])[s[:, 29] > 0]).median() if (s[:, 29] > 0).any() else 0:.0f} ticks "
+              f"(prologue {(s[:, 1] - s[:, 0]).median():.0f}, epilogue {((s[:, 29] - s[:, 28])[s[:, 29] > 0]).median() if (s[:, 29] > 0).any() else 0:.0f})", flush=True)
         rows_out.append((name, ms, fl / ms / 1e9, float(ghz.median()), float(ghz.quantile(0.1)), float(ghz.quantile(0.9)), mfma_cycles / float(dt.median())))
-    raw.dm3d_debug_set_stamps_conv(C.c_void_p(0))
+    (raw.dm3d_debug_set_stamps_wino if wino else raw.dm3d_debug_set_stamps_conv)(C.c_void_p(0))
 else:
     st = torch.zeros(2048 * 16, dtype=torch.int64, device=dev)
     raw.dm3d_debug_set_stamps(C.c_void_p(st.data_ptr()))
