@@ -232,18 +232,28 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
                     rv4[ni][pi] = *reinterpret_cast<const f32x4*>(resz + (((oy0 + 4 * (pi >> 1) + k) * p.os + ooy) * p.fw
                                                                           + (ox0 + xa * (pi & 1) + dxl) * p.os + oox) * p.cout + n0 + ni * 16 + c4);
         }
+        // Every load of this path comes before its first store: vmcnt counts loads and stores together, in order, so a bias / vector load
+        // behind the stores of the previous column tile waited out their whole write latency — four serialised round trips per slice,
+        // ~20 000 cycles of a 43 000-cycle epilogue where no other wave hides them (in-kernel stamps of the Winograd form, round 3).
+        f32x4 add_t[NCT], ps_t[NCT], pt_t[NCT];
 #pragma unroll
         for (int ni = 0; ni < NCT; ++ni) {
-            const int n = n0 + ni * 16 + c4;             // first of this lane's four channels
-            f32x4 add = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int n = n0 + ni * 16 + c4;
+            const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+            add_t[ni] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : zero;
             if (p.vec) {
                 const f32x4 vv = *reinterpret_cast<const f32x4*>(p.vec + (size_t)vrow * p.vec_ld + n);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) add[j] += vv[j];
+                for (int j = 0; j < 4; ++j) add_t[ni][j] += vv[j];
             }
-            const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 ps = p.post_scale ? *reinterpret_cast<const f32x4*>(p.post_scale + n) : one;
-            const f32x4 pt = p.post_scale ? *reinterpret_cast<const f32x4*>(p.post_shift + n) : zero;
+            ps_t[ni] = p.post_scale ? *reinterpret_cast<const f32x4*>(p.post_scale + n) : one;
+            pt_t[ni] = p.post_scale ? *reinterpret_cast<const f32x4*>(p.post_shift + n) : zero;
+        }
+#pragma unroll
+        for (int ni = 0; ni < NCT; ++ni) {
+            const int n = n0 + ni * 16 + c4;             // first of this lane's four channels
+            const f32x4 add = add_t[ni], ps = ps_t[ni], pt = pt_t[ni];
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             // DM3D_FMT_H2: the hi halves of channels n..n+3 are 8 contiguous bytes of the voxel's record, the lo halves 32 bytes further
             const int h2off = (n >> 4) * 64 + ((n >> 3) & 1) * 16 + (n & 7) * 2 - n * 4;
 #pragma unroll

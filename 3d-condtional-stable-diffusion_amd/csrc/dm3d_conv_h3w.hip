@@ -570,9 +570,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
                 lds_e[((s * 4 + 2 * g) * 4 + ni) * 256 + tid] = (m0 + m1) + m2;
                 lds_e[((s * 4 + 2 * g + 1) * 4 + ni) * 256 + tid] = (m1 - m2) - m3;
             }
+    STAMP(20);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         __builtin_amdgcn_sched_barrier(0);
+        if (s == 1) STAMP(21);
         f32x4v e[4][4];
 #pragma unroll
         for (int pi = 0; pi < 4; ++pi)

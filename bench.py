@@ -254,7 +254,8 @@ def main():
             per_kind[kind] = {"launches_per_step": n // reps, "ms_per_step": round(ms / reps, 4),
                               "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if fl else None}
         # the dominant kernel: the 8-slice form where the grid is large enough for it (B = 32), else the 4-slice form (small batches)
-        dom = "conv_f8" if "conv_f8" in acc else "conv_k3s1" if "conv_k3s1" in acc else "conv_k3s1_td4"
+        # (the kind with the most time per step among the k3 / stride-1 forms with the fused prologue; the float8 form wherever it runs)
+        dom = "conv_f8" if "conv_f8" in acc else max((k for k in ("conv_wino", "conv_k3s1", "conv_k3s1_td4") if k in acc), key=lambda k: acc[k][1])
         wide = dom == "conv_k3s1"
         n, ms, fl, by, ex = acc[dom]
         achieved = fl / (ms * 1e-3) / 1e12
@@ -263,6 +264,12 @@ def main():
                      "hi+lo split: hi.hi on v_mfma_f32_16x16x32_f16, both cross terms on one v_mfma_scale_f32_16x16x128_f8f6f4 "
                      "stream (float8 e4m3 copies of the halves), fp32 accumulate)")
             peak, passes = PEAK_F16_MFMA_TFLOPS, 1.5
+        elif dom == "conv_wino":
+            kname = ("conv3d_igemm_h3w<1> (k3 stride-1 Conv3d with the fused norm+SiLU prologue as Winograd F(2,3) along x: 8x8x8 bricks, one wave "
+                     "per SIMD with 256 accumulator registers, 40 k-steps per output pair instead of 54; float16 hi+lo split, 3 x "
+                     "v_mfma_f32_16x16x32_f16 per transformed product, fp32 accumulate; launches with Cin < 96 or small grids stay on the direct "
+                     "kernel conv3d_igemm_h3v3, listed as conv_k3s1 / conv_k3s1_td4)")
+            peak, passes = PEAK_F16_MFMA_TFLOPS, round(3 * 40 / 54, 3)
         elif args.precision in ("h3", "h3f8"):
             kname = ("conv3d_igemm_h3v3<3, 1, 8, 4> (k3 stride-1 Conv3d with the fused norm+SiLU prologue, 8-slice bricks, free-running "
                      "software-pipelined waves; float16 hi+lo split, 3 x v_mfma_f32_16x16x32_f16 per algorithmic product, fp32 accumulate; "
@@ -294,7 +301,8 @@ def main():
         import csv
         import glob
         want = "conv3d_igemm_h3f8<3, 1>" if "conv_f8" in per_kind else \
-            ("conv3d_igemm_h3v3<3, 1, 8, 4>" if "conv_k3s1" in per_kind else "conv3d_igemm_h3v3<3, 1, 4, 4>") if args.precision != "fp32" \
+            ("conv3d_igemm_h3w<1>" if roofline["kernel"].startswith("conv3d_igemm_h3w") else
+             "conv3d_igemm_h3v3<3, 1, 8, 4>" if "conv_k3s1" in per_kind else "conv3d_igemm_h3v3<3, 1, 4, 4>") if args.precision != "fp32" \
             else "conv3d_igemm_f32<4, 8, 8, 1, 3, 4, 1>"
         sig = f"batch={B} size={S} channels={Cc} norm={args.norm} precision={args.precision} csrc={csrc_digest()}"
         reason = "no profiles/*_pmc_hbm.csv records this workload and these kernel sources: " + sig

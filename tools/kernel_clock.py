@@ -60,6 +60,7 @@ if what == "conv":
               f"| chunk loop {dt.median():.0f} ticks = {dr.median() / 100:.1f} us, MFMA duty in the loop {mfma_cycles / dt.median():.3f} "
               f"| {s.shape[0]} workgroups stamped; whole workgroup {((s[:, 29] - s[:, 0])[s[:, 29] > 0]).median() if (s[:, 29] > 0).any() else 0:.0f} ticks "
               f"(prologue {(s[:, 1] - s[:, 0]).median():.0f}, epilogue {((s[:, 29] - s[:, 28])[s[:, 29] > 0]).median() if (s[:, 29] > 0).any() else 0:.0f})", flush=True)
+        if wino: print(f"    epilogue stamps: accumulators -> LDS {(s[:, 20] - s[:, 28]).median():.0f}, slice 0 {(s[:, 21] - s[:, 20]).median():.0f}, slice 1 {((s[:, 29] - s[:, 21])[s[:, 29] > 0]).median():.0f} ticks", flush=True)
         rows_out.append((name, ms, fl / ms / 1e9, float(ghz.median()), float(ghz.quantile(0.1)), float(ghz.quantile(0.9)), mfma_cycles / float(dt.median())))
     (raw.dm3d_debug_set_stamps_wino if wino else raw.dm3d_debug_set_stamps_conv)(C.c_void_p(0))
 else:
