@@ -345,7 +345,19 @@ def main():
             lines = open(path).read().splitlines()
             if not any(l.startswith("# workload: ") and l.strip().endswith("csrc=" + csrc_digest()) for l in lines):
                 continue
+            is_wino = any(l.startswith("# workload: kernel_clock conv wino") for l in lines)
+            if is_wino != roofline["kernel"].startswith("conv3d_igemm_h3w"):
+                continue                                # the clock of another kernel (profile_round.sh writes one file per conv form)
             rows = list(csv.DictReader(l for l in lines if not l.startswith("#")))
+            if rows and is_wino:
+                vals = sorted(float(r["clock_ghz_median"]) for r in rows)
+                roofline["clock_ghz"] = vals[len(vals) // 2]
+                roofline["clock_note"] = ("in-kernel shader clock of the Winograd-x conv kernel under sustained load on random data (median of " +
+                                          ", ".join(f'{r["shape"]}: {r["clock_ghz_median"]}' for r in rows) + " GHz; matrix-pipe duty inside the chunk loop " +
+                                          ", ".join(r["mfma_duty_in_loop"] for r in rows) + "; " + os.path.basename(path) +
+                                          "); one wave per SIMD: this kernel is bound by what a single wave can issue beside its MFMAs, not by the chip's "
+                                          "power management — the direct two-waves-per-SIMD kernel it replaces on these launches is (DESIGN.md section 4)")
+                break
             if rows:
                 vals = sorted(float(r["clock_ghz_median"]) for r in rows)
                 roofline["clock_ghz"] = vals[len(vals) // 2]

@@ -8,7 +8,7 @@ out=$PWD/gpurun_out; mkdir -p $out
 timeout -k 10 1100 python3 -m pytest tests -x -q -m gpu > $out/${tag}_gpu_tests.log 2>&1 || { tail -40 $out/${tag}_gpu_tests.log; exit 1; }
 tail -2 $out/${tag}_gpu_tests.log
 bash tools/profile_round.sh ${tag}_h3 h3
-mkdir -p $out/keep && cp $out/${tag}_h3_pmc_hbm.csv $out/${tag}_h3_sq.csv $out/${tag}_h3_clock.csv profiles/      # so that the bench below attaches them
+mkdir -p $out/keep && cp $out/${tag}_h3_pmc_hbm.csv $out/${tag}_h3_sq.csv $out/${tag}_h3_clock.csv $out/${tag}_h3_clockv3.csv profiles/      # so that the bench below attaches them
 python3 bench.py --steps 30 --warmup 5 2> $out/${tag}_h3_bench.log | tail -1 > $out/${tag}_h3_bench.json
 python3 bench.py --batch 4 --channels 4 --steps 50 --warmup 5 --no-fp32-mode --no-h3f8-mode 2> /dev/null | tail -1 > $out/${tag}_h3_config2_bench.json
 python3 bench.py --batch 1 --steps 50 --warmup 5 --no-cpu-baseline --no-fp32-mode --no-h3f8-mode --no-full-chain 2> /dev/null | tail -1 > $out/${tag}_h3_b1_bench.json

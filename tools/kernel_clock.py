@@ -36,8 +36,9 @@ if what == "conv":
     st = torch.zeros(4096 * 32, dtype=torch.int64, device=dev)
     wino = os.environ.get("CLOCK_WINO") == "1"           # the Winograd-x form (dm3d_conv_h3w.hip): one wave per SIMD, 20 steps of 48 MFMAs per chunk
     (raw.dm3d_debug_set_stamps_wino if wino else raw.dm3d_debug_set_stamps_conv)(C.c_void_p(st.data_ptr()))
-    for name, e, cin, cout, res in (("32^3 64->64", 32, 64, 64, 1), ("32^3 192->64", 32, 192, 64, 0), ("16^3 128->128", 16, 128, 128, 1),
-                                    ("16^3 384->128", 16, 384, 128, 0)):
+    # (the Winograd form serves Cin >= 96: its first shape is the smallest conv of the U-Net that takes it)
+    for name, e, cin, cout, res in ((("32^3 96->64", 32, 96, 64, 0) if wino else ("32^3 64->64", 32, 64, 64, 1)), ("32^3 192->64", 32, 192, 64, 0),
+                                    ("16^3 128->128", 16, 128, 128, 1), ("16^3 384->128", 16, 384, 128, 0)):
         x = torch.randn(B, e, e, e, cin, device=dev)
         k = torch.randn(3, 3, 3, cin, cout, device=dev) * 0.05
         if os.environ.get("CLOCK_ZEROS") == "1":      # all-zero operands: the clock the chip holds when the data costs no switching power
@@ -88,8 +89,9 @@ if os.environ.get("CLOCK_OUT") and rows_out:
     import bench
     with open(os.environ["CLOCK_OUT"], "w") as f:
         f.write("# in-kernel shader clock = delta(s_memtime) / delta(s_memrealtime) x 100 MHz around the chunk loop, median over workgroups, after "
-                f"{SECONDS:.0f} s of back-to-back launches on {'ZERO' if os.environ.get('CLOCK_ZEROS') == '1' else 'random'} data (tools/kernel_clock.py conv, B=32, k3 conv with norm+SiLU prologue)\n")
-        f.write(f"# workload: kernel_clock conv csrc={bench.csrc_digest()}\n")
+                f"{SECONDS:.0f} s of back-to-back launches on {'ZERO' if os.environ.get('CLOCK_ZEROS') == '1' else 'random'} data (tools/kernel_clock.py conv, B=32, k3 conv with norm+SiLU prologue; "
+                f"kernel {'conv3d_igemm_h3w<1> (Winograd-x form, CLOCK_WINO=1)' if wino else 'conv3d_igemm_h3v3<3, 1, 8, 4> (direct form)'})\n")
+        f.write(f"# workload: kernel_clock conv{' wino' if wino else ''} csrc={bench.csrc_digest()}\n")
         f.write("shape,ms,algorithmic_tflops,clock_ghz_median,clock_ghz_p10,clock_ghz_p90,mfma_duty_in_loop\n")
         for r in rows_out:
             f.write(f'"{r[0]}",{r[1]:.4f},{r[2]:.1f},{r[3]:.3f},{r[4]:.3f},{r[5]:.3f},{r[6]:.3f}\n')

@@ -31,8 +31,12 @@ python3 profiles/summarize_sq.py $out/${tag}_sq.csv \
   "batch=32 size=32 channels=8 norm=batch precision=$prec csrc=$(python3 bench.py --print-csrc-digest)" $out/prof_sqA $out/prof_sqB | head -6 | cut -c1-400
 # 5. in-kernel clock of the conv kernel (diagnostic library variants/cck.so: python3 tools/mk_stamp_variants.py) -> <tag>_clock.csv
 if [ -f 3d-condtional-stable-diffusion_amd/csrc/variants/cck.so ]; then
-  CLOCK_OUT=$out/${tag}_clock.csv DM3D_LIB=$PWD/3d-condtional-stable-diffusion_amd/csrc/variants/cck.so python3 tools/kernel_clock.py conv > $out/${tag}_clock.log 2>&1 || tail -5 $out/${tag}_clock.log
-  CLOCK_ZEROS=1 CLOCK_OUT=$out/${tag}_clock_zeros.txt DM3D_LIB=$PWD/3d-condtional-stable-diffusion_amd/csrc/variants/cck.so python3 tools/kernel_clock.py conv > $out/${tag}_clock_zeros.log 2>&1 || true
-  cat $out/${tag}_clock.csv
+  # <tag>_clock.csv: the Winograd-x form (the dominant kernel at B = 32 since round 3); <tag>_clockv3.csv: the direct free-running kernel
+  lib=$PWD/3d-condtional-stable-diffusion_amd/csrc/variants/cck.so
+  CLOCK_WINO=1 CLOCK_OUT=$out/${tag}_clock.csv DM3D_LIB=$lib python3 tools/kernel_clock.py conv > $out/${tag}_clock.log 2>&1 || tail -5 $out/${tag}_clock.log
+  CLOCK_WINO=1 CLOCK_ZEROS=1 CLOCK_OUT=$out/${tag}_clock_zeros.txt DM3D_LIB=$lib python3 tools/kernel_clock.py conv > $out/${tag}_clock_zeros.log 2>&1 || true
+  DM3D_CONV_WINO=0 CLOCK_OUT=$out/${tag}_clockv3.csv DM3D_LIB=$lib python3 tools/kernel_clock.py conv > $out/${tag}_clockv3.log 2>&1 || tail -5 $out/${tag}_clockv3.log
+  DM3D_CONV_WINO=0 CLOCK_ZEROS=1 CLOCK_OUT=$out/${tag}_clockv3_zeros.txt DM3D_LIB=$lib python3 tools/kernel_clock.py conv > $out/${tag}_clockv3_zeros.log 2>&1 || true
+  cat $out/${tag}_clock.csv $out/${tag}_clockv3.csv
 fi
 rm -rf $out/prof_stats $out/prof_FETCH_SIZE $out/prof_WRITE_SIZE $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/prof_sqA $out/prof_sqB
