@@ -249,54 +249,69 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
             ps_t[ni] = p.post_scale ? *reinterpret_cast<const f32x4*>(p.post_scale + n) : one;
             pt_t[ni] = p.post_scale ? *reinterpret_cast<const f32x4*>(p.post_shift + n) : zero;
         }
-#pragma unroll
-        for (int ni = 0; ni < NCT; ++ni) {
-            const int n = n0 + ni * 16 + c4;             // first of this lane's four channels
-            const f32x4 add = add_t[ni], ps = ps_t[ni], pt = pt_t[ni];
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            // DM3D_FMT_H2: the hi halves of channels n..n+3 are 8 contiguous bytes of the voxel's record, the lo halves 32 bytes further
-            const int h2off = (n >> 4) * 64 + ((n >> 3) & 1) * 16 + (n & 7) * 2 - n * 4;
-#pragma unroll
-            for (int pi = 0; pi < 4; ++pi) {
-                float a[4] = {acc[pi][ni][0], acc[pi][ni][1], acc[pi][ni][2], acc[pi][ni][3]};
-                {   // quad transpose: a[j] of lane k  <-  a[k] of lane j
-                    float s0 = b0 ? a[0] : a[1], s1 = b0 ? a[2] : a[3];
-                    float r0 = xor1(s0), r1 = xor1(s1);
-                    if (b0) { a[0] = r0; a[2] = r1; } else { a[1] = r0; a[3] = r1; }
-                    s0 = b1 ? a[0] : a[2]; s1 = b1 ? a[1] : a[3];
-                    r0 = xor2(s0); r1 = xor2(s1);
-                    if (b1) { a[0] = r0; a[1] = r1; } else { a[2] = r0; a[3] = r1; }
-                }
-                const int o = (((oy0 + 4 * (pi >> 1) + k) * p.os + ooy) * p.fw + (ox0 + xa * (pi & 1) + dxl) * p.os + oox) * p.cout + n;
-                f32x4 al4 = zero;
-                if (prz) al4 = *reinterpret_cast<const f32x4*>(prz + o);
-                f32x4 v4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = fmaf(a[j], p.out_scale, add[j]);
-                    if (p.relu) v = fmaxf(v, 0.0f);
-                    if (prz) v = v > 0.0f ? v : al4[j] * v;
-                    if (resz) v += rv4[ni][pi][j];
-                    if (p.relu_out) v = fmaxf(v, 0.0f);
-                    if (p.post_scale) v = dm3d_silu(fmaf(v, ps[j], pt[j]));           // the consumer's norm + SiLU, applied once here
-                    DM3D_AMAX(amax, v);
-                    v4[j] = v;
-                }
-                if (p.out_h2) {
-                    const unsigned int w0 = split1_bits(v4[0]), w1 = split1_bits(v4[1]), w2 = split1_bits(v4[2]), w3 = split1_bits(v4[3]);
-                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                    char* dst = reinterpret_cast<char*>(outz) + (size_t)o * 4 + h2off;
-                    *reinterpret_cast<u32x2*>(dst) = u32x2{(w0 & 0xffffu) | (w1 << 16), (w2 & 0xffffu) | (w3 << 16)};
-                    *reinterpret_cast<u32x2*>(dst + 32) = u32x2{(w0 >> 16) | (w1 & 0xffff0000u), (w2 >> 16) | (w3 & 0xffff0000u)};
-                } else {
-                    *reinterpret_cast<f32x4*>(outz + o) = v4;
+        // The two rare options are compile-time forms of the loop: as run-time tests of uniform flags hipcc if-converted them, i.e. every
+        // element paid the consumer's SiLU (v_exp_f32, v_rcp_f32) and the DM3D_FMT_H2 split and then selected them away — 164 instructions
+        // per tile instead of ~60, 12 500 cycles per slice where no other wave hides them (in-kernel stamps of the Winograd form, round 3).
+        auto tiles = [&](auto POST_T, auto H2_T) {
+            constexpr bool POST = decltype(POST_T)::value, H2 = decltype(H2_T)::value;
+    #pragma unroll
+            for (int ni = 0; ni < NCT; ++ni) {
+                const int n = n0 + ni * 16 + c4;             // first of this lane's four channels
+                const f32x4 add = add_t[ni], ps = ps_t[ni], pt = pt_t[ni];
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                // DM3D_FMT_H2: the hi halves of channels n..n+3 are 8 contiguous bytes of the voxel's record, the lo halves 32 bytes further
+                const int h2off = (n >> 4) * 64 + ((n >> 3) & 1) * 16 + (n & 7) * 2 - n * 4;
+    #pragma unroll
+                for (int pi = 0; pi < 4; ++pi) {
+                    float a[4] = {acc[pi][ni][0], acc[pi][ni][1], acc[pi][ni][2], acc[pi][ni][3]};
+                    {   // quad transpose: a[j] of lane k  <-  a[k] of lane j
+                        float s0 = b0 ? a[0] : a[1], s1 = b0 ? a[2] : a[3];
+                        float r0 = xor1(s0), r1 = xor1(s1);
+                        if (b0) { a[0] = r0; a[2] = r1; } else { a[1] = r0; a[3] = r1; }
+                        s0 = b1 ? a[0] : a[2]; s1 = b1 ? a[1] : a[3];
+                        r0 = xor2(s0); r1 = xor2(s1);
+                        if (b1) { a[0] = r0; a[1] = r1; } else { a[2] = r0; a[3] = r1; }
+                    }
+                    const int o = (((oy0 + 4 * (pi >> 1) + k) * p.os + ooy) * p.fw + (ox0 + xa * (pi & 1) + dxl) * p.os + oox) * p.cout + n;
+                    f32x4 al4 = zero;
+                    if (prz) al4 = *reinterpret_cast<const f32x4*>(prz + o);
+                    f32x4 v4;
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = fmaf(a[j], p.out_scale, add[j]);
+                        if (p.relu) v = fmaxf(v, 0.0f);
+                        if (prz) v = v > 0.0f ? v : al4[j] * v;
+                        if (resz) v += rv4[ni][pi][j];
+                        if (p.relu_out) v = fmaxf(v, 0.0f);
+                        if constexpr (POST) v = dm3d_silu(fmaf(v, ps[j], pt[j]));         // the consumer's norm + SiLU, applied once here
+                        DM3D_AMAX(amax, v);
+                        v4[j] = v;
+                    }
+                    if constexpr (H2) {
+                        const unsigned int w0 = split1_bits(v4[0]), w1 = split1_bits(v4[1]), w2 = split1_bits(v4[2]), w3 = split1_bits(v4[3]);
+                        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                        char* dst = reinterpret_cast<char*>(outz) + (size_t)o * 4 + h2off;
+                        *reinterpret_cast<u32x2*>(dst) = u32x2{(w0 & 0xffffu) | (w1 << 16), (w2 & 0xffffu) | (w3 << 16)};
+                        *reinterpret_cast<u32x2*>(dst + 32) = u32x2{(w0 >> 16) | (w1 & 0xffff0000u), (w2 >> 16) | (w3 & 0xffff0000u)};
+                    } else {
+                        *reinterpret_cast<f32x4*>(outz + o) = v4;
+                    }
                 }
             }
-        }
+        };
+        const std::true_type yes_t;
+        const std::false_type no_t;
+        if (p.post_scale) { if (p.out_h2) tiles(yes_t, yes_t); else tiles(yes_t, no_t); }
+        else { if (p.out_h2) tiles(no_t, yes_t); else tiles(no_t, no_t); }
         if (p.range_flag && amax > rlim) *p.range_flag = 1;
         return;
     }
 #endif
+    // The slower forms below start from opaque copies of the lane's channel and column: without them hipcc computes THEIR per-element
+    // 64-bit addresses (a thousand instructions, a hundred scratch stores) in front of the branch, i.e. also on the way into the 16-byte
+    // form above — 12 500 cycles at the head of every epilogue (in-kernel stamps of the Winograd form, round 3: 15 900 -> 3 400).
+    int rowq = row, dxq = dxl;
+    asm volatile("" : "+v"(rowq), "+v"(dxq));
     if (full) {
         // full brick, scalar form (split-K launches add their halves atomically; -DDM3D_EPILOGUE_SCALAR: the A/B arm of the form above):
         // all 64 residual values of this lane are requested before the first one is used
@@ -309,11 +324,11 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         rv[ni][pi][r] = resz[((oy0 + 4 * (pi >> 1)) * p.os + ooy) * p.fw * p.cout
-                                             + ((ox0 + xa * (pi & 1) + dxl) * p.os + oox) * p.cout + n0 + ni * 16 + row + r * ystep];
+                                             + ((ox0 + xa * (pi & 1) + dxq) * p.os + oox) * p.cout + n0 + ni * 16 + rowq + r * ystep];
         }
 #pragma unroll
         for (int ni = 0; ni < NCT; ++ni) {
-            const int n = n0 + ni * 16 + row;
+            const int n = n0 + ni * 16 + rowq;
             float add = p.bias ? p.bias[n] : 0.0f;
             if (p.vec) add += p.vec[(size_t)vrow * p.vec_ld + n];
             if (!lead) add = 0.0f;
@@ -322,7 +337,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
             const int h2col = (n >> 4) * 64 + ((n >> 3) & 1) * 16 + ((n & 7) >> 1) * 4 + (n & 1) * 32 - n * 4;
 #pragma unroll
             for (int pi = 0; pi < 4; ++pi) {
-                const int base = (((oy0 + 4 * (pi >> 1)) * p.os + ooy) * p.fw + (ox0 + xa * (pi & 1) + dxl) * p.os + oox) * p.cout + n;
+                const int base = (((oy0 + 4 * (pi >> 1)) * p.os + ooy) * p.fw + (ox0 + xa * (pi & 1) + dxq) * p.os + oox) * p.cout + n;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int o = base + r * ystep;
@@ -351,7 +366,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
     }
 #pragma unroll
     for (int ni = 0; ni < NCT; ++ni) {
-        const int n = n0 + ni * 16 + row;
+        const int n = n0 + ni * 16 + rowq;
         const bool n_ok = n < p.cout;
         const int nc = n_ok ? n : p.cout - 1;
         float add = p.bias ? p.bias[nc] : 0.0f;
@@ -359,7 +374,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
         if (!lead) add = 0.0f;
 #pragma unroll
         for (int pi = 0; pi < 4; ++pi) {
-            const int oyb = oy0 + 4 * (pi >> 1), ox = ox0 + xa * (pi & 1) + dxl;
+            const int oyb = oy0 + 4 * (pi >> 1), ox = ox0 + xa * (pi & 1) + dxq;
             const int base = ((oyb * p.os + ooy) * p.fw + ox * p.os + oox) * p.cout + nc;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -41,9 +41,10 @@
 // at pass heads, where the counted LDS waits can account for them.  The MFMAs are inline asm with the accumulator constrained to AGPRs (left
 // alone, hipcc's allocator shuffled accumulator tiles between AGPRs, VGPRs and scratch, and a scratch reload in this loop costs a vmcnt(0)).
 // First forms of this loop (staging in per-pass bursts; packed VALU; spills) ran at 0.54 MFMA duty and lost to the direct kernel; this one
-// holds 0.63-0.65 at 2.05-2.2 GHz — the chip is NOT at its power limit under it — and takes 7-17 % less time than the direct kernel from
-// 96 input channels up (profiles/r03_wino_*.log).  The prologue and the epilogue (the shared one, once per slice) run unoverlapped — one
-// workgroup per CU — and cost 18 % of a 12-chunk workgroup: the launcher keeps launches with few chunks on the direct kernel.
+// holds 0.63-0.65 at 2.05-2.2 GHz (the same duty on all-zero operands: bound in cycles by single-wave issue, not by the power limit) and
+// takes 7-18 % less time than the direct kernel from 64 input channels up (profiles/r03_wino_*.log).  The prologue and the epilogue
+// (the shared one, once per slice) run unoverlapped — one workgroup per CU — and cost 15 % of a 12-chunk workgroup, a third of a
+// 4-chunk one: the launcher keeps launches with fewer chunks on the direct kernel.
 #include <cstdlib>
 #include "dm3d_conv_h3v2_parts.h"
 
@@ -608,9 +609,9 @@ int launch_w(ConvArgs& a, hipStream_t st) {
 
 // The Winograd form serves a k3 / stride-1 launch when the caller supplied the transformed image (wpk_wino), the volume is whole 8 x 8 x 8
 // bricks, there is no fused skip conv (its tail phase is written for one slice per wave), the grid gives every CU two workgroups in turn
-// (the same threshold as the 8-slice bricks of the direct kernel: DM3D_CONV_WIDE_WGS) and Cin is at least 96 (six 16-channel chunks,
-// DM3D_CONV_WINO_MINCHUNKS: its unoverlapped prologue and epilogue cost as much as four chunks; at 64 input channels the two kernels
-// tie, profiles/r03_wino_ab.log).  The input tensors must be below 4 GB (32-bit lane offsets).  DM3D_CONV_WINO=0 (A/B knob, read per
+// (the same threshold as the 8-slice bricks of the direct kernel: DM3D_CONV_WIDE_WGS) and Cin is at least 64 (four 16-channel chunks,
+// DM3D_CONV_WINO_MINCHUNKS: its unoverlapped prologue and epilogue cost as much as two chunks; at 64 input channels it is 7 % ahead of
+// the direct kernel, profiles/r03_wino_ab.log).  The input tensors must be below 4 GB (32-bit lane offsets).  DM3D_CONV_WINO=0 (A/B knob, read per
 // call): never.
 bool dm3d_conv_h3w_serves(const ConvArgs& a, int which) {
     if (!a.wpk_wino || which != DM3D_CONV_K3S1 || a.parity || a.s_npairs > 0 || a.cout <= 32) return false;
@@ -618,7 +619,7 @@ bool dm3d_conv_h3w_serves(const ConvArgs& a, int which) {
     const char* e = getenv("DM3D_CONV_WINO");
     if (e && e[0] == '0') return false;
     const char* mc = getenv("DM3D_CONV_WINO_MINCHUNKS");
-    if (a.nchunks < (mc ? atoi(mc) : 6)) return false;
+    if (a.nchunks < (mc ? atoi(mc) : 4)) return false;
     const long long vox = (long long)a.batch * a.ind * a.inh * a.inw;
     if (vox * (a.c1 > a.c2 ? a.c1 : a.c2) * 4 >= (1ll << 32)) return false;
     const long wgs = (long)a.batch * (a.od / 8) * (a.oh / 8) * (a.ow / 8) * (a.coutpad / 64);

@@ -104,7 +104,7 @@ def test_winograd_hand_off_pair(dev, small_grids, dims):
 
 
 def test_winograd_launch_policy(dev, monkeypatch):
-    """dm3d_conv_tile_form() names the Winograd form (10) only with the second image, whole 8x8x8 bricks, Cin >= 96, a large grid and no fused
+    """dm3d_conv_tile_form() names the Winograd form (10) only with the second image, whole 8x8x8 bricks, Cin >= 64, a large grid and no fused
     skip conv; DM3D_CONV_WINO=0 switches it off per call."""
     from dm3d_amd import _lib
     from dm3d_amd._lib import ConvDesc, lib
@@ -125,8 +125,8 @@ def test_winograd_launch_policy(dev, monkeypatch):
 
     assert form() == 10
     assert form(wino=False) == 8
-    assert form(c1=64) == 8                      # four chunks: the prologue / epilogue of the one-workgroup-per-CU form do not pay
-    assert form(c1=96) == 10
+    assert form(c1=48) == 8                      # three chunks: the prologue / epilogue of the one-workgroup-per-CU form do not pay
+    assert form(c1=64) == 10
     assert form(batch=1) != 10                   # 64 workgroups
     assert form(ed=36) != 10                     # not whole 8-slice bricks
     assert form(cout=32) != 10
@@ -136,7 +136,7 @@ def test_winograd_launch_policy(dev, monkeypatch):
 
 
 def test_unet_eps_with_and_without_the_winograd_image(dev, monkeypatch):
-    """eps of the conditional 32^3 U-Net at B = 32 (where the policy picks the Winograd form for the Cin >= 96 convs) against the same
+    """eps of the conditional 32^3 U-Net at B = 32 (where the policy picks the Winograd form for the Cin >= 64 convs without a fused skip conv) against the same
     network on the direct kernel only: far inside the 1e-3 contract, and the plan does contain Winograd launches."""
     import dm3d_amd
     cfg = dm3d_amd.UNetConfig(img_size=32, img_channels=8, conditional=True)
