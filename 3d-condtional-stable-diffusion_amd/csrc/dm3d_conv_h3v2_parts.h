@@ -212,8 +212,10 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
     float amax = 0.0f;                                                   // range guard: largest |value| this lane stores
     const float rlim = split ? 0.5f * p.range_limit : p.range_limit;     // two atomic halves: either may carry half the sum
 #ifndef DM3D_EPILOGUE_SCALAR
-    if (full && !split && p.epi_vec4) {
-        // Full brick, plain stores, aligned operands (the common case).  The MFMA leaves a lane with ONE channel of FOUR voxels (r = 0..3: brick rows); stored
+    if (full && !split && p.epi_vec4 && !prz) {
+        // Full brick, plain stores, aligned operands, no PReLU (the common case; the autoencoder's PReLU convs take the scalar form below: a
+        // per-tile slope load under a uniform `if` left an unconditional vmcnt(0) behind it, and with it every tile waited for the previous
+        // tile's STORE to complete — 600-800 cycles per tile for every conv of the U-Net, in-kernel stamps of round 3).  The MFMA leaves a lane with ONE channel of FOUR voxels (r = 0..3: brick rows); stored
         // like that every access is 4 bytes per lane — 64 loads + 64 stores per lane with a residual, and the epilogue of a 64 -> 64 conv
         // took 17-25 thousand cycles (in-kernel stamps), bound by the number of memory instructions, not by bytes.  A 4 x 4 transpose
         // inside each quad of lanes (two DPP exchange rounds, 16 VALU per tile) gives a lane FOUR consecutive channels of ONE voxel
@@ -258,7 +260,6 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
             for (int ni = 0; ni < NCT; ++ni) {
                 const int n = n0 + ni * 16 + c4;             // first of this lane's four channels
                 const f32x4 add = add_t[ni], ps = ps_t[ni], pt = pt_t[ni];
-                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                 // DM3D_FMT_H2: the hi halves of channels n..n+3 are 8 contiguous bytes of the voxel's record, the lo halves 32 bytes further
                 const int h2off = (n >> 4) * 64 + ((n >> 3) & 1) * 16 + (n & 7) * 2 - n * 4;
     #pragma unroll
@@ -273,14 +274,11 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
                         if (b1) { a[0] = r0; a[1] = r1; } else { a[2] = r0; a[3] = r1; }
                     }
                     const int o = (((oy0 + 4 * (pi >> 1) + k) * p.os + ooy) * p.fw + (ox0 + xa * (pi & 1) + dxl) * p.os + oox) * p.cout + n;
-                    f32x4 al4 = zero;
-                    if (prz) al4 = *reinterpret_cast<const f32x4*>(prz + o);
                     f32x4 v4;
     #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float v = fmaf(a[j], p.out_scale, add[j]);
                         if (p.relu) v = fmaxf(v, 0.0f);
-                        if (prz) v = v > 0.0f ? v : al4[j] * v;
                         if (resz) v += rv4[ni][pi][j];
                         if (p.relu_out) v = fmaxf(v, 0.0f);
                         if constexpr (POST) v = dm3d_silu(fmaf(v, ps[j], pt[j]));         // the consumer's norm + SiLU, applied once here
