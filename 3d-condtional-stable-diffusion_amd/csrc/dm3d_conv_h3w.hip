@@ -114,12 +114,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
     const int oy0 = ((brick / p.bw) % p.bh) * TH;
     const int ox0 = (brick % p.bw) * TW;
 
-    // ---- staging: thread t owns 16-byte piece t >> 7 (8 channels) of halo row t & 127 = (hz, hy): ten voxels in, sixteen records out.
-    // The piece is the same for a whole wave: the chunk's scale / shift vectors and channel masks are scalar registers (loaded by
-    // s_load), not 16 vector registers per lane.
-    const int piece = __builtin_amdgcn_readfirstlane(tid >> 7);
-    const bool s_act = (tid & 127) < HROWS;
-    const int srow = s_act ? (tid & 127) : HROWS - 1;
+    // ---- staging: thread t owns 16-byte piece t & 1 (8 channels) of halo row t >> 1 = (hz, hy): ten voxels in, sixteen records out.
+    // (neighbouring lanes take the two pieces of one voxel: a wave's load instruction touches 32 cache lines, not 64)
+    const int piece = tid & 1;
+    const bool s_act = (tid >> 1) < HROWS;
+    const int srow = s_act ? (tid >> 1) : HROWS - 1;
     const int hz = srow / HH, hy = srow % HH;
     const int iz = oz0 - 1 + hz, iy = oy0 - 1 + hy;
     const bool row_in = iz >= 0 && iz < p.ind && iy >= 0 && iy < p.inh;
