@@ -356,6 +356,8 @@ extern "C" int32_t dm3d_conv_tile_form(const dm3d_conv_desc* d) {
     if (dm3d_conv_h3v2_f8(a)) return 9;
     a.wpk_wino = d->wpk_wino; a.cout = d->cout; a.c1 = d->c1; a.c2 = d->c2; a.ind = d->in_d; a.inh = d->in_h; a.inw = d->in_w;
     a.nchunks = (int)(dm3d_round_up(d->c1 + d->c2, DM3D_CIN_PAD) / 16);
+    a.x1 = d->x1; a.x2 = d->x2; a.out = d->out; a.res = d->res; a.relu = d->relu; a.relu_out = d->relu_out; a.prelu = d->prelu_alpha;      // (the Cin split
+    a.out_h2 = d->out_fmt == DM3D_FMT_H2; a.post_scale = d->post_scale;                                                                      //  needs a linear epilogue)
     a.padz = a.pady = a.padx = (d->ksize == 3 && d->stride == 1 && !par_mode) ? 1 : 0;
     if (dm3d_conv_h3w_serves(a, (d->ksize == 3 && d->stride == 1 && !par_mode) ? DM3D_CONV_K3S1 : DM3D_CONV_UP)) return 10;
     return dm3d_conv_h3v3_td(a);

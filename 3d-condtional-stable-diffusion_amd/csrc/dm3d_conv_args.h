@@ -47,7 +47,7 @@ int dm3d_conv_launch_h3v2(ConvArgs& a, int which, hipStream_t st);     // DM3D_W
 int dm3d_conv_launch_h3v3(ConvArgs& a, int which, hipStream_t st);     // same weights and arguments: the free-running form (dm3d_conv_h3v3.hip)
 bool dm3d_conv_h3v3_serves(const ConvArgs& a, int which);
 struct H3v2Launch { ConvArgs k; bool reduce; size_t out_elems; };       // what pre_launch decided: the kernel's own arguments, a reduce launch behind it
-int dm3d_h3v2_pre_launch(ConvArgs& a, int td, bool f8, H3v2Launch& L, hipStream_t st);
+int dm3d_h3v2_pre_launch(ConvArgs& a, int td, bool f8, H3v2Launch& L, hipStream_t st, int force_ksplit = 0);    // force_ksplit > 0: the caller's Cin split
 int dm3d_h3v2_post_launch(const ConvArgs& a, const H3v2Launch& L, hipStream_t st);
 int dm3d_conv_h3v2_ksplit(const ConvArgs& a, bool with_scratch);
 int dm3d_conv_h3v3_td(const ConvArgs& a);              // z-slices per brick (4 or 8) the free-running kernel takes for this launch
@@ -58,4 +58,5 @@ int dm3d_pack_h3v2(const float* keras_kernel, int taps, int cin, int cout, int w
                    int f8, hipStream_t st);
 bool dm3d_conv_h3w_serves(const ConvArgs& a, int which);    // true: the Winograd-x form (wpk_wino, dm3d_conv_h3w.hip) serves this launch
 int dm3d_conv_launch_h3w(ConvArgs& a, int which, hipStream_t st);
+int dm3d_conv_h3w_ksplit(const ConvArgs& a);             // workgroups per brick along Cin the Winograd form would use (1 or 2)
 bool dm3d_conv_h3v2_f8(const ConvArgs& a);               // true: the float8 cross-term form (wpk_f8) serves this launch

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, lo
 
 // Everything around the conv launch itself that the v2 and v3 kernels share: brick counts, Cin splitting for small grids (zero fill +
 // two-way atomic add, or raw partial sums into caller scratch + a reduce launch that applies the epilogue), 16-byte epilogue eligibility.
-int dm3d_h3v2_pre_launch(ConvArgs& a, int td, bool f8, H3v2Launch& L, hipStream_t st) {
+int dm3d_h3v2_pre_launch(ConvArgs& a, int td, bool f8, H3v2Launch& L, hipStream_t st, int force_ksplit) {
     a.bd = (a.od + td - 1) / td;
     a.bh = (a.oh + 7) / 8;
     a.bw = (a.ow + 7) / 8;
@@ -447,7 +447,8 @@ int dm3d_h3v2_pre_launch(ConvArgs& a, int td, bool f8, H3v2Launch& L, hipStream_
     // nothing to hide its barriers and LDS latency behind: in-kernel stamps showed 58 % MFMA occupancy inside the tap loop there;
     // at B = 1 that level has 8 workgroups for 256 CUs) split the Cin chunks over several workgroups per brick.
     const bool with_scratch = a.scratch != nullptr;
-    a.ksplit = (td != 4 || a.out_h2 || a.post_scale) ? 1 : dm3d_conv_h3v2_ksplit(a, with_scratch);     // the fused output forms live in the plain epilogue
+    a.ksplit = force_ksplit > 0 ? force_ksplit
+             : (td != 4 || a.out_h2 || a.post_scale) ? 1 : dm3d_conv_h3v2_ksplit(a, with_scratch);     // the fused output forms live in the plain epilogue
     const size_t out_elems = (size_t)a.batch * a.fd * a.fh * a.fw * a.cout;
     a.split_atomic = 0;
     a.split_stride = 0;

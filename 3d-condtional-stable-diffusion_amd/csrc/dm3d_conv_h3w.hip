@@ -98,15 +98,20 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
 
     // ---- XCD-aware work assignment (as dm3d_conv_h3v3.hip: a pure renumbering of the grid)
     const int ny = gridDim.y;
-    int brick, ntile;
+    int brick, by;
     {
         const unsigned total = gridDim.x * gridDim.y;
         const unsigned d = blockIdx.x + gridDim.x * blockIdx.y;
         unsigned w = d;
         if ((total & 7u) == 0) w = (d & 7u) * (total >> 3) + (d >> 3);
         brick = (int)(w / (unsigned)ny);
-        ntile = (int)(w - (unsigned)brick * (unsigned)ny);
+        by = (int)(w - (unsigned)brick * (unsigned)ny);
     }
+    // by = ntile + ntiles * khalf.  ksplit == 2 (grids that would leave half the CUs idle: the 8^3 level at B = 32): this workgroup contracts
+    // chunks [c_lo, c_hi) only; the shared epilogue adds the two partial sums into the zeroed output (or stores them for the reduce launch).
+    const int ntiles = p.coutpad / NT;
+    const int ntile = by % ntiles, khalf = by / ntiles;
+    const int c_lo = khalf * (p.nchunks / p.ksplit), c_hi = c_lo + p.nchunks / p.ksplit;
     const int bpv = p.bd * p.bh * p.bw;
     const int b = brick / bpv;
     brick -= b * bpv;
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
 
     // weights: the packed image IS the LDS image, step sq of this column tile is a linear 8 KB copy; wave w moves the 1 KB pieces w, w + 4
     const char* w_img = reinterpret_cast<const char*>(static_cast<const _Float16*>(p.wpk) + (size_t)ntile * p.nchunks * NS * WPAIR) + wave * 1024 + lane * 16;
-    const int sq_end = p.nchunks * NS;
+    const int sq_end = c_hi * NS;
     auto fetch_w1 = [&](int sq, int slot, const int i) {              // unconditional (past the end the last step is fetched again): hipcc can count what is in flight
         const char* src = w_img + (size_t)(sq < sq_end ? sq : sq_end - 1) * (WPAIR * 2);
         char* dst = reinterpret_cast<char*>(lds_w) + slot * (WPAIR * 2) + wave * 1024;
@@ -159,9 +164,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
                                          (__attribute__((address_space(3))) void*)(dst + i * (NW * 1024)), 16, 0, 0);
     };
     auto fetch_w = [&](int sq, int slot) { fetch_w1(sq, slot, 0); fetch_w1(sq, slot, 1); };
-    int sq = 0;                                          // running step number of the step being multiplied
+    int sq = c_lo * NS;                                  // running step number of the step being multiplied
 #pragma unroll
-    for (int i = 0; i < RING; ++i) fetch_w(i, i);        // the ring starts full; pass B of step s refills s's buffer with step s + 4  (NS % RING == 0: slot = step & 3)
+    for (int i = 0; i < RING; ++i) fetch_w(sq + i, i);        // the ring starts full; pass B of step s refills s's buffer with step s + 4  (NS % RING == 0: slot = step & 3)
 
     f32x4 va[10][2];                                     // the row's ten voxels: raw -> activated float32, in place
     u32x4 oh[4], ol[4];                                  // one transform term's four records (x-pairs), hi and lo pieces
@@ -283,8 +288,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
 
     // ---- prologue: the first chunk's image
 #pragma unroll
-    for (int hx = 0; hx < 10; ++hx) load_voxel(0, hx);
-    load_chunk_params(0);
+    for (int hx = 0; hx < 10; ++hx) load_voxel(c_lo, hx);
+    load_chunk_params(c_lo);
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0) (with an instruction hipcc's wait-count pass sees): halo and the first four weight steps
     chunk_masks();
 #pragma unroll
@@ -464,10 +469,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
     read_a(ah, 0, 0, false); read_a(ah, 0, 1, false); read_a(ah, 0, 2, false); read_a(ah, 0, 3, false);
     STAMP(1);
 
-    for (int ch = 0; ch < p.nchunks; ++ch) {
+    for (int ch = c_lo; ch < c_hi; ++ch) {
         // keeps the per-voxel offsets from being hoisted out of the chunk loop as 64-bit pairs
         asm volatile("" : "+v"(gv0));
-        const int ch_next = ch + 1 < p.nchunks ? ch + 1 : ch;       // (past the end: the last chunk again, unconditional like the DMAs)
+        const int ch_next = ch + 1 < c_hi ? ch + 1 : ch;       // (past the end: the last chunk again, unconditional like the DMAs)
         // (a generic lambda over integral constants, not `#pragma unroll`: hipcc unrolls a 20-step body of this size only in part, and a step
         // index that is not a constant turns acc[t] into scratch memory)
         static_for<NS>([&](auto S_) {
@@ -555,7 +560,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
     asm volatile("" ::: "memory");
 
     // ---- output transform, then the shared epilogue once per slice: tile (2g + parity, ni) of slice s = rows 4g .. 4g+3, x = 2 * xpair + parity
-    const Brick br = {b, oz0, oy0, ox0, p.ooz, p.ooy, p.oox, ntile, 0};
+    const Brick br = {b, oz0, oy0, ox0, p.ooz, p.ooy, p.oox, ntile, khalf};
     // The transformed outputs go through LDS (free now; each thread reads back only what it wrote: no barrier): with 256 accumulator
     // registers, 128 of outputs and the epilogue's own operands (64 registers of residual per slice) alive together hipcc spilled
     // registers INSIDE the step loop — and every scratch reload there waits vmcnt(0), i.e. for the weight DMA and halo requests in flight.
@@ -595,10 +600,9 @@ int launch_w(ConvArgs& a, hipStream_t st) {
         attr_set = true;
     }
     H3v2Launch L;
-    if (int rc = dm3d_h3v2_pre_launch(a, 8, false, L, st)) return rc;
-    DM3D_REQUIRE(L.k.ksplit == 1 && !L.reduce, "conv: the Winograd form does not split Cin");
+    if (int rc = dm3d_h3v2_pre_launch(a, 8, false, L, st, dm3d_conv_h3w_ksplit(a))) return rc;
     L.k.wpk = a.wpk_wino;
-    dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64), 1u);
+    dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64 * a.ksplit), 1u);
     hipLaunchKernelGGL((conv3d_igemm_h3w<MODE>), grid, dim3(256), lds, st, L.k);
     if (int rc = dm3d_launch_check("conv3d_igemm_h3w")) return rc;
     return dm3d_h3v2_post_launch(a, L, st);
@@ -621,9 +625,22 @@ bool dm3d_conv_h3w_serves(const ConvArgs& a, int which) {
     if (a.nchunks < (mc ? atoi(mc) : 4)) return false;
     const long long vox = (long long)a.batch * a.ind * a.inh * a.inw;
     if (vox * (a.c1 > a.c2 ? a.c1 : a.c2) * 4 >= (1ll << 32)) return false;
-    const long wgs = (long)a.batch * (a.od / 8) * (a.oh / 8) * (a.ow / 8) * (a.coutpad / 64);
+    const long wgs = (long)a.batch * (a.od / 8) * (a.oh / 8) * (a.ow / 8) * (a.coutpad / 64) * dm3d_conv_h3w_ksplit(a);
     const char* w = getenv("DM3D_CONV_WIDE_WGS");
-    return wgs >= (w ? atol(w) : 512L);
+    const long need = w ? atol(w) : 512L;
+    return wgs >= (dm3d_conv_h3w_ksplit(a) > 1 ? (need < 256 ? need : 256L) : need);
+}
+
+// Cin split of the Winograd form: two workgroups per brick and column tile where one would leave at least half of the CUs without work
+// (the 8^3 level at B = 32: 32 bricks x 4 column tiles), each contracting half of the chunks (at least eight), their partial sums meeting
+// in the shared epilogue (atomic add into the zeroed output when the epilogue is linear, else scratch + reduce launch: dm3d_h3v2_pre_launch).
+// The fused output forms (hand-off format, post-activation) live in the 16-byte epilogue and are not split.  DM3D_CONV_WINO_SPLIT=0: never.
+int dm3d_conv_h3w_ksplit(const ConvArgs& a) {
+    static const bool off = [] { const char* e = getenv("DM3D_CONV_WINO_SPLIT"); return e && e[0] == '0'; }();
+    if (off || a.out_h2 || a.post_scale || a.nchunks % 2 != 0 || a.nchunks < 16) return 1;
+    if (a.relu || a.prelu || a.relu_out || a.res == a.out || a.x1 == a.out || a.x2 == a.out) return 1;      // (a linear epilogue: the halves may meet by atomic add)
+    const long wgs = (long)a.batch * (a.od / 8) * (a.oh / 8) * (a.ow / 8) * (a.coutpad / 64);
+    return wgs <= 128 ? 2 : 1;
 }
 
 int dm3d_conv_launch_h3w(ConvArgs& a, int which, hipStream_t st) {

@@ -103,18 +103,45 @@ def test_winograd_hand_off_pair(dev, small_grids, dims):
     assert _rel(outs[0], yr) < 2e-5 and _rel(outs[1], yr) < 2e-5
 
 
+def test_winograd_cin_split_on_a_small_grid(dev, monkeypatch):
+    """B = 32 at 8^3 is 128 workgroups of the one-per-CU form: it runs as two workgroups per brick, each contracting half of the chunks, the
+    halves meeting by atomic add in the shared epilogue (linear epilogues only; Cin >= 256)."""
+    from dm3d_amd import ops, _lib
+    for v in ("DM3D_CONV_WIDE_WGS", "DM3D_CONV_WINO_MINCHUNKS", "DM3D_CONV_WINO", "DM3D_CONV_WINO_SPLIT"):
+        monkeypatch.delenv(v, raising=False)
+    torch.manual_seed(5)
+    B, e, cin, cout = 32, 8, 256, 256
+    x = torch.randn(B, e, e, e, cin, device=dev)
+    k = torch.randn(3, 3, 3, cin, cout, device=dev) * 0.05
+    wpk, w_exp = ops.pack_weights_h3(k)
+    wino = ops.pack_weights_h3w(k, w_exp)
+    ps = (torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.1)
+    r = torch.randn(B, e, e, e, cout, device=dev)
+    kw = dict(bias=torch.randn(cout, device=dev), pro_scale=ps[0], pro_shift=ps[1], res=r, precision=_lib.PREC_H3, w_exp=w_exp)
+    y_direct = ops.conv3d(x, wpk, cout, 3, **kw)
+    y_wino = ops.conv3d(x, wpk, cout, 3, wpk_wino=wino, **kw)
+    yr = _ref_conv(x[:2], k, kw["bias"], ps, r[:2])
+    assert not torch.equal(y_wino, y_direct), "the Winograd form did not run"
+    assert _rel(y_wino[:2], yr) < 2e-5 and _rel(y_wino, y_direct) < 2e-5
+    # a ReLU epilogue is not linear: the launch stays on the direct kernel (bit-identical results with and without the second image)
+    y_a = ops.conv3d(x, wpk, cout, 3, relu=True, **kw)
+    y_b = ops.conv3d(x, wpk, cout, 3, relu=True, wpk_wino=wino, **kw)
+    assert torch.equal(y_a, y_b)
+
+
 def test_winograd_launch_policy(dev, monkeypatch):
     """dm3d_conv_tile_form() names the Winograd form (10) only with the second image, whole 8x8x8 bricks, Cin >= 64, a large grid and no fused
     skip conv; DM3D_CONV_WINO=0 switches it off per call."""
     from dm3d_amd import _lib
     from dm3d_amd._lib import ConvDesc, lib
-    for v in ("DM3D_CONV_WIDE_WGS", "DM3D_CONV_WINO_MINCHUNKS", "DM3D_CONV_WINO", "DM3D_CONV_V3_TD"):
+    for v in ("DM3D_CONV_WIDE_WGS", "DM3D_CONV_WINO_MINCHUNKS", "DM3D_CONV_WINO", "DM3D_CONV_V3_TD", "DM3D_CONV_WINO_SPLIT"):
         monkeypatch.delenv(v, raising=False)
     buf = torch.zeros(64, device=dev)
 
     def form(batch=32, e=32, c1=128, cout=64, wino=True, skip=False, ed=None):
         d = ConvDesc()
-        d.x1 = d.wpk = d.out = buf.data_ptr()
+        d.x1 = d.wpk = buf.data_ptr()
+        d.out = buf.data_ptr() + 128
         d.c1, d.batch, d.in_d, d.in_h, d.in_w = c1, batch, ed or e, e, e
         d.ksize, d.stride, d.cout, d.precision, d.w_layout = 3, 1, cout, _lib.PREC_H3, _lib.WL_PAIR
         if wino:
@@ -128,6 +155,8 @@ def test_winograd_launch_policy(dev, monkeypatch):
     assert form(c1=48) == 8                      # three chunks: the prologue / epilogue of the one-workgroup-per-CU form do not pay
     assert form(c1=64) == 10
     assert form(batch=1) != 10                   # 64 workgroups
+    assert form(e=8, c1=256, cout=256) == 10     # 128 workgroups, Cin >= 256: two workgroups per brick (the Cin split)
+    assert form(e=8, c1=128, cout=256) != 10     # too few chunks to split
     assert form(ed=36) != 10                     # not whole 8-slice bricks
     assert form(cout=32) != 10
     assert form(skip=True) == 4

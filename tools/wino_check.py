@@ -43,6 +43,25 @@ for name, B, e, c1, c2, cout, pro, res in [("plain 8^3 16->64", 1, 8, 16, 0, 64,
     ok = e1 < 2e-5 and not torch.equal(y0, y1)
     bad += not ok
     print(f"{name:34s} direct {e0:.2e}  wino {e1:.2e}  wino-direct {d:.2e}  {'ok' if ok else 'FAIL (or the Winograd form did not run)'}", flush=True)
+# Cin split: a grid of 128 workgroups (B = 32 at 8^3) runs as two workgroups per brick, their halves meeting by atomic add
+os.environ.pop("DM3D_CONV_WIDE_WGS", None)
+for name, B, e, cin, cout, res in [("split 8^3 B=32 256->256 +res", 32, 8, 256, 256, 1), ("split 8^3 B=32 512->256", 32, 8, 512, 256, 0)]:
+    x = torch.randn(B, e, e, e, cin, device=dev)
+    k = torch.randn(3, 3, 3, cin, cout, device=dev) * 0.05
+    wpk, w_exp = ops.pack_weights_h3(k)
+    wino = ops.pack_weights_h3w(k, w_exp)
+    bias = torch.randn(cout, device=dev)
+    ps = (torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.1)
+    r = torch.randn(B, e, e, e, cout, device=dev) if res else None
+    kw = dict(bias=bias, pro_scale=ps[0], pro_shift=ps[1], res=r, precision=_lib.PREC_H3, w_exp=w_exp)
+    y0 = ops.conv3d(x, wpk, cout, 3, **kw)
+    y1 = ops.conv3d(x, wpk, cout, 3, wpk_wino=wino, **kw)
+    yr = ref_conv(x[:4], k, bias, ps, r[:4] if res else None)
+    e0, e1 = rel(y0[:4], yr), rel(y1[:4], yr)
+    ok = e1 < 2e-5 and not torch.equal(y0, y1) and float((y1 - y0).abs().max() / y0.abs().max()) < 2e-5
+    bad += not ok
+    print(f"{name:34s} direct {e0:.2e}  wino {e1:.2e}  wino-direct {rel(y1, y0):.2e}  {'ok' if ok else 'FAIL (or the Winograd form did not run)'}", flush=True)
+os.environ["DM3D_CONV_WIDE_WGS"] = "1"
 # hand-off pair (ResidualBlock conv1 -> norm + SiLU -> conv2): conv A stores DM3D_FMT_H2 behind its fused post-activation, conv B reads it (kernel MODE 2)
 for name, B, e, c, cm in [("hand-off 8^3 96->128->64", 1, 8, 96, 128), ("hand-off 16^3 128->192->128", 1, 16, 128, 192)]:
     x = torch.randn(B, e, e, e, c, device=dev)
@@ -70,7 +89,7 @@ if len(sys.argv) > 1 and not bad:
     del os.environ["DM3D_CONV_WIDE_WGS"]; os.environ["DM3D_CONV_WINO_MINCHUNKS"] = "1"
     B = int(os.environ.get("AB_BATCH", "32"))
     for name, e, cin, cout, res in [("32^3 64->64 pro+res", 32, 64, 64, 1), ("32^3 96->64 pro", 32, 96, 64, 0), ("32^3 192->64 pro", 32, 192, 64, 0),
-                                    ("16^3 128->128 pro+res", 16, 128, 128, 1), ("16^3 384->128 pro", 16, 384, 128, 0), ("8^3 256->256 pro", 8, 256, 256, 0)]:
+                                    ("16^3 128->128 pro+res", 16, 128, 128, 1), ("16^3 384->128 pro", 16, 384, 128, 0), ("8^3 256->256 pro", 8, 256, 256, 0), ("8^3 512->256 pro", 8, 512, 256, 0), ("8^3 256->256 pro+res", 8, 256, 256, 1)]:
         x = torch.randn(B, e, e, e, cin, device=dev)
         k = torch.randn(3, 3, 3, cin, cout, device=dev) * 0.05
         wpk, w_exp = ops.pack_weights_h3(k)
