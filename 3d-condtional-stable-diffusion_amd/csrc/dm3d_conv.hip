@@ -351,7 +351,7 @@ extern "C" int32_t dm3d_conv_tile_form(const dm3d_conv_desc* d) {
     a.batch = d->batch; a.od = d->in_d; a.oh = d->in_h; a.ow = d->in_w;      // (WL_PAIR convs are stride 1 / parity convs on the input grid)
     a.coutpad = (int)dm3d_round_up(d->cout, DM3D_COUT_PAD);
     a.parity = par_mode ? 1 : 0;
-    a.s_npairs = d->skip_wpk ? 1 : 0;
+    a.s_npairs = d->skip_wpk ? (int)(dm3d_round_up(d->skip_c1 + d->skip_c2, 32) / 32) : 0;
     a.wpk_f8 = d->wpk_f8;
     if (dm3d_conv_h3v2_f8(a)) return 9;
     a.wpk_wino = d->wpk_wino; a.cout = d->cout; a.c1 = d->c1; a.c2 = d->c2; a.ind = d->in_d; a.inh = d->in_h; a.inw = d->in_w;

@@ -561,10 +561,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
 
     // ---- output transform, then the shared epilogue once per slice: tile (2g + parity, ni) of slice s = rows 4g .. 4g+3, x = 2 * xpair + parity
     const Brick br = {b, oz0, oy0, ox0, p.ooz, p.ooy, p.oox, ntile, khalf};
-    // The transformed outputs go through LDS (free now; each thread reads back only what it wrote: no barrier): with 256 accumulator
-    // registers, 128 of outputs and the epilogue's own operands (64 registers of residual per slice) alive together hipcc spilled
-    // registers INSIDE the step loop — and every scratch reload there waits vmcnt(0), i.e. for the weight DMA and halo requests in flight.
-    f32x4v* lds_e = reinterpret_cast<f32x4v*>(smem_w);                    // [32 tiles][256 threads] x 16 bytes = 128 KB
+    // ---- output transform: tile (2g + parity, ni) of slice s = rows 4g .. 4g+3, x = 2 * xpair + parity
+    f32x4v e[2][4][4];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -572,9 +570,130 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 const f32x4v m0 = acc[0][2 * s + g][ni], m1 = acc[1][2 * s + g][ni], m2 = acc[2][2 * s + g][ni], m3 = acc[3][2 * s + g][ni];
-                lds_e[((s * 4 + 2 * g) * 4 + ni) * 256 + tid] = (m0 + m1) + m2;
-                lds_e[((s * 4 + 2 * g + 1) * 4 + ni) * 256 + tid] = (m1 - m2) - m3;
+                e[s][2 * g][ni] = (m0 + m1) + m2;
+                e[s][2 * g + 1][ni] = (m1 - m2) - m3;
             }
+
+    // ---- fused 1x1 conv over a second, raw input (ResidualBlock: out = conv2(...) + Conv3D(width, 1)(x), conditional_dm3d.py:243-248, 268)
+    // on the transformed tiles.  The arithmetic and the weight image (dm3d_pack_weights_skip_h3p) are those of the direct kernel's tail phase
+    // (dm3d_conv_h3v2_parts.h): K = 32 per MFMA = two 16-channel chunks of the SAME voxel, chunk 2i in LDS region 0, chunk 2i + 1 in
+    // region 1 (brick voxels only), the lane half picks the region; here a wave owns two slices and its tile rows are (y, x-pair) of one
+    // column parity.  Per pair of chunks: voxels through registers (the next pair's requests fly beside this pair's 96 MFMAs), weights by
+    // LDS-DMA into one of two buffers, two barriers (the old image is read / the new one is visible).
+    if (p.s_npairs > 0) {
+        constexpr int SROWP = 9, SREC = TD * TH * SROWP;                        // 8 voxels + 1 pad record per brick row; 576 records per region
+        _Float16* lds_sa = smem_w;                                              // [2][SREC][REC]            (72 KB)
+        _Float16* lds_sw = smem_w + 2 * SREC * REC;                             // [2 buffers][2][NT][REC]   (16 KB)
+        const int np = p.s_npairs;
+        int sgv[8], sst[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int it = tid + j * 256, t = it >> 10, iv = (it & 1023) >> 1, pc = it & 1;
+            const int z = iv >> 6, y = (iv >> 3) & 7, x = iv & 7;
+            sgv[j] = ((b * p.ind + oz0 + z) * p.inh + oy0 + y) * p.inw + ox0 + x;
+            const int v = (z * TH + y) * SROWP + x;
+            sst[j] = (t * SREC + v) * REC + ((pc ^ ((x >> 1) & 3)) << 3);
+        }
+        f32x4 sr0[8], sr1[8];
+        bool sk0[8], sk1[8];
+        auto sload = [&](int pp) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int it = tid + j * 256, pc = it & 1;
+                const int c0 = (pp * 2 + (it >> 10)) * CK;
+                const float* src;
+                int ldc, cb;
+                if (c0 < p.sc1) { src = p.sx1; ldc = p.sc1; cb = c0; } else { src = p.sx2; ldc = p.sc2; cb = c0 - p.sc1; }
+                const int cpos = cb + pc * 8;
+                const bool real = src != nullptr && cb < ldc && pp < np;     // a pad chunk past the last channel reads zeros
+                sk0[j] = real && cpos < ldc;
+                sk1[j] = real && cpos + 4 < ldc;
+                const float* qp = (real ? src : p.sx1) + (size_t)sgv[j] * (real ? ldc : p.sc1);
+                sr0[j] = *reinterpret_cast<const f32x4*>(qp + (sk0[j] ? cpos : 0));
+                sr1[j] = *reinterpret_cast<const f32x4*>(qp + (sk1[j] ? cpos + 4 : 0));
+            }
+        };
+        const char* sw_img = reinterpret_cast<const char*>(p.swpk) + (size_t)ntile * p.s_npairs * (2 * NT * REC * 2) + wave * 1024 + lane * 16;
+        auto sdma = [&](int pp, int buf) {
+            const char* src = sw_img + (size_t)(pp < np ? pp : np - 1) * (2 * NT * REC * 2);
+            char* dst = reinterpret_cast<char*>(lds_sw) + buf * (2 * NT * REC * 2) + wave * 1024;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * (NW * 1024)),
+                                                 (__attribute__((address_space(3))) void*)(dst + i * (NW * 1024)), 16, 0, 0);
+        };
+        // fragment addresses: row i of a tile = (y = i & 3, x-pair i >> 2); hi piece at slot q ^ (x-pair & 3) (lo: ^ 2)
+        const unsigned sa_addr = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)lds_sa
+                                 + (unsigned)((((2 * wave) * TH + ay) * SROWP + 2 * (row >> 2) + half * SREC) * (REC * 2) + ((q ^ ((row >> 2) & 3)) << 4));
+        const unsigned sw_addr = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)lds_sw + (unsigned)b_hi * 2u;
+        sdma(0, 0);
+        sload(0);
+        for (int pp = 0; pp < np; ++pp) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0): this pair's voxels and weights have landed
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {                                      // in place: the registers become the two 16-byte pieces
+                h8 hi_, lo_;
+                split8(sr0[j], sr1[j], sk0[j] ? 65504.0f : 0.0f, sk1[j] ? 65504.0f : 0.0f, hi_, lo_);
+                sr0[j] = __builtin_bit_cast(f32x4, hi_);
+                sr1[j] = __builtin_bit_cast(f32x4, lo_);
+            }
+            lds_barrier();                                                     // everyone has left the previous image
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                *reinterpret_cast<f32x4*>(lds_sa + sst[j]) = sr0[j];
+                *reinterpret_cast<f32x4*>(lds_sa + (sst[j] ^ 16)) = sr1[j];
+            }
+            lds_barrier();                                                     // the image and this pair's weights are visible
+            sdma(pp + 1, (pp + 1) & 1);                                        // (past the end: the last pair again, into the buffer nobody reads)
+            sload(pp + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned wa = sw_addr + (unsigned)((pp & 1) * (2 * NT * REC * 2));
+            h8 sbh[4], sbl[4];
+#define DM3D_SDSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+            DM3D_SDSR(sbh[0], wa, 0); DM3D_SDSR(sbh[1], wa, 16 * REC * 2); DM3D_SDSR(sbh[2], wa, 32 * REC * 2); DM3D_SDSR(sbh[3], wa, 48 * REC * 2);
+            {
+                const unsigned wl = wa ^ 32u;
+                DM3D_SDSR(sbl[0], wl, 0); DM3D_SDSR(sbl[1], wl, 16 * REC * 2); DM3D_SDSR(sbl[2], wl, 32 * REC * 2); DM3D_SDSR(sbl[3], wl, 48 * REC * 2);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int pi = 0; pi < 4; ++pi) {
+                    h8 sah, sal;
+                    const unsigned aa = sa_addr;
+                    switch (s * 4 + pi) {          // slice s, row group pi >> 1, column parity pi & 1
+#define DM3D_SA(k_) case k_: DM3D_SDSR(sah, aa, (((k_) >> 2) * TH + 4 * (((k_) >> 1) & 1)) * SROWP * REC * 2 + ((k_) & 1) * REC * 2); \
+                             DM3D_SDSR(sal, aa ^ 32u, (((k_) >> 2) * TH + 4 * (((k_) >> 1) & 1)) * SROWP * REC * 2 + ((k_) & 1) * REC * 2); break;
+                        DM3D_SA(0) DM3D_SA(1) DM3D_SA(2) DM3D_SA(3) DM3D_SA(4) DM3D_SA(5) DM3D_SA(6) DM3D_SA(7)
+#undef DM3D_SA
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        f32x4v& c_ = e[s][pi][ni];
+                        c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(sal, sbh[ni], c_, 0, 0, 0);
+                        c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(sah, sbl[ni], c_, 0, 0, 0);
+                        c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(sah, sbh[ni], c_, 0, 0, 0);
+                    }
+                }
+#undef DM3D_SDSR
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // the tail requests: nothing may land in LDS the staging below reuses
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    // The finished tiles go through LDS (each thread reads back only what it wrote: no barrier): with the outputs and the epilogue's own
+    // operands (64 registers of residual per slice) alive beside the accumulators hipcc spilled registers INSIDE the step loop — and every
+    // scratch reload there waits vmcnt(0), i.e. for the weight DMA and halo requests in flight.
+    f32x4v* lds_e = reinterpret_cast<f32x4v*>(smem_w);                    // [32 tiles][256 threads] x 16 bytes = 128 KB
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) lds_e[((s * 4 + pi) * 4 + ni) * 256 + tid] = e[s][pi][ni];
     STAMP(20);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -611,13 +730,16 @@ int launch_w(ConvArgs& a, hipStream_t st) {
 }  // namespace
 
 // The Winograd form serves a k3 / stride-1 launch when the caller supplied the transformed image (wpk_wino), the volume is whole 8 x 8 x 8
-// bricks, there is no fused skip conv (its tail phase is written for one slice per wave), the grid gives every CU two workgroups in turn
+// bricks, a fused skip conv is short or the main loop long (below), the grid gives every CU two workgroups in turn
 // (the same threshold as the 8-slice bricks of the direct kernel: DM3D_CONV_WIDE_WGS) and Cin is at least 64 (four 16-channel chunks,
 // DM3D_CONV_WINO_MINCHUNKS: its unoverlapped prologue and epilogue cost as much as two chunks; at 64 input channels it is 7 % ahead of
 // the direct kernel, profiles/r03_wino_ab.log).  The input tensors must be below 4 GB (32-bit lane offsets).  DM3D_CONV_WINO=0 (A/B knob, read per
 // call): never.
 bool dm3d_conv_h3w_serves(const ConvArgs& a, int which) {
-    if (!a.wpk_wino || which != DM3D_CONV_K3S1 || a.parity || a.s_npairs > 0 || a.cout <= 32) return false;
+    if (!a.wpk_wino || which != DM3D_CONV_K3S1 || a.parity || a.cout <= 32) return false;
+    // (a fused skip conv: its tail phase here keeps one pair of chunks in flight, the direct kernel's two — behind a main loop of only four
+    // chunks the direct kernel wins from three pairs on: profiles/r03_list_convs.log)
+    if (a.s_npairs > 2 && a.nchunks < 8) return false;
     if (a.od % 8 != 0 || a.oh % 8 != 0 || a.ow % 8 != 0 || a.padz != 1 || a.pady != 1 || a.padx != 1) return false;
     const char* e = getenv("DM3D_CONV_WINO");
     if (e && e[0] == '0') return false;
@@ -637,7 +759,7 @@ bool dm3d_conv_h3w_serves(const ConvArgs& a, int which) {
 // The fused output forms (hand-off format, post-activation) live in the 16-byte epilogue and are not split.  DM3D_CONV_WINO_SPLIT=0: never.
 int dm3d_conv_h3w_ksplit(const ConvArgs& a) {
     static const bool off = [] { const char* e = getenv("DM3D_CONV_WINO_SPLIT"); return e && e[0] == '0'; }();
-    if (off || a.out_h2 || a.post_scale || a.nchunks % 2 != 0 || a.nchunks < 16) return 1;
+    if (off || a.out_h2 || a.post_scale || a.s_npairs > 0 || a.nchunks % 2 != 0 || a.nchunks < 16) return 1;
     if (a.relu || a.prelu || a.relu_out || a.res == a.out || a.x1 == a.out || a.x2 == a.out) return 1;      // (a linear epilogue: the halves may meet by atomic add)
     const long wgs = (long)a.batch * (a.od / 8) * (a.oh / 8) * (a.ow / 8) * (a.coutpad / 64);
     return wgs <= 128 ? 2 : 1;

@@ -103,6 +103,36 @@ def test_winograd_hand_off_pair(dev, small_grids, dims):
     assert _rel(outs[0], yr) < 2e-5 and _rel(outs[1], yr) < 2e-5
 
 
+SKIP_CASES = [("8^3 64->64 + k1(32)", 2, 8, 64, 32, 0, 64), ("16^3 128->128 + k1(64+32)", 1, 16, 128, 64, 32, 128), ("8^3 32->96 + k1(40), ragged", 1, 8, 32, 40, 0, 96)]
+
+
+@pytest.mark.parametrize("case", SKIP_CASES, ids=[c[0] for c in SKIP_CASES])
+def test_winograd_fused_skip_conv(dev, small_grids, case):
+    """ResidualBlock tail in one launch: conv_k3(silu(bn(h))) + bias + Conv3D(width, 1)(concat(x, skip)) (conditional_dm3d.py:243-248, 268)
+    with the 1x1 conv as the tail phase of the Winograd kernel, on the transformed tiles."""
+    from dm3d_amd import ops, _lib
+    name, B, e, cm, s1, s2, cout = case
+    torch.manual_seed(7)
+    h = torch.randn(B, e, e, e, cm, device=dev)
+    x1 = torch.randn(B, e, e, e, s1, device=dev)
+    x2 = torch.randn(B, e, e, e, s2, device=dev) if s2 else None
+    k = torch.randn(3, 3, 3, cm, cout, device=dev) * 0.05
+    ks = torch.randn(1, 1, 1, s1 + s2, cout, device=dev) * 0.2
+    w_exp = ops.h3_weight_exponent(k.cpu(), ks.cpu())
+    wpk, _ = ops.pack_weights_h3(k, w_exp=w_exp)
+    wino = ops.pack_weights_h3w(k, w_exp)
+    swpk = ops.pack_weights_skip_h3p(ks, w_exp)
+    bias = torch.randn(cout, device=dev)
+    ps = (torch.rand(cm, device=dev) + 0.5, torch.randn(cm, device=dev) * 0.1)
+    kw = dict(bias=bias, pro_scale=ps[0], pro_shift=ps[1], precision=_lib.PREC_H3, w_exp=w_exp, skip=(x1, x2, swpk))
+    y_direct = ops.conv3d(h, wpk, cout, 3, **kw)
+    y_wino = ops.conv3d(h, wpk, cout, 3, wpk_wino=wino, **kw)
+    xs = torch.cat([x1, x2], -1) if s2 else x1
+    yr = _ref_conv(h, k, bias, ps) + torch.einsum("bdhwc,co->bdhwo", xs.double(), ks.double()[0, 0, 0])
+    assert not torch.equal(y_wino, y_direct), "the Winograd form did not run"
+    assert _rel(y_wino, yr) < 2e-5 and _rel(y_direct, yr) < 2e-5
+
+
 def test_winograd_cin_split_on_a_small_grid(dev, monkeypatch):
     """B = 32 at 8^3 is 128 workgroups of the one-per-CU form: it runs as two workgroups per brick, each contracting half of the chunks, the
     halves meeting by atomic add in the shared epilogue (linear epilogues only; Cin >= 256)."""
@@ -130,15 +160,15 @@ def test_winograd_cin_split_on_a_small_grid(dev, monkeypatch):
 
 
 def test_winograd_launch_policy(dev, monkeypatch):
-    """dm3d_conv_tile_form() names the Winograd form (10) only with the second image, whole 8x8x8 bricks, Cin >= 64, a large grid and no fused
-    skip conv; DM3D_CONV_WINO=0 switches it off per call."""
+    """dm3d_conv_tile_form() names the Winograd form (10) only with the second image, whole 8x8x8 bricks, Cin >= 64, a large grid (or its Cin split) and at most a short
+    fused skip conv; DM3D_CONV_WINO=0 switches it off per call."""
     from dm3d_amd import _lib
     from dm3d_amd._lib import ConvDesc, lib
     for v in ("DM3D_CONV_WIDE_WGS", "DM3D_CONV_WINO_MINCHUNKS", "DM3D_CONV_WINO", "DM3D_CONV_V3_TD", "DM3D_CONV_WINO_SPLIT"):
         monkeypatch.delenv(v, raising=False)
     buf = torch.zeros(64, device=dev)
 
-    def form(batch=32, e=32, c1=128, cout=64, wino=True, skip=False, ed=None):
+    def form(batch=32, e=32, c1=128, cout=64, wino=True, skip=False, ed=None, skip_c=64):
         d = ConvDesc()
         d.x1 = d.wpk = buf.data_ptr()
         d.out = buf.data_ptr() + 128
@@ -147,7 +177,7 @@ def test_winograd_launch_policy(dev, monkeypatch):
         if wino:
             d.wpk_wino = buf.data_ptr()
         if skip:
-            d.skip_wpk, d.skip_x1, d.skip_c1 = buf.data_ptr(), buf.data_ptr(), 64
+            d.skip_wpk, d.skip_x1, d.skip_c1 = buf.data_ptr(), buf.data_ptr(), skip_c
         return lib().dm3d_conv_tile_form(C.byref(d))
 
     assert form() == 10
@@ -159,7 +189,8 @@ def test_winograd_launch_policy(dev, monkeypatch):
     assert form(e=8, c1=128, cout=256) != 10     # too few chunks to split
     assert form(ed=36) != 10                     # not whole 8-slice bricks
     assert form(cout=32) != 10
-    assert form(skip=True) == 4
+    assert form(skip=True) == 10                 # a fused skip conv of two pairs of chunks behind eight chunks of main loop
+    assert form(c1=64, skip=True, skip_c=192) == 4 and form(c1=64, skip=True, skip_c=32) == 10      # four chunks of main loop: short skip convs only
     monkeypatch.setenv("DM3D_CONV_WINO", "0")
     assert form() == 8
 

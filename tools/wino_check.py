@@ -62,6 +62,29 @@ for name, B, e, cin, cout, res in [("split 8^3 B=32 256->256 +res", 32, 8, 256, 
     bad += not ok
     print(f"{name:34s} direct {e0:.2e}  wino {e1:.2e}  wino-direct {rel(y1, y0):.2e}  {'ok' if ok else 'FAIL (or the Winograd form did not run)'}", flush=True)
 os.environ["DM3D_CONV_WIDE_WGS"] = "1"
+# fused 1x1 skip conv (ResidualBlock tail: conv2(...) + Conv3D(width, 1)(concat(x, skip))) as a tail phase of the Winograd kernel
+os.environ["DM3D_CONV_WIDE_WGS"] = "1"; os.environ["DM3D_CONV_WINO_MINCHUNKS"] = "1"
+for name, B, e, cm, s1, s2, cout in [("skip 8^3 64->64 + k1(32)", 2, 8, 64, 32, 0, 64), ("skip 16^3 128->128 + k1(64+32)", 1, 16, 128, 64, 32, 128),
+                                     ("skip 8^3 32->96 + k1(40) ragged", 1, 8, 32, 40, 0, 96)]:
+    h = torch.randn(B, e, e, e, cm, device=dev)
+    x1 = torch.randn(B, e, e, e, s1, device=dev); x2 = torch.randn(B, e, e, e, s2, device=dev) if s2 else None
+    k = torch.randn(3, 3, 3, cm, cout, device=dev) * 0.05
+    ks = torch.randn(1, 1, 1, s1 + s2, cout, device=dev) * 0.2
+    w_exp = ops.h3_weight_exponent(k.cpu(), ks.cpu())
+    wpk, _ = ops.pack_weights_h3(k, w_exp=w_exp)
+    wino = ops.pack_weights_h3w(k, w_exp)
+    swpk = ops.pack_weights_skip_h3p(ks, w_exp)
+    bias = torch.randn(cout, device=dev)
+    ps = (torch.rand(cm, device=dev) + 0.5, torch.randn(cm, device=dev) * 0.1)
+    kw = dict(bias=bias, pro_scale=ps[0], pro_shift=ps[1], precision=_lib.PREC_H3, w_exp=w_exp, skip=(x1, x2, swpk))
+    y0 = ops.conv3d(h, wpk, cout, 3, **kw)
+    y1 = ops.conv3d(h, wpk, cout, 3, wpk_wino=wino, **kw)
+    xs = torch.cat([x1, x2], -1) if s2 else x1
+    yr = ref_conv(h, k, bias, ps) + torch.einsum("bdhwc,co->bdhwo", xs.double(), ks.double()[0, 0, 0])
+    e0, e1 = rel(y0, yr), rel(y1, yr)
+    ok = e1 < 2e-5 and not torch.equal(y0, y1)
+    bad += not ok
+    print(f"{name:34s} direct {e0:.2e}  wino {e1:.2e}  wino-direct {rel(y1, y0):.2e}  {'ok' if ok else 'FAIL (or the Winograd form did not run)'}", flush=True)
 # hand-off pair (ResidualBlock conv1 -> norm + SiLU -> conv2): conv A stores DM3D_FMT_H2 behind its fused post-activation, conv B reads it (kernel MODE 2)
 for name, B, e, c, cm in [("hand-off 8^3 96->128->64", 1, 8, 96, 128), ("hand-off 16^3 128->192->128", 1, 16, 128, 192)]:
     x = torch.randn(B, e, e, e, c, device=dev)
