@@ -730,7 +730,7 @@ int launch_w(ConvArgs& a, hipStream_t st) {
 }  // namespace
 
 // The Winograd form serves a k3 / stride-1 launch when the caller supplied the transformed image (wpk_wino), the volume is whole 8 x 8 x 8
-// bricks, a fused skip conv is short or the main loop long (below), the grid gives every CU two workgroups in turn
+// bricks, a fused skip conv is short or the main loop long (below), the grid gives every CU two workgroups in turn or exactly one
 // (the same threshold as the 8-slice bricks of the direct kernel: DM3D_CONV_WIDE_WGS) and Cin is at least 64 (four 16-channel chunks,
 // DM3D_CONV_WINO_MINCHUNKS: its unoverlapped prologue and epilogue cost as much as two chunks; at 64 input channels it is 7 % ahead of
 // the direct kernel, profiles/r03_wino_ab.log).  The input tensors must be below 4 GB (32-bit lane offsets).  DM3D_CONV_WINO=0 (A/B knob, read per
@@ -750,7 +750,9 @@ bool dm3d_conv_h3w_serves(const ConvArgs& a, int which) {
     const long wgs = (long)a.batch * (a.od / 8) * (a.oh / 8) * (a.ow / 8) * (a.coutpad / 64) * dm3d_conv_h3w_ksplit(a);
     const char* w = getenv("DM3D_CONV_WIDE_WGS");
     const long need = w ? atol(w) : 512L;
-    return wgs >= (dm3d_conv_h3w_ksplit(a) > 1 ? (need < 256 ? need : 256L) : need);
+    // (one workgroup per CU: exactly 256 workgroups are one full round — B = 4 at 32^3, config 2: 3.21 -> 3.09 ms per step —; between 256
+    // and 512 the second round would be part empty, which two small workgroups per CU of the direct kernel handle better)
+    return wgs >= need || wgs == 256 || (dm3d_conv_h3w_ksplit(a) > 1 && wgs >= (need < 256 ? need : 256L));
 }
 
 // Cin split of the Winograd form: two workgroups per brick and column tile where one would leave at least half of the CUs without work

@@ -185,6 +185,7 @@ def test_winograd_launch_policy(dev, monkeypatch):
     assert form(c1=48) == 8                      # three chunks: the prologue / epilogue of the one-workgroup-per-CU form do not pay
     assert form(c1=64) == 10
     assert form(batch=1) != 10                   # 64 workgroups
+    assert form(batch=4) == 10 and form(batch=6) != 10       # exactly one workgroup per CU is a full round; 384 workgroups are a round and a half
     assert form(e=8, c1=256, cout=256) == 10     # 128 workgroups, Cin >= 256: two workgroups per brick (the Cin split)
     assert form(e=8, c1=128, cout=256) != 10     # too few chunks to split
     assert form(ed=36) != 10                     # not whole 8-slice bricks
