@@ -111,7 +111,7 @@ print("failures:", bad)
 if len(sys.argv) > 1 and not bad:
     del os.environ["DM3D_CONV_WIDE_WGS"]; os.environ["DM3D_CONV_WINO_MINCHUNKS"] = "1"
     B = int(os.environ.get("AB_BATCH", "32"))
-    for name, e, cin, cout, res in [("32^3 64->64 pro+res", 32, 64, 64, 1), ("32^3 96->64 pro", 32, 96, 64, 0), ("32^3 192->64 pro", 32, 192, 64, 0),
+    for name, e, cin, cout, res in [("32^3 32->64 pro", 32, 32, 64, 0), ("32^3 64->64 pro+res", 32, 64, 64, 1), ("32^3 96->64 pro", 32, 96, 64, 0), ("32^3 192->64 pro", 32, 192, 64, 0),
                                     ("16^3 128->128 pro+res", 16, 128, 128, 1), ("16^3 384->128 pro", 16, 384, 128, 0), ("8^3 256->256 pro", 8, 256, 256, 0), ("8^3 512->256 pro", 8, 512, 256, 0), ("8^3 256->256 pro+res", 8, 256, 256, 1)]:
         x = torch.randn(B, e, e, e, cin, device=dev)
         k = torch.randn(3, 3, 3, cin, cout, device=dev) * 0.05
