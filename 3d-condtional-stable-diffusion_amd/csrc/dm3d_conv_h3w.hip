@@ -146,13 +146,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
     const int b_pos = pi_pos(row);
     const int b_hi = (half * NT + b_pos) * REC + ((q ^ swz(b_pos)) << 3);
 
-    f32x4v acc[4][4][4];                                                // [t][2 * slice + row group][column tile]
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int pi = 0; pi < 4; ++pi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[t][pi][ni] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    f32x4v acc[4][4][4];                                                // [t][2 * slice + row group][column tile]; zeroed in the prologue
 
     // weights: the packed image IS the LDS image, step sq of this column tile is a linear 8 KB copy; wave w moves the 1 KB pieces w, w + 4
     const char* w_img = reinterpret_cast<const char*>(static_cast<const _Float16*>(p.wpk) + (size_t)ntile * p.nchunks * NS * WPAIR) + wave * 1024 + lane * 16;
@@ -290,6 +284,15 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
 #pragma unroll
     for (int hx = 0; hx < 10; ++hx) load_voxel(c_lo, hx);
     load_chunk_params(c_lo);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                acc[t][pi][ni] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                asm volatile("" : "+a"(acc[t][pi][ni]));      // zeroed HERE, in the shadow of the first image's loads (hipcc sinks the 256 writes to the first MFMA otherwise)
+            }
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0) (with an instruction hipcc's wait-count pass sees): halo and the first four weight steps
     chunk_masks();
 #pragma unroll
@@ -731,9 +734,9 @@ int launch_w(ConvArgs& a, hipStream_t st) {
 
 // The Winograd form serves a k3 / stride-1 launch when the caller supplied the transformed image (wpk_wino), the volume is whole 8 x 8 x 8
 // bricks, a fused skip conv is short or the main loop long (below), the grid gives every CU two workgroups in turn or exactly one
-// (the same threshold as the 8-slice bricks of the direct kernel: DM3D_CONV_WIDE_WGS) and Cin is at least 64 (four 16-channel chunks,
-// DM3D_CONV_WINO_MINCHUNKS: its unoverlapped prologue and epilogue cost as much as two chunks; at 64 input channels it is 7 % ahead of
-// the direct kernel, profiles/r03_wino_ab.log).  The input tensors must be below 4 GB (32-bit lane offsets).  DM3D_CONV_WINO=0 (A/B knob, read per
+// (the same threshold as the 8-slice bricks of the direct kernel: DM3D_CONV_WIDE_WGS) and Cin is at least 32 (two 16-channel chunks,
+// DM3D_CONV_WINO_MINCHUNKS: its unoverlapped prologue and epilogue cost as much as two chunks; at 32 input channels it is still 9 %
+// ahead of the direct kernel, at 64 10-13 %, profiles/r03_wino_ab.log).  The input tensors must be below 4 GB (32-bit lane offsets).  DM3D_CONV_WINO=0 (A/B knob, read per
 // call): never.
 bool dm3d_conv_h3w_serves(const ConvArgs& a, int which) {
     if (!a.wpk_wino || which != DM3D_CONV_K3S1 || a.parity || a.cout <= 32) return false;
@@ -744,7 +747,7 @@ bool dm3d_conv_h3w_serves(const ConvArgs& a, int which) {
     const char* e = getenv("DM3D_CONV_WINO");
     if (e && e[0] == '0') return false;
     const char* mc = getenv("DM3D_CONV_WINO_MINCHUNKS");
-    if (a.nchunks < (mc ? atoi(mc) : 4)) return false;
+    if (a.nchunks < (mc ? atoi(mc) : 2)) return false;
     const long long vox = (long long)a.batch * a.ind * a.inh * a.inw;
     if (vox * (a.c1 > a.c2 ? a.c1 : a.c2) * 4 >= (1ll << 32)) return false;
     const long wgs = (long)a.batch * (a.od / 8) * (a.oh / 8) * (a.ow / 8) * (a.coutpad / 64) * dm3d_conv_h3w_ksplit(a);

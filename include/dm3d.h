@@ -200,7 +200,7 @@ typedef struct dm3d_conv_desc {
     /* Optional weight image of the Winograd F(2,3)-along-x form of a DM3D_PREC_H3 k3 / stride-1 conv with cout > 32 (dm3d_pack_weights_h3w,
        packed with THIS conv's w_exp): two neighbouring outputs of a row from four transformed inputs — 36 instead of 54 MFMA k-steps per
        output pair, same split-float16 products and float32 accumulation (results differ from the direct form in the last bits only).
-       The kernel uses it when the volume is whole 8x8x8 bricks, Cin >= 64, the launch has no fused skip conv and enough bricks (a launch of
+       The kernel uses it when the volume is whole 8x8x8 bricks, Cin >= 32, the launch has no fused skip conv and enough bricks (a launch of
        at most 128 of its workgroups with Cin >= 256 and a linear epilogue splits Cin two ways, the halves meeting by atomic add)
        (dm3d_conv_tile_form() == 10); otherwise wpk serves the launch as before.  The transformed inputs are up to 2 max|x|: producers of
        such a conv must keep |x| <= 32752 (pass range_limit <= 32752 to them).  NULL: never. */

@@ -160,7 +160,7 @@ def test_winograd_cin_split_on_a_small_grid(dev, monkeypatch):
 
 
 def test_winograd_launch_policy(dev, monkeypatch):
-    """dm3d_conv_tile_form() names the Winograd form (10) only with the second image, whole 8x8x8 bricks, Cin >= 64, a large grid (or its Cin split) and at most a short
+    """dm3d_conv_tile_form() names the Winograd form (10) only with the second image, whole 8x8x8 bricks, Cin >= 32, a large grid (or its Cin split) and at most a short
     fused skip conv; DM3D_CONV_WINO=0 switches it off per call."""
     from dm3d_amd import _lib
     from dm3d_amd._lib import ConvDesc, lib
@@ -182,8 +182,8 @@ def test_winograd_launch_policy(dev, monkeypatch):
 
     assert form() == 10
     assert form(wino=False) == 8
-    assert form(c1=48) == 8                      # three chunks: the prologue / epilogue of the one-workgroup-per-CU form do not pay
-    assert form(c1=64) == 10
+    assert form(c1=16) == 8                      # one chunk: the prologue / epilogue of the one-workgroup-per-CU form do not pay
+    assert form(c1=32) == 10
     assert form(batch=1) != 10                   # 64 workgroups
     assert form(batch=4) == 10 and form(batch=6) != 10       # exactly one workgroup per CU is a full round; 384 workgroups are a round and a half
     assert form(e=8, c1=256, cout=256) == 10     # 128 workgroups, Cin >= 256: two workgroups per brick (the Cin split)
