@@ -122,6 +122,19 @@ def csrc_digest() -> str:
     return h.hexdigest()[:16]
 
 
+def _restarting(smp):
+    """step() of a sampler whose finished chain (t = 0 done) restarts from x_T, as the headline loop does: --steps may exceed T."""
+    left = [T_FULL]
+
+    def step():
+        if left[0] == 0:
+            smp.reset()
+            left[0] = T_FULL
+        smp.step()
+        left[0] -= 1
+    return step
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,8 +368,9 @@ def main():
                 roofline["clock_note"] = ("in-kernel shader clock of the Winograd-x conv kernel under sustained load on random data (median of " +
                                           ", ".join(f'{r["shape"]}: {r["clock_ghz_median"]}' for r in rows) + " GHz; matrix-pipe duty inside the chunk loop " +
                                           ", ".join(r["mfma_duty_in_loop"] for r in rows) + "; " + os.path.basename(path) +
-                                          "); one wave per SIMD: this kernel is bound by what a single wave can issue beside its MFMAs, not by the chip's "
-                                          "power management — the direct two-waves-per-SIMD kernel it replaces on these launches is (DESIGN.md section 4)")
+                                          "); one wave per SIMD: in cycles this kernel is bound by what a single wave can issue beside its MFMAs (the same "
+                                          "duty on all-zero operands at 2.38 GHz); the clock those cycles run at is set by the chip's power management "
+                                          "(socket power 1.3-1.35 kW under the sustained chain: profiles/r03_clocks_under_load.log; DESIGN.md section 4)")
                 break
             if rows:
                 vals = sorted(float(r["clock_ghz_median"]) for r in rows)
@@ -376,12 +390,13 @@ def main():
         s32 = m32.sampler((B, S, S, S, Cc), context_value=1, seed=parallel.rank_seed(1234, rank), use_graph=not args.no_graph)
         s32.prepare()
         s32.reset()
+        step32 = _restarting(s32)
         for _ in range(max(1, Wm)):
-            s32.step()
+            step32()
         torch.cuda.synchronize()
         t32 = time.perf_counter()
         for _ in range(K):
-            s32.step()
+            step32()
         torch.cuda.synchronize()
         sp32 = (time.perf_counter() - t32) / K
         acc32 = [0, 0.0, 0.0]
@@ -410,12 +425,13 @@ def main():
         s8 = m8.sampler((B, S, S, S, Cc), context_value=1, seed=parallel.rank_seed(1234, rank), use_graph=not args.no_graph)
         s8.prepare()
         s8.reset()
+        step8 = _restarting(s8)
         for _ in range(max(1, Wm)):
-            s8.step()
+            step8()
         torch.cuda.synchronize()
         t8 = time.perf_counter()
         for _ in range(K):
-            s8.step()
+            step8()
         torch.cuda.synchronize()
         sp8 = (time.perf_counter() - t8) / K
         acc8 = {}
