@@ -41,10 +41,11 @@
 // at pass heads, where the counted LDS waits can account for them.  The MFMAs are inline asm with the accumulator constrained to AGPRs (left
 // alone, hipcc's allocator shuffled accumulator tiles between AGPRs, VGPRs and scratch, and a scratch reload in this loop costs a vmcnt(0)).
 // First forms of this loop (staging in per-pass bursts; packed VALU; spills) ran at 0.54 MFMA duty and lost to the direct kernel; this one
-// holds 0.63-0.65 at 2.05-2.2 GHz (the same duty on all-zero operands: bound in cycles by single-wave issue, not by the power limit) and
-// takes 7-18 % less time than the direct kernel from 64 input channels up (profiles/r03_wino_*.log).  The prologue and the epilogue
-// (the shared one, once per slice) run unoverlapped — one workgroup per CU — and cost 15 % of a 12-chunk workgroup, a third of a
-// 4-chunk one: the launcher keeps launches with fewer chunks on the direct kernel.
+// holds 0.65-0.68 (the same duty on all-zero operands: in cycles it is bound by single-wave issue) at the 2.0-2.15 GHz the chip's power
+// limit leaves on real data (2.38 on zeros; profiles/r03_clocks_under_load.log), and takes 10-21 % less time than the direct kernel from
+// 32 input channels up (profiles/r03_wino_ab.log).  The prologue and the epilogue (the shared one, once per slice) run unoverlapped — one
+// workgroup per CU — and cost 10 % of a 12-chunk workgroup, a quarter of a 4-chunk one: one-chunk launches stay on the direct kernel.
+// A tenth of the MFMAs multiply the zero pad tap (5-9.5 % of the time: profiles/r03_wino_pad_cost.log; DESIGN.md section 8 on removing it).
 #include <cstdlib>
 #include "dm3d_conv_h3v2_parts.h"
 
@@ -213,9 +214,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
         if (s >= NLD) return 0;
         return 4 + (s == 0 ? PLOADS : 0);
     };
-    // ---- the staging arithmetic, two channels at a time (packed float32 VALU: v_pk_fma / v_pk_mul / v_pk_add).  Instruction COUNT is what
-    // matters here: a wave alone on its SIMD issues strictly in order and an MFMA holds its issue port for all 16 cycles — in-kernel stamps
-    // put a chunk at 15 360 cycles of MFMA + 4 cycles x every other instruction, to the percent, however the two are interleaved.
+    // ---- the staging arithmetic.  Two forms of the same operations in the same order: whole quads / pairs at once for the prologue's
+    // first image (act_quad, split_pair: nothing to hide behind yet), and one or two scalar instructions per MFMA gap inside the step loop
+    // (slot_gap below — packed float32 VALU costs far more than its count beside MFMAs: tools/micro/mfma_valu_overlap.hip).
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     h8 g_hi, g_lo;
 #define DM3D_PIN(x) asm volatile("" :: "v"(x))        /* an ordered use: what feeds it cannot sink below this point (instruction selection
@@ -306,11 +307,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
     }
     lds_barrier();
 
-    // ---- the step loop.  A wave alone on its SIMD has only its own MFMAs to hide its other instructions behind: an MFMA takes 4 cycles to
-    // issue and holds the matrix pipe for 16, so up to three other instructions ride in its shadow — if they are THERE, between two MFMAs,
-    // and independent of the neighbours (in-kernel stamps of the first forms of this loop, which issued reads, DMA and staging arithmetic in
-    // bursts between the passes: 28 000 cycles per chunk for 15 360 of MFMA, at 2.15 GHz — the chip is not at its power limit here, unlike
-    // under the two-waves-per-SIMD direct kernel).  So a pass is 16 GAPS, each one MFMA plus at most a few instructions:
+    // ---- the step loop.  A wave alone on its SIMD has only its own MFMAs to hide its other instructions behind: an MFMA holds the vector
+    // issue for 8 of its 16 cycles, so 8 cycles of other instructions ride in its shadow — if they are THERE, between two MFMAs, and
+    // independent of the neighbours (in-kernel stamps of the first forms of this loop, which issued reads, DMA and staging arithmetic in
+    // bursts between the passes: 28 000 cycles per chunk for 15 360 of MFMA).  So a pass is 16 GAPS, each one MFMA plus at most a few
+    // instructions:
     //   * fragment reads, one or two per group of four MFMAs, into registers the group just released.  Pass A (al.bh, row-group major)
     //     re-requests bl for this step's pass C behind groups 0-1 and al of the NEXT step behind groups 1-3; pass B (ah.bh, column-tile
     //     major) requests bh of the next step behind each group; pass C (ah.bl, row-group major) ah of the next step.  LDS returns in order:
@@ -559,6 +560,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
 #undef DM3D_DSR
     STAMP(28);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // the redundant tail fetches / reads
+    // (this wait must stay the first instruction behind the loop: an asm ds_read returns at once, and its destination — dead to hipcc after
+    // the last step — is hipcc's to reuse before the data has landed.  Pinning the twelve fragments here instead costs eight more spills.)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
