@@ -543,10 +543,12 @@ __global__ __launch_bounds__(256) void pack_weights_h3v2_kernel(const float* __r
         float v = 0.f;
         if (ci < cin && co < cout && tap < taps) {
             if (mode == 3) {
-                // Winograd F(2,3) along x (dm3d_conv_h3w.hip): virtual tap = 2 * step + h, step = 5 * t + tappair; (dz, dy) tap 2 * tappair + h
-                // (the tenth is a zero pad), transform term t of its three x taps
-                const int step = tap >> 1, tq = (step % 5) * 2 + (tap & 1), t = step / 5;
-                if (tq < 9) {
+                // Winograd F(2,3) along x (dm3d_conv_h3w.hip): virtual tap = 2 * step + h, step = 5 * t + tap pair; the pair's two (dz, dy)
+                // taps, lane half h picking one: (dz, 0) | (dz, 1) for pairs 0-2, (0, 2) | zero pad, (1, 2) | (2, 2) — two per-lane operand
+                // bases serve all five (the kernel's a_pair); transform term t of the tap's three x taps
+                const int step = tap >> 1, t = step / 5;
+                const int tq = (step % 5) < 3 ? (step % 5) * 3 + (tap & 1) : ((step % 5) == 3 ? ((tap & 1) ? -1 : 2) : ((tap & 1) ? 8 : 5));
+                if (tq >= 0) {
                     const float g0 = w[((long)(tq * 3 + 0) * cin + ci) * cout + co], g1 = w[((long)(tq * 3 + 1) * cin + ci) * cout + co],
                                 g2 = w[((long)(tq * 3 + 2) * cin + ci) * cout + co];
                     v = t == 0 ? g0 : (t == 1 ? 0.5f * ((g0 + g2) + g1) : (t == 2 ? 0.5f * ((g0 + g2) - g1) : g2));

@@ -56,10 +56,10 @@ using namespace h3v2;
 #ifdef DM3D_CLOCK_STAMPS
 __device__ unsigned long long* g_dbg_stamps_w = nullptr;
 extern "C" int dm3d_debug_set_stamps_wino(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_stamps_w), &p, sizeof(p)); }
-#define STAMP(i) do { if (g_dbg_stamps_w && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) { \
-    g_dbg_stamps_w[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
-    if ((i) == 1) g_dbg_stamps_w[blockIdx.x * 32 + 30] = __builtin_amdgcn_s_memrealtime(); \
-    if ((i) == 28) g_dbg_stamps_w[blockIdx.x * 32 + 31] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define STAMP(i) do { if (g_dbg_stamps_w && threadIdx.x == 0 && cur.ntile == 0 && cur.khalf == 0 && item / ny < 4096u) { \
+    g_dbg_stamps_w[(item / ny) * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if ((i) == 1) g_dbg_stamps_w[(item / ny) * 32 + 30] = __builtin_amdgcn_s_memrealtime(); \
+    if ((i) == 28) g_dbg_stamps_w[(item / ny) * 32 + 31] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -75,7 +75,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // MODE 0: float32 input as is; 1: float32 input through the fused norm + SiLU prologue; 2: x1 already activated and split (DM3D_FMT_H2)
-template <int MODE>
+// SKIP: the launch carries a fused 1x1 skip conv (its tail phase and the LDS-staged epilogue overlay the main loop's images: one work item
+// per workgroup); otherwise the workgroup is PERSISTENT: it walks a list of work items, and the next item's first image and weight steps are
+// staged during the last chunk of the current one
+template <int MODE, bool SKIP>
 __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
     constexpr int TD = 8, TH = 8, TW = 8, CK = 16, NT = 64, NW = 4;
     constexpr int HD = TD + 2, HH = TH + 2, HROWS = HD * HH;
@@ -92,33 +95,48 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
     _Float16* lds_w = smem_w;                   // [RING][2 taps][NT][REC]
     _Float16* lds_in = smem_w + RING * WPAIR;   // [HROWS][4 t][4 x-pairs (+ 1 pad)][REC]
 
-    STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform: DMA destinations, M0, stay in scalar registers)
     const int half = lane >> 5, q = (lane >> 4) & 1, row = lane & 15;
 
-    // ---- XCD-aware work assignment (as dm3d_conv_h3v3.hip: a pure renumbering of the grid)
-    const int ny = gridDim.y;
-    int brick, by;
-    {
-        const unsigned total = gridDim.x * gridDim.y;
-        const unsigned d = blockIdx.x + gridDim.x * blockIdx.y;
-        unsigned w = d;
-        if ((total & 7u) == 0) w = (d & 7u) * (total >> 3) + (d >> 3);
-        brick = (int)(w / (unsigned)ny);
-        by = (int)(w - (unsigned)brick * (unsigned)ny);
-    }
-    // by = ntile + ntiles * khalf.  ksplit == 2 (grids that would leave half the CUs idle: the 8^3 level at B = 32): this workgroup contracts
-    // chunks [c_lo, c_hi) only; the shared epilogue adds the two partial sums into the zeroed output (or stores them for the reduce launch).
+    // ---- work items.  An item = (brick, column tile, Cin part); item w = brick * ny + by, by = ntile + ntiles * khalf (column tile fastest:
+    // the column tiles of one brick share all of its halo voxels).  XCD-aware as in dm3d_conv_h3v3.hip: dispatch ids d and d + 8 share an
+    // XCD, XCD k takes the k-th contiguous eighth of the item list, and inside the XCD the G / 8 workgroups take its items round-robin, so
+    // that the workgroups of one L2 work on neighbouring bricks at about the same time.  ksplit == 2 (grids that would leave half the CUs
+    // idle: the 8^3 level at B = 32): an item contracts chunks [c_lo, c_hi) only; the shared epilogue adds the two partial sums into the
+    // zeroed output (or stores them for the reduce launch).
     const int ntiles = p.coutpad / NT;
-    const int ntile = by % ntiles, khalf = by / ntiles;
-    const int c_lo = khalf * (p.nchunks / p.ksplit), c_hi = c_lo + p.nchunks / p.ksplit;
+    const unsigned ny = (unsigned)(ntiles * p.ksplit);
     const int bpv = p.bd * p.bh * p.bw;
-    const int b = brick / bpv;
-    brick -= b * bpv;
-    const int oz0 = (brick / (p.bh * p.bw)) * TD;
-    const int oy0 = ((brick / p.bw) % p.bh) * TH;
-    const int ox0 = (brick % p.bw) * TW;
+    const int cpp = p.nchunks / p.ksplit;                                // chunks per Cin part
+    unsigned item, item_end, item_step;
+    {
+        const unsigned n_items = (unsigned)(p.batch * bpv) * ny, G = gridDim.x, d = blockIdx.x;
+        if ((G & 7u) == 0 && (n_items & 7u) == 0) {
+            const unsigned per = n_items >> 3;
+            item = (d & 7u) * per + (d >> 3); item_end = (d & 7u) * per + per; item_step = G >> 3;
+        } else { item = d; item_end = n_items; item_step = G; }
+    }
+    struct Item { int b, oz0, oy0, ox0, ntile, khalf; };
+    auto decode = [&](unsigned w) {
+        Item it;
+        unsigned brick = w / ny;
+        const unsigned by = w - brick * ny;
+        it.ntile = (int)(by % (unsigned)ntiles); it.khalf = (int)(by / (unsigned)ntiles);
+        it.b = (int)(brick / (unsigned)bpv);
+        brick -= (unsigned)(it.b * bpv);
+        it.oz0 = (int)(brick / (unsigned)(p.bh * p.bw)) * TD;
+        it.oy0 = (int)((brick / (unsigned)p.bw) % (unsigned)p.bh) * TH;
+        it.ox0 = (int)(brick % (unsigned)p.bw) * TW;
+        // (uniform, but the divisions run on the vector unit: without this hipcc keeps both items and everything derived from them —
+        // the weight pointers — in vector registers, twenty of them across the step loop)
+        it.b = __builtin_amdgcn_readfirstlane(it.b); it.oz0 = __builtin_amdgcn_readfirstlane(it.oz0); it.oy0 = __builtin_amdgcn_readfirstlane(it.oy0);
+        it.ox0 = __builtin_amdgcn_readfirstlane(it.ox0); it.ntile = __builtin_amdgcn_readfirstlane(it.ntile); it.khalf = __builtin_amdgcn_readfirstlane(it.khalf);
+        return it;
+    };
+    Item cur = decode(item);
+    int c_lo = cur.khalf * cpp, c_hi = c_lo + cpp;
+    STAMP(0);
 
     // ---- staging: thread t owns 16-byte piece t & 1 (8 channels) of halo row t >> 1 = (hz, hy): ten voxels in, sixteen records out.
     // (neighbouring lanes take the two pieces of one voxel: a wave's load instruction touches 32 cache lines, not 64)
@@ -126,14 +144,20 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
     const bool s_act = (tid >> 1) < HROWS;
     const int srow = s_act ? (tid >> 1) : HROWS - 1;
     const int hz = srow / HH, hy = srow % HH;
-    const int iz = oz0 - 1 + hz, iy = oy0 - 1 + hy;
-    const bool row_in = iz >= 0 && iz < p.ind && iy >= 0 && iy < p.inh;
-    const bool x_lo = ox0 > 0, x_hi = ox0 + TW < p.inw;                 // is halo column 0 / 9 inside the volume
-    int gv0;                                                            // voxel index of halo column 0 (rows outside the volume: a clamped row, masked later)
-    {
+    // the staging state always describes the image being staged — the next chunk's, which in a persistent workgroup's last chunk is the
+    // NEXT item's first image: sample, whether this thread's halo row lies inside the volume, whether halo columns 0 / 9 do, and the voxel
+    // index of halo column 0 (rows outside the volume: a clamped row, masked later)
+    int sb, gv0;
+    bool row_in, x_lo, x_hi;
+    auto stage_setup = [&](const Item& it) {
+        const int iz = it.oz0 - 1 + hz, iy = it.oy0 - 1 + hy;
+        row_in = iz >= 0 && iz < p.ind && iy >= 0 && iy < p.inh;
+        x_lo = it.ox0 > 0; x_hi = it.ox0 + TW < p.inw;
         const int izc = iz < 0 ? 0 : (iz >= p.ind ? p.ind - 1 : iz), iyc = iy < 0 ? 0 : (iy >= p.inh ? p.inh - 1 : iy);
-        gv0 = ((b * p.ind + izc) * p.inh + iyc) * p.inw + ox0 - 1;
-    }
+        gv0 = ((it.b * p.ind + izc) * p.inh + iyc) * p.inw + it.ox0 - 1;
+        sb = it.b;
+    };
+    stage_setup(cur);
     const int st_base = srow * RREC * REC + ((piece ^ (hy & 3)) << 3);  // halfs: record k = t * 4 + xpair sits k * REC further; lo piece: ^ 16
 
     // ---- operand addressing: lane (half, q, row): row = 4 * xpair + y inside a group, half = tap of the pair, q = 8-channel piece
@@ -149,19 +173,22 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
 
     f32x4v acc[4][4][4];                                                // [t][2 * slice + row group][column tile]; zeroed in the prologue
 
-    // weights: the packed image IS the LDS image, step sq of this column tile is a linear 8 KB copy; wave w moves the 1 KB pieces w, w + 4
-    const char* w_img = reinterpret_cast<const char*>(static_cast<const _Float16*>(p.wpk) + (size_t)ntile * p.nchunks * NS * WPAIR) + wave * 1024 + lane * 16;
-    const int sq_end = c_hi * NS;
-    auto fetch_w1 = [&](int sq, int slot, const int i) {              // unconditional (past the end the last step is fetched again): hipcc can count what is in flight
-        const char* src = w_img + (size_t)(sq < sq_end ? sq : sq_end - 1) * (WPAIR * 2);
+    // weights: the packed image IS the LDS image, a step of a column tile is a linear 8 KB copy; wave w moves the 1 KB pieces w, w + 4.
+    // Source = a per-lane pointer into the image of the chunk being multiplied + a uniform offset (the steps of the chunk behind it — in an
+    // item's last chunk the next item's first — lie w_jump further).
+    auto w_chunk = [&](int ntile_, int ch_) {
+        return reinterpret_cast<const char*>(static_cast<const _Float16*>(p.wpk) + ((size_t)ntile_ * p.nchunks + ch_) * (NS * WPAIR));
+    };
+    const char* wcur = w_chunk(cur.ntile, c_lo);                          // (uniform)
+    const char* wlane = wcur + (wave * 1024 + lane * 16);                 // this lane's 16 bytes of step 0 of the chunk being multiplied
+    long w_jump = 0;                                                      // (uniform) bytes from that chunk's image to the image of the chunk behind it
+    auto fetch_w1 = [&](const long off, int slot, const int i) {
         char* dst = reinterpret_cast<char*>(lds_w) + slot * (WPAIR * 2) + wave * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * (NW * 1024)),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wlane + (off + i * (NW * 1024))),
                                          (__attribute__((address_space(3))) void*)(dst + i * (NW * 1024)), 16, 0, 0);
     };
-    auto fetch_w = [&](int sq, int slot) { fetch_w1(sq, slot, 0); fetch_w1(sq, slot, 1); };
-    int sq = c_lo * NS;                                  // running step number of the step being multiplied
 #pragma unroll
-    for (int i = 0; i < RING; ++i) fetch_w(sq + i, i);        // the ring starts full; pass B of step s refills s's buffer with step s + 4  (NS % RING == 0: slot = step & 3)
+    for (int i = 0; i < RING; ++i) { fetch_w1(i * (WPAIR * 2), i, 0); fetch_w1(i * (WPAIR * 2), i, 1); }      // the ring starts full; pass B of step s refills s's buffer with step s + 4  (NS % RING == 0: slot = step & 3)
 
     f32x4 va[10][2];                                     // the row's ten voxels: raw -> activated float32, in place
     u32x4 oh[4], ol[4];                                  // one transform term's four records (x-pairs), hi and lo pieces
@@ -201,7 +228,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
         ok1 = cpos + 4 < ldc;
         if (pro) {
             const int s0 = ok0 ? c0 + piece * 8 : 0, s1 = ok1 ? c0 + piece * 8 + 4 : 0;
-            const size_t bo = (size_t)b * p.pro_bstride;
+            const size_t bo = (size_t)sb * p.pro_bstride;
             sc0 = *reinterpret_cast<const f32x4*>(p.pscale + bo + s0);
             sh0 = *reinterpret_cast<const f32x4*>(p.pshift + bo + s0);
             sc1 = *reinterpret_cast<const f32x4*>(p.pscale + bo + s1);
@@ -268,10 +295,20 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
         km[0][0] = row_in && x_lo && ok0; km[0][1] = row_in && x_lo && ok1; km[1][0] = row_in && ok0; km[1][1] = row_in && ok1;
         km[2][0] = row_in && x_hi && ok0; km[2][1] = row_in && x_hi && ok1;
     };
+    // (inline asm with the lo address made on the spot: as C++ stores hipcc keeps both addresses in registers for the whole loop — and, the
+    // register file being full, spills them and reloads them at every store site behind a vmcnt(0))
+    const unsigned st_addr = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)lds_in + (unsigned)st_base * 2u;
     auto store_record = [&](const int t, const int xt) {
         if (s_act) {
-            *reinterpret_cast<u32x4*>(lds_in + st_base + (t * 4 + xt) * REC) = t == 3 ? o3h[xt] : oh[xt];
-            *reinterpret_cast<u32x4*>(lds_in + ((st_base + (t * 4 + xt) * REC) ^ 16)) = t == 3 ? o3l[xt] : ol[xt];
+            unsigned lo_addr;
+            const u32x4 dh = t == 3 ? o3h[xt] : oh[xt], dl = t == 3 ? o3l[xt] : ol[xt];
+            switch (t * 4 + xt) {
+#define DM3D_ST(k_) case k_: asm volatile("ds_write_b128 %1, %2 offset:%4\n\tv_xor_b32 %0, 32, %1\n\tds_write_b128 %0, %3 offset:%4" \
+                                          : "=&v"(lo_addr) : "v"(st_addr), "v"(dh), "v"(dl), "n"((k_) * REC * 2) : "memory"); break;
+                DM3D_ST(0) DM3D_ST(1) DM3D_ST(2) DM3D_ST(3) DM3D_ST(4) DM3D_ST(5) DM3D_ST(6) DM3D_ST(7)
+                DM3D_ST(8) DM3D_ST(9) DM3D_ST(10) DM3D_ST(11) DM3D_ST(12) DM3D_ST(13) DM3D_ST(14) DM3D_ST(15)
+#undef DM3D_ST
+            }
         }
     };
     // raw barrier behind this wave's own LDS traffic (never drains the vector-memory counter: the DMA fills stay in flight across it)
@@ -326,31 +363,33 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
     // moved accumulator tiles between AGPRs, VGPRs and scratch around the term blocks, and every scratch reload inside the loop is
     // followed by vmcnt(0), which drains the weight DMA and halo requests in flight.
     h8 ah[4], al[4], bh[4], bl[4];
-    // per-lane operand bases: tap pair tp = taps 2tp, 2tp + 1 of the nine (dz, dy) (the pad tap re-reads the last real tap's voxels against
-    // zero weights), the lane half picks the tap; hi piece (lo: ^ 32)
-    unsigned a_tp[5];
-#pragma unroll
-    for (int tp = 0; tp < 5; ++tp) {
-        const int ta = 2 * tp, tb = ta + 1 < 9 ? ta + 1 : 8;
-        const unsigned ka = (unsigned)((((ta / 3) * HH + ta % 3) * RREC) * (REC * 2)), kb = (unsigned)((((tb / 3) * HH + tb % 3) * RREC) * (REC * 2));
-        a_tp[tp] = a_base + (half ? kb + sl[tb % 3] : ka + sl[ta % 3]);
-    }
-    const unsigned wb_hi = w_addr + (unsigned)b_hi * 2u, wb_lo = w_addr + (unsigned)(b_hi ^ 16) * 2u;
+    // per-lane operand bases.  A step's tap pair = two (dz, dy) taps, the lane half picks one: pairs 0-2 = (dz, 0) | (dz, 1) for dz = 0, 1, 2;
+    // pair 3 = (0, 2) | the pad (the voxels of (1, 2) against zero weights); pair 4 = (1, 2) | (2, 2).  So TWO lane-dependent bases serve
+    // all five (the swizzled slot depends on dy only) and the pair is an immediate: a_pair[0] + dz * DZ, a_pair[1] + {0, DZ}; hi piece (lo: ^ 32)
+    constexpr int DZB = HH * RREC * REC * 2, DYB = RREC * REC * 2;        // bytes to the halo row one z / one y further
+    unsigned a_pair[2];
+    a_pair[0] = a_base + (half ? DYB + sl[1] : sl[0]);
+    a_pair[1] = a_base + 2 * DYB + sl[2] + (half ? DZB : 0);
+    const unsigned wb_hi = w_addr + (unsigned)b_hi * 2u;                   // hi piece (lo: ^ 32)
+    // the lo-piece addresses are made where they are used (one v_xor_b32 per step and operand), not kept: registers
+    auto lo_of = [](const unsigned a) { unsigned r; asm volatile("v_xor_b32 %0, 32, %1" : "=v"(r) : "v"(a)); return r; };
 #define DM3D_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
     constexpr int GOFF = 4 * RREC * REC * 2, SOFF = HH * RREC * REC * 2;    // bytes to the second row group / the second slice
-    // fragment i (0 .. 3: slice i >> 1, row group i & 1) of step s (term s / 5: 256 bytes per term inside a halo row)
-    auto read_a = [&](h8 (&dst)[4], const int s, const int i, const bool lo) {
-        const unsigned a0 = lo ? a_tp[s % 5] ^ 32u : a_tp[s % 5];
-        switch ((s / 5) * 4 + i) {
-#define DM3D_RA(t_, i_) case (t_) * 4 + (i_): DM3D_DSR(dst[i_], a0, (t_) * 4 * REC * 2 + ((i_) >> 1) * SOFF + ((i_) & 1) * GOFF); break;
+    auto a_hi = [&](const int s) { return a_pair[(s % 5) >= 3]; };
+    // fragment i (0 .. 3: slice i >> 1, row group i & 1) of step s (term s / 5: 256 bytes per term inside a halo row) from a0 = a_hi(s) or its lo twin
+    auto read_a = [&](h8 (&dst)[4], const int s, const int i, const unsigned a0) {
+        const int tp = s % 5;
+        switch (((s / 5) * 4 + i) * 3 + (tp < 3 ? tp : tp - 3)) {      // (term, fragment, z step of the pair): the immediate offset
+#define DM3D_RA1(t_, i_, z_) case ((t_) * 4 + (i_)) * 3 + (z_): DM3D_DSR(dst[i_], a0, (z_) * DZB + (t_) * 4 * REC * 2 + ((i_) >> 1) * SOFF + ((i_) & 1) * GOFF); break;
+#define DM3D_RA(t_, i_) DM3D_RA1(t_, i_, 0) DM3D_RA1(t_, i_, 1) DM3D_RA1(t_, i_, 2)
             DM3D_RA(0, 0) DM3D_RA(0, 1) DM3D_RA(0, 2) DM3D_RA(0, 3) DM3D_RA(1, 0) DM3D_RA(1, 1) DM3D_RA(1, 2) DM3D_RA(1, 3)
             DM3D_RA(2, 0) DM3D_RA(2, 1) DM3D_RA(2, 2) DM3D_RA(2, 3) DM3D_RA(3, 0) DM3D_RA(3, 1) DM3D_RA(3, 2) DM3D_RA(3, 3)
 #undef DM3D_RA
+#undef DM3D_RA1
         }
     };
-    // column tile i of the weights in ring slot `slot`
-    auto read_b = [&](h8 (&dst)[4], const int slot, const int i, const bool lo) {
-        const unsigned wa = lo ? wb_lo : wb_hi;
+    // column tile i of the weights in ring slot `slot` from wa = wb_hi or its lo twin
+    auto read_b = [&](h8 (&dst)[4], const int slot, const int i, const unsigned wa) {
         switch (slot * 4 + i) {
 #define DM3D_RB(k_, i_) case (k_) * 4 + (i_): DM3D_DSR(dst[i_], wa, (k_) * WPAIR * 2 + (i_) * 16 * REC * 2); break;
             DM3D_RB(0, 0) DM3D_RB(0, 1) DM3D_RB(0, 2) DM3D_RB(0, 3) DM3D_RB(1, 0) DM3D_RB(1, 1) DM3D_RB(1, 2) DM3D_RB(1, 3)
@@ -394,15 +433,35 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
         if (G >= 208 && G < 568) {
             const int i = (G - 208) / 18, r = (G - 208) % 18;
             const int hx = i >> 1, h = i & 1, col = hx == 0 ? 0 : (hx == 9 ? 2 : 1);
-            if (xh2) {                   // the split pair back to one float32 per channel
-                if (r == 0 && h == 0) { g_hi = __builtin_bit_cast(h8, va[hx][0]); g_lo = __builtin_bit_cast(h8, va[hx][1]); }
-                if (r < 4) { const _Float16 a = g_hi[4 * h + r], b = g_lo[4 * h + r]; g_y[r] = (float)a; g_z[r] = (float)b; DM3D_PIN(g_y[r]); DM3D_PIN(g_z[r]); }
-                else if (r < 6) { const int c = 2 * (r - 4); g_y[c] += g_z[c]; g_y[c + 1] += g_z[c + 1]; DM3D_PIN(g_y[c]); DM3D_PIN(g_y[c + 1]); }
-                else if (r < 8) {
-                    const int c = 2 * (r - 6);
-                    float v0 = km[col][0] ? g_y[c] : 0.0f, v1 = km[col][0] ? g_y[c + 1] : 0.0f;
-                    DM3D_PIN(v0); DM3D_PIN(v1);
-                    va[hx][h][c] = v0; va[hx][h][c + 1] = v1;
+            if (xh2) {
+                // the split pair back to one float32 per channel: (float)hi + (float)lo as ONE v_fma_mix_f32 (hi * 1.0 + lo, both read as
+                // float16 halves straight from the loaded registers: the same single rounding).  va[hx][0] / [1] arrive as the hi / lo
+                // halves of channels 0-7 and leave as the float32 channels 0-3 / 4-7: channels 0-3 wait in g_y until 4-7, which are
+                // written over the lo halves in an order that has consumed them, have read the hi halves.
+                auto mix = [&](const int c) {          // channel c of the voxel
+                    float d;
+                    const float hv = va[hx][0][c >> 1], lv = va[hx][1][c >> 1];
+                    if (c & 1) asm volatile("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(hv), "v"(lv));
+                    else asm volatile("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(hv), "v"(lv));
+                    return d;
+                };
+                if (h == 0) {
+                    if (r < 2) { g_y[2 * r] = mix(2 * r); g_y[2 * r + 1] = mix(2 * r + 1); }
+                } else {
+                    if (r < 2) {
+                        const float v0 = mix(4 + 2 * r), v1 = mix(5 + 2 * r);
+                        va[hx][1][2 * r] = v0; va[hx][1][2 * r + 1] = v1;
+                    } else if (r < 4) {
+                        const int c = 2 * (r - 2);
+                        float v0 = km[col][0] ? g_y[c] : 0.0f, v1 = km[col][0] ? g_y[c + 1] : 0.0f;
+                        DM3D_PIN(v0); DM3D_PIN(v1);
+                        va[hx][0][c] = v0; va[hx][0][c + 1] = v1;
+                    } else if (r < 6) {
+                        const int c = 2 * (r - 4);
+                        float v0 = km[col][0] ? va[hx][1][c] : 0.0f, v1 = km[col][0] ? va[hx][1][c + 1] : 0.0f;
+                        DM3D_PIN(v0); DM3D_PIN(v1);
+                        va[hx][1][c] = v0; va[hx][1][c + 1] = v1;
+                    }
                 }
                 return;
             }
@@ -468,15 +527,31 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
 #define DM3D_MFMA(T, PI, NI, A, B) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[T][PI][NI]) : "v"(A[PI]), "v"(B[NI]))
 #define DM3D_WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(n) : "memory")
 
-    read_a(al, 0, 0, true); read_a(al, 0, 1, true); read_a(al, 0, 2, true); read_a(al, 0, 3, true);
-    read_b(bh, 0, 0, false); read_b(bh, 0, 1, false); read_b(bh, 0, 2, false); read_b(bh, 0, 3, false);
-    read_a(ah, 0, 0, false); read_a(ah, 0, 1, false); read_a(ah, 0, 2, false); read_a(ah, 0, 3, false);
+    // ---- the item loop (persistent form; SKIP: one pass)
+    bool has_next = !SKIP && item + item_step < item_end;
+    for (;;) {
+    // (requested here, not carried over from the previous item's last step: the epilogue wants the registers)
+    {
+        const unsigned a_lo0 = lo_of(a_hi(0));
+        read_a(al, 0, 0, a_lo0); read_a(al, 0, 1, a_lo0); read_a(al, 0, 2, a_lo0); read_a(al, 0, 3, a_lo0);
+    }
+    read_b(bh, 0, 0, wb_hi); read_b(bh, 0, 1, wb_hi); read_b(bh, 0, 2, wb_hi); read_b(bh, 0, 3, wb_hi);
+    read_a(ah, 0, 0, a_hi(0)); read_a(ah, 0, 1, a_hi(0)); read_a(ah, 0, 2, a_hi(0)); read_a(ah, 0, 3, a_hi(0));
     STAMP(1);
 
     for (int ch = c_lo; ch < c_hi; ++ch) {
         // keeps the per-voxel offsets from being hoisted out of the chunk loop as 64-bit pairs
         asm volatile("" : "+v"(gv0));
-        const int ch_next = ch + 1 < c_hi ? ch + 1 : ch;       // (past the end: the last chunk again, unconditional like the DMAs)
+        // the chunk staged during this one: the item's next chunk; in its last chunk the NEXT item's first (the staging state moves on to
+        // that item's brick: nothing of this item is staged any more); behind the last item the same chunk again (unconditional like the DMAs)
+        int ch_next;
+        if (ch + 1 < c_hi) { ch_next = ch + 1; w_jump = NS * WPAIR * 2; }
+        else if (has_next) {
+            // (decoded here, once per item: the next item's coordinates do not live in registers across the chunk loop)
+            const Item n = decode(item + item_step);
+            stage_setup(n); ch_next = n.khalf * cpp; w_jump = w_chunk(n.ntile, ch_next) - w_chunk(cur.ntile, ch);
+        }
+        else { ch_next = ch; w_jump = 0; }
         // (a generic lambda over integral constants, not `#pragma unroll`: hipcc unrolls a 20-step body of this size only in part, and a step
         // index that is not a constant turns acc[t] into scratch memory)
         static_for<NS>([&](auto S_) {
@@ -495,14 +570,17 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
             }
             head_stores(3 * s);
             __builtin_amdgcn_sched_barrier(0);
+            unsigned b_lo = 0u, a_lo = 0u;
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 DM3D_MFMA(t, g >> 2, g & 3, al, bh);
                 slot_gap(16 * (3 * s) + g);
-                if (g == 3) { read_b(bl, ws, 0, true); read_b(bl, ws, 1, true); }
-                if (g == 7) { read_b(bl, ws, 2, true); read_b(bl, ws, 3, true); read_a(al, sn, 0, true); }
-                if (g == 11) { read_a(al, sn, 1, true); read_a(al, sn, 2, true); }
-                if (g == 15) read_a(al, sn, 3, true);
+                if (g == 2) b_lo = lo_of(wb_hi);
+                if (g == 3) { read_b(bl, ws, 0, b_lo); read_b(bl, ws, 1, b_lo); }
+                if (g == 6) a_lo = lo_of(a_hi(sn));
+                if (g == 7) { read_b(bl, ws, 2, b_lo); read_b(bl, ws, 3, b_lo); read_a(al, sn, 0, a_lo); }
+                if (g == 11) { read_a(al, sn, 1, a_lo); read_a(al, sn, 2, a_lo); }
+                if (g == 15) read_a(al, sn, 3, a_lo);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // ---- pass B: ah(s).bh(s), column-tile major.  Its head is the step's one barrier: behind this wave's lgkmcnt(4) (its reads of
@@ -527,15 +605,16 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
                 asm volatile("" ::: "memory");
             }
             __builtin_amdgcn_sched_barrier(0);
-            fetch_w1(sq + RING, ws, 0);              // into the buffer step s just left (an LDS-DMA piece costs ~60 cycles of issue: the second one two gaps on)
+            const long w_src = s + RING < NS ? (long)((s + RING) * (WPAIR * 2)) : w_jump + (s + RING - NS) * (WPAIR * 2);      // step s + 4
+            fetch_w1(w_src, ws, 0);                  // into the buffer step s just left (an LDS-DMA piece costs ~60 cycles of issue: the second one two gaps on)
             head_stores(3 * s + 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 DM3D_MFMA(t, g & 3, g >> 2, ah, bh);
                 slot_gap(16 * (3 * s + 1) + g);
-                if ((g & 3) == 3) read_b(bh, ws1, g >> 2, false);
-                if (g == 1) fetch_w1(sq + RING, ws, 1);
+                if ((g & 3) == 3) read_b(bh, ws1, g >> 2, wb_hi);
+                if (g == 1) fetch_w1(w_src, ws, 1);
                 if (s < NLD && g == 5) load_voxel(ch_next, 2 * s);
                 if (s < NLD && g == 9) load_voxel(ch_next, 2 * s + 1);
                 if (s == 0 && g == 13) load_chunk_params(ch_next);
@@ -548,26 +627,75 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
             for (int g = 0; g < 16; ++g) {
                 DM3D_MFMA(t, g >> 2, g & 3, ah, bl);
                 slot_gap(16 * (3 * s + 2) + g);
-                if ((g & 3) == 3) read_a(ah, sn, g >> 2, false);
+                if ((g & 3) == 3) read_a(ah, sn, g >> 2, a_hi(sn));
                 __builtin_amdgcn_sched_barrier(0);
             }
-            ++sq;
         });
+        wlane += w_jump;
     }
 #undef DM3D_MFMA
 #undef DM3D_WAIT_LGKM
 #undef DM3D_PIN
 #undef DM3D_DSR
     STAMP(28);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // the redundant tail fetches / reads
-    // (this wait must stay the first instruction behind the loop: an asm ds_read returns at once, and its destination — dead to hipcc after
-    // the last step — is hipcc's to reuse before the data has landed.  Pinning the twelve fragments here instead costs eight more spills.)
+    const Brick br = {cur.b, cur.oz0, cur.oy0, cur.ox0, p.ooz, p.ooy, p.oox, cur.ntile, cur.khalf};
+    if constexpr (!SKIP) {
+        // (this wait must stay the first instruction behind the loop: an asm ds_read returns at once, and its destination — dead to hipcc
+        // after the last step — is hipcc's to reuse before the data has landed.  The vector-memory counter is left alone: what is in
+        // flight are DMA pieces of the next item's first steps, on their way into ring buffers nobody reads before the next barrier.)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        STAMP(20);
+        // ---- output transform and the shared epilogue, one slice at a time straight from the accumulators (the LDS holds the next item's
+        // image and weights): tile (2g + parity, ni) of slice s = rows 4g .. 4g+3, x = 2 * x-pair + parity.
+        static_for<2>([&](auto S_) {
+            constexpr int s = decltype(S_)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if (s == 1) STAMP(21);
+            f32x4v e[4][4];
+            // (pinned in the accumulator file up to here: hipcc otherwise copies both slices' tiles out at the loop exit — 200 registers)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) asm volatile("" : "+a"(acc[t][2 * s + g][ni]));
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const f32x4v m0 = acc[0][2 * s + g][ni], m1 = acc[1][2 * s + g][ni], m2 = acc[2][2 * s + g][ni], m3 = acc[3][2 * s + g][ni];
+                    e[2 * g][ni] = (m0 + m1) + m2;
+                    e[2 * g + 1][ni] = (m1 - m2) - m3;
+                }
+            epilogue<TD, 4>(p, e, br, 2 * wave + s, 1, 2 * (lane >> 4));
+        });
+        STAMP(29);
+        if (!has_next) break;
+        // the accumulators of the next item: zeroed only now, with every old value dead (zeroing a slice's tiles as soon as they were read
+        // made hipcc's allocator move the OTHER slice's tiles out of the accumulator file, through vector registers and scratch memory)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    acc[t][pi][ni] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                    asm volatile("" : "+a"(acc[t][pi][ni]));
+                }
+        item += item_step;
+        cur = decode(item);
+        c_lo = cur.khalf * cpp; c_hi = c_lo + cpp;
+        has_next = item + item_step < item_end;
+        STAMP(0);
+        continue;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // the redundant tail fetches / reads (first behind the loop: see above)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    // ---- output transform, then the shared epilogue once per slice: tile (2g + parity, ni) of slice s = rows 4g .. 4g+3, x = 2 * xpair + parity
-    const Brick br = {b, oz0, oy0, ox0, p.ooz, p.ooy, p.oox, ntile, khalf};
     // ---- output transform: tile (2g + parity, ni) of slice s = rows 4g .. 4g+3, x = 2 * xpair + parity
+    const int b = cur.b, oz0 = cur.oz0, oy0 = cur.oy0, ox0 = cur.ox0, ntile = cur.ntile;
     f32x4v e[2][4][4];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -713,22 +841,35 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
         epilogue<TD, 4>(p, e, br, 2 * wave + s, 1, 2 * (lane >> 4));
     }
     STAMP(29);
+    break;
+    }       // items
 }
 
-template <int MODE>
+template <int MODE, bool SKIP>
 int launch_w(ConvArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)(4 * 2 * 64 * REC + 10 * 10 * 17 * REC) * sizeof(_Float16);      // 32 KB of weights + 106 KB of image
     static_assert(lds <= 160 * 1024, "one workgroup per CU");
-    static bool attr_set = false;
-    if (!attr_set) {
-        DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3w<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    // (per device: the attribute and the CU count belong to the device the launch goes to)
+    static int cus[64] = {0};
+    int dev = 0;
+    DM3D_HIP(hipGetDevice(&dev));
+    DM3D_REQUIRE(dev >= 0 && dev < 64, "conv: device ordinal %d", dev);
+    if (cus[dev] == 0) {
+        DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3w<MODE, SKIP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int n = 0;
+        DM3D_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        cus[dev] = n > 0 ? n : 256;
     }
     H3v2Launch L;
     if (int rc = dm3d_h3v2_pre_launch(a, 8, false, L, st, dm3d_conv_h3w_ksplit(a))) return rc;
     L.k.wpk = a.wpk_wino;
-    dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64 * a.ksplit), 1u);
-    hipLaunchKernelGGL((conv3d_igemm_h3w<MODE>), grid, dim3(256), lds, st, L.k);
+    // work items = bricks x column tiles x Cin parts.  With a fused skip conv every workgroup takes one (its tail phase overlays the
+    // images); otherwise one persistent workgroup per CU walks its share of the list (DM3D_CONV_WINO_PERSIST=0: one item per workgroup)
+    const long items = (long)a.batch * a.bd * a.bh * a.bw * (a.coutpad / 64) * a.ksplit;
+    static const bool persist = [] { const char* e = getenv("DM3D_CONV_WINO_PERSIST"); return !(e && e[0] == '0'); }();
+    long g = items;
+    if (!SKIP && persist && items > cus[dev]) g = (items % 8 == 0) ? (cus[dev] / 8 * 8) : cus[dev];
+    hipLaunchKernelGGL((conv3d_igemm_h3w<MODE, SKIP>), dim3((unsigned)g), dim3(256), lds, st, L.k);
     if (int rc = dm3d_launch_check("conv3d_igemm_h3w")) return rc;
     return dm3d_h3v2_post_launch(a, L, st);
 }
@@ -775,6 +916,10 @@ int dm3d_conv_h3w_ksplit(const ConvArgs& a) {
 
 int dm3d_conv_launch_h3w(ConvArgs& a, int which, hipStream_t st) {
     (void)which;
-    if (a.x_h2) return launch_w<2>(a, st);
-    return a.pscale ? launch_w<1>(a, st) : launch_w<0>(a, st);
+    if (a.s_npairs > 0) {
+        if (a.x_h2) return launch_w<2, true>(a, st);
+        return a.pscale ? launch_w<1, true>(a, st) : launch_w<0, true>(a, st);
+    }
+    if (a.x_h2) return launch_w<2, false>(a, st);
+    return a.pscale ? launch_w<1, false>(a, st) : launch_w<0, false>(a, st);
 }
