@@ -215,11 +215,14 @@ int launch_conv(ConvArgs& a, hipStream_t st) {
     a.bd = (a.od + TD - 1) / TD;
     a.bh = (a.oh + TH - 1) / TH;
     a.bw = (a.ow + TW - 1) / TW;
-    static bool attr_set = false;                       // one per instantiation
-    if (!attr_set) {
+    static bool attr_set[64] = {false};            // per device: the attribute belongs to the device the launch goes to
+    int dev_ = 0;
+    DM3D_HIP(hipGetDevice(&dev_));
+    DM3D_REQUIRE(dev_ >= 0 && dev_ < 64, "conv: device ordinal %d", dev_);
+    if (!attr_set[dev_]) {
         DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_f32<TD, TH, TW, S, KS, WM, WN>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[dev_] = true;
     }
     dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64), a.parity ? 8u : 1u);
     hipLaunchKernelGGL((conv3d_igemm_f32<TD, TH, TW, S, KS, WM, WN>), grid, dim3(256), lds, st, a);
@@ -278,10 +281,6 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
     a.prelu = d->prelu_alpha; a.relu_out = d->relu_out;
     a.scratch = d->scratch; a.scratch_bytes = d->scratch_bytes;
     a.range_flag = d->range_flag; a.range_limit = d->range_limit > 0.0f ? d->range_limit : 65504.0f;
-    if (d->wpk_f8) {
-        DM3D_REQUIRE(d->precision == DM3D_PREC_H3 && dm3d_aligned16(d->wpk_f8), "conv: wpk_f8 needs precision H3 and 16-byte alignment");
-        a.wpk_f8 = d->wpk_f8;
-    }
     if (d->wpk_wino) {
         DM3D_REQUIRE(d->precision == DM3D_PREC_H3 && dm3d_aligned16(d->wpk_wino), "conv: wpk_wino needs precision H3 and 16-byte alignment");
         a.wpk_wino = d->wpk_wino;
@@ -327,10 +326,10 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
     const int layout = dm3d_conv_weight_layout(d->ksize, d->stride, d->upsample, d->transpose, d->cout);
     DM3D_REQUIRE(d->w_layout == layout, "conv: w_layout %d but this geometry reads layout %d (dm3d_conv_weight_layout)", d->w_layout, layout);
     if (layout != DM3D_WL_PAIR) return dm3d_conv_launch_h3(a, which, st);
-    // same arguments and epilogue; the free-running form (dm3d_conv_h3v3.hip) unless the float8 cross-term arithmetic was asked for, or the
-    // Winograd-x form (dm3d_conv_h3w.hip, its own weight image) is eligible
-    if (dm3d_conv_h3v3_serves(a, which) && dm3d_conv_h3w_serves(a, which)) return dm3d_conv_launch_h3w(a, which, st);
-    return dm3d_conv_h3v3_serves(a, which) ? dm3d_conv_launch_h3v3(a, which, st) : dm3d_conv_launch_h3v2(a, which, st);
+    // same arguments and epilogue: the Winograd-x form (dm3d_conv_h3w.hip, its own weight image) where it is eligible, else the
+    // free-running direct form (dm3d_conv_h3v3.hip)
+    if (dm3d_conv_h3w_serves(a, which)) return dm3d_conv_launch_h3w(a, which, st);
+    return dm3d_conv_launch_h3v3(a, which, st);
 }
 
 extern "C" int64_t dm3d_packed_weight_skip_h3p_bytes(int32_t cin, int32_t cout) {
@@ -352,8 +351,6 @@ extern "C" int32_t dm3d_conv_tile_form(const dm3d_conv_desc* d) {
     a.coutpad = (int)dm3d_round_up(d->cout, DM3D_COUT_PAD);
     a.parity = par_mode ? 1 : 0;
     a.s_npairs = d->skip_wpk ? (int)(dm3d_round_up(d->skip_c1 + d->skip_c2, 32) / 32) : 0;
-    a.wpk_f8 = d->wpk_f8;
-    if (dm3d_conv_h3v2_f8(a)) return 9;
     a.wpk_wino = d->wpk_wino; a.cout = d->cout; a.c1 = d->c1; a.c2 = d->c2; a.ind = d->in_d; a.inh = d->in_h; a.inw = d->in_w;
     a.nchunks = (int)(dm3d_round_up(d->c1 + d->c2, DM3D_CIN_PAD) / 16);
     a.x1 = d->x1; a.x2 = d->x2; a.out = d->out; a.res = d->res; a.relu = d->relu; a.relu_out = d->relu_out; a.prelu = d->prelu_alpha;      // (the Cin split
@@ -395,7 +392,7 @@ extern "C" int dm3d_pack_weights_h3p(const float* keras_kernel, int32_t taps, in
     DM3D_REQUIRE(mode >= 0 && mode <= 2 && (mode == 0 || taps == 8), "pack_weights_h3p: mode %d with taps %d", mode, taps);
     DM3D_REQUIRE(w_exp >= -100 && w_exp <= 100, "pack_weights_h3p: w_exp %d out of range", w_exp);
     DM3D_REQUIRE(dm3d_aligned16(packed), "pack_weights_h3p: packed must be 16-byte aligned");
-    return dm3d_pack_h3v2(keras_kernel, taps, cin, cout, w_exp, in_scale, packed, mode, 0, static_cast<hipStream_t>(stream));
+    return dm3d_pack_h3v2(keras_kernel, taps, cin, cout, w_exp, in_scale, packed, mode, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int64_t dm3d_packed_weight_h3w_bytes(int32_t cin, int32_t cout) {
@@ -408,21 +405,7 @@ extern "C" int dm3d_pack_weights_h3w(const float* keras_kernel, int32_t cin, int
     DM3D_REQUIRE(keras_kernel && packed && cin > 0 && cout > 0, "pack_weights_h3w: bad arguments");
     DM3D_REQUIRE(w_exp >= -100 && w_exp <= 100, "pack_weights_h3w: w_exp %d out of range", w_exp);
     DM3D_REQUIRE(dm3d_aligned16(packed), "pack_weights_h3w: packed must be 16-byte aligned");
-    return dm3d_pack_h3v2(keras_kernel, 40, cin, cout, w_exp, in_scale, packed, 3, 0, static_cast<hipStream_t>(stream));
-}
-
-extern "C" int64_t dm3d_packed_weight_h3f8_bytes(int32_t taps, int32_t cin, int32_t cout) {
-    if (taps <= 0 || cin <= 0 || cout <= 0) return 0;
-    return dm3d_h3v2_image_bytes(taps, cin, cout, 1);
-}
-
-extern "C" int dm3d_pack_weights_h3f8(const float* keras_kernel, int32_t taps, int32_t cin, int32_t cout, int32_t w_exp,
-                                      const float* in_scale, void* packed, int32_t mode, void* stream) {
-    DM3D_REQUIRE(keras_kernel && packed && taps > 0 && cin > 0 && cout > 0, "pack_weights_h3f8: bad arguments");
-    DM3D_REQUIRE(mode >= 0 && mode <= 2 && (mode == 0 || taps == 8), "pack_weights_h3f8: mode %d with taps %d", mode, taps);
-    DM3D_REQUIRE(w_exp >= -100 && w_exp <= 100, "pack_weights_h3f8: w_exp %d out of range", w_exp);
-    DM3D_REQUIRE(dm3d_aligned16(packed), "pack_weights_h3f8: packed must be 16-byte aligned");
-    return dm3d_pack_h3v2(keras_kernel, taps, cin, cout, w_exp, in_scale, packed, mode, 1, static_cast<hipStream_t>(stream));
+    return dm3d_pack_h3v2(keras_kernel, 40, cin, cout, w_exp, in_scale, packed, 3, static_cast<hipStream_t>(stream));
 }
 
 int dm3d_conv_launch_f32(ConvArgs& a, int which, hipStream_t st) {

@@ -32,7 +32,6 @@ struct ConvArgs {
     int x_h2;                 // h3v2: x1 arrives in DM3D_FMT_H2 (c1 % 16 == 0, no x2, no prologue)
     // h3v2 only: a 1x1 conv over a second (raw, un-normalised) input accumulated into the same tile (ResidualBlock skip path)
     const float* sx1; const float* sx2; int sc1, sc2; const void* swpk; int s_npairs;   // s_npairs = round_up(sc1+sc2, 32) / 32
-    const void* wpk_f8;                      // optional second weight image: the float8 cross-term form (dm3d_h3.h "H3F8")
     const void* wpk_wino;                    // optional weight image of the Winograd-x form (dm3d_conv_h3w.hip)
     int* range_flag; float range_limit;      // H3 range guard (include/dm3d.h): *range_flag = 1 if any |output| > range_limit
     int epi_vec4;                            // h3v2: every epilogue operand is 16-byte aligned (cout, vec_ld % 4 == 0): 16-byte epilogue accesses
@@ -43,20 +42,17 @@ enum { DM3D_CONV_K3S1 = 0, DM3D_CONV_K3S2 = 1, DM3D_CONV_K1 = 2, DM3D_CONV_UP = 
 
 int dm3d_conv_launch_f32(ConvArgs& a, int which, hipStream_t st);
 int dm3d_conv_launch_h3(ConvArgs& a, int which, hipStream_t st);
-int dm3d_conv_launch_h3v2(ConvArgs& a, int which, hipStream_t st);     // DM3D_WL_PAIR weights; which in {K3S1, UP}
-int dm3d_conv_launch_h3v3(ConvArgs& a, int which, hipStream_t st);     // same weights and arguments: the free-running form (dm3d_conv_h3v3.hip)
-bool dm3d_conv_h3v3_serves(const ConvArgs& a, int which);
+int dm3d_conv_launch_h3v3(ConvArgs& a, int which, hipStream_t st);     // DM3D_WL_PAIR weights; which in {K3S1, UP}: the free-running form (dm3d_conv_h3v3.hip)
 struct H3v2Launch { ConvArgs k; bool reduce; size_t out_elems; };       // what pre_launch decided: the kernel's own arguments, a reduce launch behind it
-int dm3d_h3v2_pre_launch(ConvArgs& a, int td, bool f8, H3v2Launch& L, hipStream_t st, int force_ksplit = 0);    // force_ksplit > 0: the caller's Cin split
+int dm3d_h3v2_pre_launch(ConvArgs& a, int td, H3v2Launch& L, hipStream_t st, int force_ksplit = 0);    // force_ksplit > 0: the caller's Cin split
 int dm3d_h3v2_post_launch(const ConvArgs& a, const H3v2Launch& L, hipStream_t st);
 int dm3d_conv_h3v2_ksplit(const ConvArgs& a, bool with_scratch);
 int dm3d_conv_h3v3_td(const ConvArgs& a);              // z-slices per brick (4 or 8) the free-running kernel takes for this launch
 int64_t dm3d_h3v2_skip_image_bytes(int cin, int cout);
 int dm3d_pack_skip_h3v2(const float* keras_kernel, int cin, int cout, int w_exp, void* packed, hipStream_t st);       // split factor the launch would choose
-int64_t dm3d_h3v2_image_bytes(int taps, int cin, int cout, int f8 = 0);
+int64_t dm3d_h3v2_image_bytes(int taps, int cin, int cout);
 int dm3d_pack_h3v2(const float* keras_kernel, int taps, int cin, int cout, int w_exp, const float* in_scale, void* packed, int mode,
-                   int f8, hipStream_t st);
+                   hipStream_t st);
 bool dm3d_conv_h3w_serves(const ConvArgs& a, int which);    // true: the Winograd-x form (wpk_wino, dm3d_conv_h3w.hip) serves this launch
 int dm3d_conv_launch_h3w(ConvArgs& a, int which, hipStream_t st);
 int dm3d_conv_h3w_ksplit(const ConvArgs& a);             // workgroups per brick along Cin the Winograd form would use (1 or 2)
-bool dm3d_conv_h3v2_f8(const ConvArgs& a);               // true: the float8 cross-term form (wpk_f8) serves this launch

@@ -370,11 +370,14 @@ int launch_h3(ConvArgs& a, hipStream_t st) {
     a.bd = (a.od + TD - 1) / TD;
     a.bh = (a.oh + TH - 1) / TH;
     a.bw = (a.ow + TW - 1) / TW;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {false};            // per device: the attribute belongs to the device the launch goes to
+    int dev_ = 0;
+    DM3D_HIP(hipGetDevice(&dev_));
+    DM3D_REQUIRE(dev_ >= 0 && dev_ < 64, "conv: device ordinal %d", dev_);
+    if (!attr_set[dev_]) {
         DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3<TD, TH, TW, S, KS, WM, WN, MINW, NRA>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[dev_] = true;
     }
     dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64), a.parity ? 8u : 1u);
     hipLaunchKernelGGL((conv3d_igemm_h3<TD, TH, TW, S, KS, WM, WN, MINW, NRA>), grid, dim3(256), lds, st, a);
@@ -452,7 +455,7 @@ extern "C" int dm3d_pack_weights_up_h3(const float* keras_kernel, int32_t cin, i
     DM3D_REQUIRE(keras_kernel && packed && cin > 0 && cout > 0, "pack_weights_up_h3: bad arguments");
     DM3D_REQUIRE(w_exp >= -100 && w_exp <= 100 && dm3d_aligned16(packed), "pack_weights_up_h3: w_exp out of range or packed unaligned");
     if (dm3d_conv_weight_layout(3, 1, 1, 0, cout) == DM3D_WL_PAIR)
-        return dm3d_pack_h3v2(keras_kernel, 8, cin, cout, w_exp, nullptr, packed, 1, 0, static_cast<hipStream_t>(stream));
+        return dm3d_pack_h3v2(keras_kernel, 8, cin, cout, w_exp, nullptr, packed, 1, static_cast<hipStream_t>(stream));
     const int nchunks = (int)(dm3d_round_up(cin, 16) / 16), ntiles = (int)(dm3d_round_up(cout, 64) / 64);
     hipLaunchKernelGGL(pack_weights_h3_kernel, dim3(4096), dim3(256), 0, static_cast<hipStream_t>(stream), keras_kernel, 8, cin,
                        cout, nchunks, ntiles, ldexpf(1.0f, w_exp), nullptr, static_cast<_Float16*>(packed), 1);
@@ -464,7 +467,7 @@ extern "C" int dm3d_pack_weights_convt_h3(const float* keras_kernel, int32_t cin
     DM3D_REQUIRE(keras_kernel && packed && cin > 0 && cout > 0, "pack_weights_convt_h3: bad arguments");
     DM3D_REQUIRE(w_exp >= -100 && w_exp <= 100 && dm3d_aligned16(packed), "pack_weights_convt_h3: w_exp out of range or packed unaligned");
     if (dm3d_conv_weight_layout(4, 2, 0, 1, cout) == DM3D_WL_PAIR)
-        return dm3d_pack_h3v2(keras_kernel, 8, cin, cout, w_exp, nullptr, packed, 2, 0, static_cast<hipStream_t>(stream));
+        return dm3d_pack_h3v2(keras_kernel, 8, cin, cout, w_exp, nullptr, packed, 2, static_cast<hipStream_t>(stream));
     const int nchunks = (int)(dm3d_round_up(cin, 16) / 16), ntiles = (int)(dm3d_round_up(cout, 64) / 64);
     hipLaunchKernelGGL(pack_weights_h3_kernel, dim3(4096), dim3(256), 0, static_cast<hipStream_t>(stream), keras_kernel, 8, cin,
                        cout, nchunks, ntiles, ldexpf(1.0f, w_exp), nullptr, static_cast<_Float16*>(packed), 2);

@@ -1,0 +1,255 @@
+// dm3d_conv_h3_host.hip — what the 16x16x32 split-float16 Conv3d kernels (dm3d_conv_h3v3.hip: the free-running three-pass kernel;
+// dm3d_conv_h3w.hip: its Winograd-x form) share on the host side: brick counts and the Cin split of small grids (zero fill + two-way atomic
+// add, or raw partial sums into caller scratch + a reduce launch that applies the epilogue), the weight packers of the DM3D_WL_PAIR
+// geometry (plain / UpSample parity sums / Conv3DTranspose / the Winograd-x transform) and of the fused skip conv's image.
+// reference ops: Conv3D / UpSampling3D + Conv3D / Conv3DTranspose weights in Keras layouts (networks/conditional_dm3d.py:238-296,
+// networks/vqvae3d_monai.py:373-377).
+#include <cstdlib>
+#include "dm3d_conv_h3v2_parts.h"
+
+using namespace h3v2;
+
+namespace {
+
+// out = epilogue(sum of the ksplit partial-sum images, added in image order): + bias[c] + vec[row(b)][c] -> ReLU -> PReLU -> + res ->
+// ReLU.  One thread per 4 consecutive channels (or per element when cout % 4 != 0).
+__global__ __launch_bounds__(256) void conv_split_reduce_kernel(const float* __restrict__ part, int nsplit, long stride, float* __restrict__ out,
+                                                                int cout, long per_sample, const float* __restrict__ bias,
+                                                                const float* __restrict__ vec, const int* __restrict__ vec_idx, int vec_ld,
+                                                                int relu, const float* __restrict__ prelu, const float* __restrict__ res,
+                                                                int relu_out, int vec4, int* range_flag, float range_limit) {
+    const int w = vec4 ? 4 : 1;
+    const long total = stride / w;
+    float amax = 0.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long e0 = i * w;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < nsplit; ++s) {
+            if (vec4) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(part + (size_t)s * stride + e0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += q[j];
+            } else {
+                v[0] += part[(size_t)s * stride + e0];
+            }
+        }
+        const unsigned e32 = (unsigned)e0;                  // the launcher guarantees stride < 2^31
+        const int c0 = (int)(e32 % (unsigned)cout);
+        const unsigned b = e32 / (unsigned)per_sample;
+        const int vrow = vec ? (vec_idx ? vec_idx[b] : (int)b) : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j >= w) break;
+            float x = v[j];
+            if (bias) x += bias[c0 + j];
+            if (vec) x += vec[(size_t)vrow * vec_ld + c0 + j];
+            if (relu) x = fmaxf(x, 0.0f);
+            if (prelu) { const float al = prelu[e32 % (unsigned)per_sample + j]; x = x > 0.0f ? x : al * x; }
+            if (res) x += res[e0 + j];
+            if (relu_out) x = fmaxf(x, 0.0f);
+            DM3D_AMAX(amax, x);
+            out[e0 + j] = x;
+        }
+    }
+    if (range_flag && amax > range_limit) *range_flag = 1;
+}
+
+// Zero fill as a kernel of our own: a hipMemsetAsync captured into the per-step HIP graph becomes a memset node, and replays of
+// that graph were observed to race it against the atomic adds of the following conv (two full T = 1000 chains diverged after
+// ~90 steps; eager launches and graphs without memset nodes did not).  A kernel node is ordered like every other launch.
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, long n4, long n) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) reinterpret_cast<f32x4*>(p)[i] = z;
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[n4 * 4 + threadIdx.x] = 0.f;
+}
+
+}  // namespace
+
+// Everything around the conv launch itself that the v2 and v3 kernels share: brick counts, Cin splitting for small grids (zero fill +
+// two-way atomic add, or raw partial sums into caller scratch + a reduce launch that applies the epilogue), 16-byte epilogue eligibility.
+int dm3d_h3v2_pre_launch(ConvArgs& a, int td, H3v2Launch& L, hipStream_t st, int force_ksplit) {
+    a.bd = (a.od + td - 1) / td;
+    a.bh = (a.oh + 7) / 8;
+    a.bw = (a.ow + 7) / 8;
+    // Small grids (the 8^3 level at B = 32 has 64 bricks x 4 channel tiles = one workgroup per CU, i.e. one wave per SIMD with
+    // nothing to hide its barriers and LDS latency behind: in-kernel stamps showed 58 % MFMA occupancy inside the tap loop there;
+    // at B = 1 that level has 8 workgroups for 256 CUs) split the Cin chunks over several workgroups per brick.
+    const bool with_scratch = a.scratch != nullptr;
+    a.ksplit = force_ksplit > 0 ? force_ksplit
+             : (td != 4 || a.out_h2 || a.post_scale) ? 1 : dm3d_conv_h3v2_ksplit(a, with_scratch);     // the fused output forms live in the plain epilogue
+    const size_t out_elems = (size_t)a.batch * a.fd * a.fh * a.fw * a.cout;
+    a.split_atomic = 0;
+    a.split_stride = 0;
+    {
+        auto al16 = [](const void* q) { return (reinterpret_cast<size_t>(q) & 15) == 0; };
+        a.epi_vec4 = a.cout % 4 == 0 && al16(a.out) && al16(a.bias) && al16(a.res) && al16(a.prelu) && al16(a.post_scale) && al16(a.post_shift)
+                     && al16(a.vec) && (a.vec == nullptr || a.vec_ld % 4 == 0);
+    }
+    ConvArgs& k = L.k;
+    k = a;
+    const bool linear = !a.relu && !a.prelu && !a.relu_out && a.res != a.out && a.x1 != a.out && a.x2 != a.out;
+    static const bool no_atomic = [] { const char* e = getenv("DM3D_CONV_NO_ATOMIC"); return e && e[0] == '1'; }();
+    const bool atomic2 = a.ksplit == 2 && linear && a.nchunks >= 8 && !(no_atomic && with_scratch);       // cheaper than a reduce launch when two parts suffice
+    L.out_elems = out_elems;
+    L.reduce = false;
+    if (a.ksplit > 1 && (!with_scratch || atomic2)) {         // two halves, order-independent atomic add into the zeroed output
+        k.split_atomic = 1;
+        long zg = ((long)(out_elems / 4) + 255) / 256;
+        if (zg > 4096) zg = 4096;
+        if (zg < 1) zg = 1;
+        hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)zg), dim3(256), 0, st, a.out, (long)(out_elems / 4), (long)out_elems);
+        if (int zrc = dm3d_launch_check("zero_f32_kernel")) return zrc;
+    } else if (a.ksplit > 1) {                                // raw partial sums -> scratch; epilogue in the reduce launch
+        DM3D_REQUIRE((size_t)a.scratch_bytes >= out_elems * sizeof(float) * a.ksplit, "conv: scratch of %ld bytes is too small", a.scratch_bytes);
+        DM3D_REQUIRE(out_elems < (1ull << 31), "conv: split-K output of %zu elements overflows the reduce kernel's 32-bit index", out_elems);
+        k.out = static_cast<float*>(a.scratch);
+        k.split_stride = (long)out_elems;
+        k.bias = nullptr; k.vec = nullptr; k.res = nullptr; k.relu = 0; k.prelu = nullptr; k.relu_out = 0;
+        k.range_flag = nullptr;                               // the reduce launch checks the finished values
+        L.reduce = true;
+    }
+    return DM3D_OK;
+}
+
+int dm3d_h3v2_post_launch(const ConvArgs& a, const H3v2Launch& L, hipStream_t st) {
+    if (!L.reduce) return DM3D_OK;
+    const size_t out_elems = L.out_elems;
+    const long n4 = (long)(out_elems / 4);                    // cout % 4 == 0 is not required of cout: fall back to scalar lanes
+    const bool vec4 = a.cout % 4 == 0;
+    const long work = vec4 ? n4 : (long)out_elems;
+    long g = (work + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(conv_split_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, static_cast<const float*>(a.scratch), a.ksplit,
+                       (long)out_elems, a.out, a.cout, (long)a.fd * a.fh * a.fw * a.cout, a.bias, a.vec, a.vec_idx, a.vec_ld, a.relu, a.prelu,
+                       a.res, a.relu_out, vec4 ? 1 : 0, a.range_flag, a.range_limit);
+    return dm3d_launch_check("conv_split_reduce_kernel");
+}
+
+namespace {
+
+// weight image of the v2 kernel: [coutpad/64][cinpad/16][TAPSP][64 positions][REC]; position 16*t16 + PI(c) holds output channel
+// 64*ntile + 16*t16 + c; taps >= taps are zero; slots swizzled by the position.  mode: 0 plain, 1 UpSample sums, 2 Conv3DTranspose
+__global__ __launch_bounds__(256) void pack_weights_h3v2_kernel(const float* __restrict__ w, int taps, int tapsp, int cin, int cout,
+                                                                int nchunks, int ntiles, float scale, const float* in_scale,
+                                                                _Float16* __restrict__ out, int mode) {
+    const long nrec = (long)ntiles * nchunks * tapsp * 64;
+    const int npar = (mode == 1 || mode == 2) ? 8 : 1;
+    for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < nrec * 16 * npar; i0 += (long)gridDim.x * 256) {
+        const int par = (int)(i0 / (nrec * 16));
+        const long i = i0 % (nrec * 16);
+        const int k = (int)(i & 15);
+        const long rec = i >> 4;
+        const int pos = (int)(rec % 64);
+        const int tap = (int)((rec / 64) % tapsp);
+        const int chunk = (int)((rec / (64L * tapsp)) % nchunks);
+        const int nt = (int)(rec / (64L * tapsp * nchunks));
+        // invert PI inside the group of 16
+        const int p16 = pos & 15;
+        int c = 0;
+        for (int cc = 0; cc < 16; ++cc) if (pi_pos(cc) == p16) c = cc;
+        const int ci = chunk * 16 + k, co = nt * 64 + (pos & ~15) + c;
+        float v = 0.f;
+        if (ci < cin && co < cout && tap < taps) {
+            if (mode == 3) {
+                // Winograd F(2,3) along x (dm3d_conv_h3w.hip): virtual tap = 2 * step + h, step = 5 * t + tap pair; the pair's two (dz, dy)
+                // taps, lane half h picking one: (dz, 0) | (dz, 1) for pairs 0-2, (0, 2) | zero pad, (1, 2) | (2, 2) — two per-lane operand
+                // bases serve all five (the kernel's a_pair); transform term t of the tap's three x taps
+                const int step = tap >> 1, t = step / 5;
+                const int tq = (step % 5) < 3 ? (step % 5) * 3 + (tap & 1) : ((step % 5) == 3 ? ((tap & 1) ? -1 : 2) : ((tap & 1) ? 8 : 5));
+                if (tq >= 0) {
+                    const float g0 = w[((long)(tq * 3 + 0) * cin + ci) * cout + co], g1 = w[((long)(tq * 3 + 1) * cin + ci) * cout + co],
+                                g2 = w[((long)(tq * 3 + 2) * cin + ci) * cout + co];
+                    v = t == 0 ? g0 : (t == 1 ? 0.5f * ((g0 + g2) + g1) : (t == 2 ? 0.5f * ((g0 + g2) - g1) : g2));
+                }
+            } else
+            v = mode == 1 ? dm3d_up_weight(w, cin, cout, par, tap, ci, co)
+              : mode == 2 ? dm3d_convt_weight(w, cin, cout, par, tap, ci, co) : w[((long)tap * cin + ci) * cout + co];
+            if (in_scale) v *= in_scale[ci];
+            v *= scale;
+        }
+        const _Float16 hi = (_Float16)v;
+        _Float16* r = out + ((long)par * nrec + rec) * REC;
+        const int sw = (pos >> 2) & 3;
+        r[(((k >> 3) ^ sw) << 3) + (k & 7)] = hi;
+        r[(((2 + (k >> 3)) ^ sw) << 3) + (k & 7)] = (_Float16)(v - (float)hi);
+    }
+}
+
+// skip-conv weight image: [coutpad/64][npairs][2 chunks][64 positions][REC] from a Keras 1x1 kernel [cin][cout]; chunk t of pair i holds
+// input channels (2i+t)*16 .. +15 (zeros past cin), rows permuted / slots swizzled like the main image
+__global__ __launch_bounds__(256) void pack_skip_h3v2_kernel(const float* __restrict__ w, int cin, int cout, int npairs, int ntiles,
+                                                             float scale, _Float16* __restrict__ out) {
+    const long nrec = (long)ntiles * npairs * 2 * 64;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nrec * 16; i += (long)gridDim.x * 256) {
+        const int k = (int)(i & 15);
+        const long rec = i >> 4;
+        const int pos = (int)(rec % 64);
+        const int t = (int)((rec / 64) % 2);
+        const int pair = (int)((rec / 128) % npairs);
+        const int nt = (int)(rec / (128L * npairs));
+        const int p16 = pos & 15;
+        int c = 0;
+        for (int cc = 0; cc < 16; ++cc) if (pi_pos(cc) == p16) c = cc;
+        const int ci = (pair * 2 + t) * 16 + k, co = nt * 64 + (pos & ~15) + c;
+        const float v = (ci < cin && co < cout) ? w[(long)ci * cout + co] * scale : 0.0f;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        _Float16* r = out + rec * REC;
+        const int sw = (pos >> 2) & 3;
+        r[(((k >> 3) ^ sw) << 3) + (k & 7)] = hi;
+        r[(((2 + (k >> 3)) ^ sw) << 3) + (k & 7)] = lo;
+    }
+}
+
+}  // namespace
+
+int64_t dm3d_h3v2_skip_image_bytes(int cin, int cout) {
+    return (int64_t)(dm3d_round_up(cin, 32) / 32) * 2 * dm3d_round_up(cout, 64) * REC * (int64_t)sizeof(_Float16);
+}
+
+int dm3d_pack_skip_h3v2(const float* keras_kernel, int cin, int cout, int w_exp, void* packed, hipStream_t st) {
+    const int npairs = (int)(dm3d_round_up(cin, 32) / 32), ntiles = (int)(dm3d_round_up(cout, 64) / 64);
+    hipLaunchKernelGGL(pack_skip_h3v2_kernel, dim3(1024), dim3(256), 0, st, keras_kernel, cin, cout, npairs, ntiles, ldexpf(1.0f, w_exp),
+                       static_cast<_Float16*>(packed));
+    return dm3d_launch_check("pack_skip_h3v2_kernel");
+}
+
+// Workgroups per brick along Cin.  Goal: at least ~2 workgroups per CU (512) while every part keeps >= 2 chunks.  Without scratch
+// only the two-way atomic form exists, and only behind a linear epilogue.
+int dm3d_conv_h3v2_ksplit(const ConvArgs& a, bool with_scratch) {
+    static const int mode = [] { const char* e = getenv("DM3D_CONV_KSPLIT"); return e ? atoi(e) : -1; }();   // 0: never split (A/B, debugging)
+    if (mode == 0) return 1;
+    const long bd = (a.od + 3) / 4, bh = (a.oh + 7) / 8, bw = (a.ow + 7) / 8;
+    const long wgs = (long)a.batch * bd * bh * bw * (a.coutpad / 64) * (a.parity ? 8 : 1);
+    static const long wg_limit = [] { const char* e = getenv("DM3D_CONV_SPLIT_WGS"); return e ? atol(e) : 256L; }();   // A/B knob
+    if (wgs > wg_limit || a.nchunks < 4) return 1;
+    if (!with_scratch) {
+        const bool linear = !a.relu && !a.prelu && !a.relu_out && a.res != a.out && a.x1 != a.out && a.x2 != a.out;
+        return (linear && a.nchunks >= 8 && a.nchunks % 2 == 0) ? 2 : 1;
+    }
+    // A/B knobs (read once: dm3d_conv_scratch_bytes and the launch must agree): least chunks per part, workgroups to aim for, most parts
+    static const int min_chunks = [] { const char* e = getenv("DM3D_CONV_SPLIT_MINCHUNKS"); return e ? atoi(e) : 2; }();
+    static const long target = [] { const char* e = getenv("DM3D_CONV_SPLIT_TARGET"); return e ? atol(e) : 512L; }();
+    static const int max_parts = [] { const char* e = getenv("DM3D_CONV_SPLIT_MAXPARTS"); return e ? atoi(e) : 16; }();
+    int best = 1;                                             // smallest divisor that fills the chip, else the largest allowed
+    for (int d = 2; d <= max_parts; ++d) {
+        if (a.nchunks % d != 0 || a.nchunks / d < min_chunks) continue;
+        best = d;
+        if (wgs * d >= target) break;
+    }
+    return best;
+}
+
+int64_t dm3d_h3v2_image_bytes(int taps, int cin, int cout) {
+    const int g = 4, tapsp = (taps + g - 1) / g * g;
+    return (int64_t)tapsp * dm3d_round_up(cout, 64) * (dm3d_round_up(cin, 16) / 16) * REC * (int64_t)sizeof(_Float16);
+}
+
+int dm3d_pack_h3v2(const float* keras_kernel, int taps, int cin, int cout, int w_exp, const float* in_scale, void* packed, int mode,
+                   hipStream_t st) {
+    const int nchunks = (int)(dm3d_round_up(cin, 16) / 16), ntiles = (int)(dm3d_round_up(cout, 64) / 64);
+    const int g = 4;
+    hipLaunchKernelGGL(pack_weights_h3v2_kernel, dim3(4096), dim3(256), 0, st, keras_kernel, taps, (taps + g - 1) / g * g, cin, cout,
+                       nchunks, ntiles, ldexpf(1.0f, w_exp), in_scale, static_cast<_Float16*>(packed), mode);
+    return dm3d_launch_check("pack_weights_h3v2_kernel");
+}

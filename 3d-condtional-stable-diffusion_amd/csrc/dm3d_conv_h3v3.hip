@@ -428,13 +428,16 @@ int launch_v3(ConvArgs& a, hipStream_t st) {
     constexpr int main_halfs = HREC * REC + 4 * 2 * 64 * REC, skip_halfs = (KS == 3 && NCT == 4) ? skip_lds_halfs<TD>() : 0;
     constexpr size_t lds = (size_t)(main_halfs > skip_halfs ? main_halfs : skip_halfs) * sizeof(_Float16);
     static_assert((TD == 4 ? 2 : 1) * lds <= 160 * 1024, "workgroups per CU x LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {false};            // per device: the attribute belongs to the device the launch goes to
+    int dev = 0;
+    DM3D_HIP(hipGetDevice(&dev));
+    DM3D_REQUIRE(dev >= 0 && dev < 64, "conv: device ordinal %d", dev);
+    if (!attr_set[dev]) {
         DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3v3<KS, MODE, TD, NCT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     H3v2Launch L;
-    if (int rc = dm3d_h3v2_pre_launch(a, TD, false, L, st)) return rc;
+    if (int rc = dm3d_h3v2_pre_launch(a, TD, L, st)) return rc;
     dim3 grid((unsigned)(a.batch * a.bd * a.bh * a.bw), (unsigned)(a.coutpad / 64 * a.ksplit), a.parity ? 8u : 1u);
     hipLaunchKernelGGL((conv3d_igemm_h3v3<KS, MODE, TD, NCT>), grid, dim3(TD * 64), lds, st, L.k);
     if (int rc = dm3d_launch_check("conv3d_igemm_h3v3")) return rc;
@@ -469,12 +472,6 @@ int dm3d_conv_h3v3_td(const ConvArgs& a) {
     const long wgs = (long)a.batch * ((a.od + 7) / 8) * ((a.oh + 7) / 8) * ((a.ow + 7) / 8) * (a.coutpad / 64) * (a.parity ? 8 : 1);
     const char* w = getenv("DM3D_CONV_WIDE_WGS");                      // threshold override (tests force the 8-slice forms onto small shapes with 1)
     return wgs >= (w ? atol(w) : 512L) ? 8 : 4;
-}
-
-// The free-running form serves every DM3D_WL_PAIR launch except the float8 cross-term arithmetic (precision "h3f8": dm3d_conv_h3v2.hip).
-bool dm3d_conv_h3v3_serves(const ConvArgs& a, int which) {
-    (void)which;
-    return !dm3d_conv_h3v2_f8(a);
 }
 
 int dm3d_conv_launch_h3v3(ConvArgs& a, int which, hipStream_t st) {

@@ -861,7 +861,7 @@ int launch_w(ConvArgs& a, hipStream_t st) {
         cus[dev] = n > 0 ? n : 256;
     }
     H3v2Launch L;
-    if (int rc = dm3d_h3v2_pre_launch(a, 8, false, L, st, dm3d_conv_h3w_ksplit(a))) return rc;
+    if (int rc = dm3d_h3v2_pre_launch(a, 8, L, st, dm3d_conv_h3w_ksplit(a))) return rc;
     L.k.wpk = a.wpk_wino;
     // work items = bricks x column tiles x Cin parts.  With a fused skip conv every workgroup takes one (its tail phase overlays the
     // images); otherwise one persistent workgroup per CU walks its share of the list (DM3D_CONV_WINO_PERSIST=0: one item per workgroup)
@@ -869,6 +869,10 @@ int launch_w(ConvArgs& a, hipStream_t st) {
     static const bool persist = [] { const char* e = getenv("DM3D_CONV_WINO_PERSIST"); return !(e && e[0] == '0'); }();
     long g = items;
     if (!SKIP && persist && items > cus[dev]) g = (items % 8 == 0) ? (cus[dev] / 8 * 8) : cus[dev];
+    if (!SKIP && persist) {                  // test knob (read per call): at most this many workgroups, so that small shapes walk item lists too
+        const char* cap = getenv("DM3D_CONV_WINO_GRID");
+        if (cap && atol(cap) > 0 && atol(cap) < g) g = atol(cap);
+    }
     hipLaunchKernelGGL((conv3d_igemm_h3w<MODE, SKIP>), dim3((unsigned)g), dim3(256), lds, st, L.k);
     if (int rc = dm3d_launch_check("conv3d_igemm_h3w")) return rc;
     return dm3d_h3v2_post_launch(a, L, st);
@@ -886,7 +890,10 @@ bool dm3d_conv_h3w_serves(const ConvArgs& a, int which) {
     if (!a.wpk_wino || which != DM3D_CONV_K3S1 || a.parity || a.cout <= 32) return false;
     // (a fused skip conv: its tail phase here keeps one pair of chunks in flight, the direct kernel's two — behind a main loop of only four
     // chunks the direct kernel wins from three pairs on: profiles/r03_list_convs.log)
-    if (a.s_npairs > 2 && a.nchunks < 8) return false;
+    {
+        static const int skipmax = [] { const char* e = getenv("DM3D_CONV_WINO_SKIPMAX"); return e ? atoi(e) : 2; }();      // (A/B knob)
+        if (a.s_npairs > skipmax && a.nchunks < 8) return false;
+    }
     if (a.od % 8 != 0 || a.oh % 8 != 0 || a.ow % 8 != 0 || a.padz != 1 || a.pady != 1 || a.padx != 1) return false;
     const char* e = getenv("DM3D_CONV_WINO");
     if (e && e[0] == '0') return false;

@@ -439,7 +439,12 @@ __global__ __launch_bounds__(256) void ddpm_kernel(const DdpmArgs p) {
                                : philox_normal4((uint64_t)(base + i), (uint32_t)t, 0xd1f0u, seed);
         f32x4 o;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = __fadd_rn(fminf(fmaxf(mean[k], -1.0f), 1.0f), __fmul_rn(sigma, z[k]));
+        for (int k = 0; k < 4; ++k) {
+            // tf.clip_by_value propagates a NaN (conditional_dm3d.py:572); fminf / fmaxf return the other operand for one, which would turn a
+            // NaN eps — diverged weights, inf - inf somewhere in the U-Net — into a plausible x = -1 + noise that no later check can see
+            const float cl = mean[k] != mean[k] ? mean[k] : fminf(fmaxf(mean[k], -1.0f), 1.0f);
+            o[k] = __fadd_rn(cl, __fmul_rn(sigma, z[k]));
+        }
         reinterpret_cast<f32x4*>(p.x)[base + i] = o;
     }
 }

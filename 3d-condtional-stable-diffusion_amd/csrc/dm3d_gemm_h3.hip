@@ -438,12 +438,15 @@ template <int MR>
 static int launch_group_mr(GemmGroup& g, bool af, bool bf, hipStream_t st) {
     constexpr int TM = 64 * MR, NT = 64 * MR;
     constexpr size_t lds = (size_t)(2 * 2 * TM * REC + 2 * 2 * NT * REC) * sizeof(_Float16);     // 65536 (MR 2) / 32768 (MR 1)
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {false};            // per device: the attribute belongs to the device the launch goes to
+    int dev = 0;
+    DM3D_HIP(hipGetDevice(&dev));
+    DM3D_REQUIRE(dev >= 0 && dev < 64, "gemm(h3): device ordinal %d", dev);
+    if (!attr_set[dev]) {
         const void* fns[] = {reinterpret_cast<const void*>(&gemm_tn_h3<false, false, MR>), reinterpret_cast<const void*>(&gemm_tn_h3<true, false, MR>),
                              reinterpret_cast<const void*>(&gemm_tn_h3<false, true, MR>), reinterpret_cast<const void*>(&gemm_tn_h3<true, true, MR>)};
         for (const void* f : fns) DM3D_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     long t = 0;
     for (int i = 0; i < g.count; ++i) {

@@ -472,7 +472,7 @@ class Sampler:
             self.finish()                     # the chain's last step: the one host read of a chain driven through step()
 
     def finish(self):
-        """Reads the H3 / h3f8 range flag of the steps taken so far (one 4-byte device read) and raises if an activation left the
+        """Reads the H3 range flag of the steps taken so far (one 4-byte device read) and raises if an activation left the
         range the arithmetic covers or turned NaN — what generate() does at its end; step() calls it after a chain's last step, a
         caller that stops a chain early calls it itself."""
         self._own()

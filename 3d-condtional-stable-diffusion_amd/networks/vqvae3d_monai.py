@@ -112,8 +112,6 @@ class VQVAE:
         self.output_act, self.num_gpus, self.input_size = output_act, num_gpus, input_size
         self.device = torch.device(device)
         self.precision = precision or os.environ.get("DM3D_PRECISION", "h3")
-        if self.precision == "h3f8":            # the float8 cross-term form belongs to the U-Net's convs; the autoencoder runs plain H3
-            self.precision = "h3"
         if self.precision not in ("fp32", "h3"):
             raise ValueError("precision must be 'fp32' or 'h3'")
         self.spec = vqvae_param_spec(in_channels, out_channels, self.num_channels, num_res_layers, self.num_res_channels,

@@ -79,21 +79,6 @@ def pack_weights_h3(kernel: torch.Tensor, in_scale: Optional[torch.Tensor] = Non
     return out, w_exp
 
 
-def pack_weights_h3f8(kernel: torch.Tensor, w_exp: int, mode: int = 0) -> torch.Tensor:
-    """Second weight image of a k3 / stride-1 conv (mode 0), an UpSample conv (mode 1: [3,3,3,cin,cout]) or a Conv3DTranspose (mode 2:
-    [4,4,4,cout,cin]) for the float8 cross-term form (conv3d(wpk_f8=...)); packed with the w_exp of the conv's main image."""
-    _f32c(kernel, "kernel")
-    if mode == 0:
-        taps, cin, cout, n = kernel.shape[0] * kernel.shape[1] * kernel.shape[2], kernel.shape[-2], kernel.shape[-1], 1
-    elif mode == 1:
-        taps, cin, cout, n = 8, kernel.shape[-2], kernel.shape[-1], 8
-    else:
-        taps, cin, cout, n = 8, kernel.shape[-1], kernel.shape[-2], 8
-    out = torch.empty(n * lib().dm3d_packed_weight_h3f8_bytes(taps, cin, cout) // 2, dtype=torch.float16, device=kernel.device)
-    check(lib().dm3d_pack_weights_h3f8(kernel.data_ptr(), taps, cin, cout, w_exp, None, out.data_ptr(), mode, _st()), "pack_weights_h3f8")
-    return out
-
-
 def pack_weights_h3w(kernel: torch.Tensor, w_exp: int, in_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Weight image of a k3 / stride-1 conv ([3,3,3,cin,cout]) for the Winograd-x form (conv3d(wpk_wino=...)): the x taps of every
     (dz, dy, cin, cout) become the four F(2,3) terms; packed with the w_exp of the conv's main image."""
@@ -147,7 +132,7 @@ def pack_weights_convt(kernel: torch.Tensor, h3: bool = False):
 
 def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False, pro_scale=None, pro_shift=None,
            vec=None, vec_idx=None, relu=False, res=None, precision=_lib.PREC_F32, w_exp=0, prelu_alpha=None,
-           relu_out=False, transpose=False, skip=None, x1_h2_channels=None, out_h2=False, post=None, wpk_f8=None, wpk_wino=None) -> torch.Tensor:
+           relu_out=False, transpose=False, skip=None, x1_h2_channels=None, out_h2=False, post=None, wpk_wino=None) -> torch.Tensor:
     """Conv3D(padding="same") on NDHWC with the fused prologue / concat / upsample / epilogue of dm3d_conv3d_ndhwc.
     ``skip=(sx1, sx2_or_None, skip_wpk)``: also accumulate Conv3D(cout, 1) of the raw concat(sx1, sx2) (H3, k3, stride 1).
     ``post=(scale, shift)``: out = silu(out*scale[c] + shift[c]) at the very end; ``out_h2``: store DM3D_FMT_H2;
@@ -188,8 +173,6 @@ def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False
         d.out_fmt = _lib.FMT_H2
     if post is not None:
         d.post_scale, d.post_shift = post[0].data_ptr(), post[1].data_ptr()
-    if wpk_f8 is not None:
-        d.wpk_f8 = wpk_f8.data_ptr()
     if wpk_wino is not None:
         d.wpk_wino = wpk_wino.data_ptr()
     if skip is not None:

@@ -56,7 +56,6 @@ class _Conv:
         self.precision, self.w_exp = precision, w_exp
         self.cin_pad = -(-cin // _lib.CIN_PAD) * _lib.CIN_PAD
         self.h2 = None              # DM3D_FMT_H2 copy of wpk ([cout_pad][cin_pad]) for the H3 GEMM
-        self.wpk_f8 = None          # second image for the float8 cross-term form (precision "h3f8")
         self.wpk_wino = None        # weight image of the Winograd-x form (dm3d_conv_desc.wpk_wino)
 
 
@@ -70,17 +69,13 @@ class UNet:
         DM3D_PRECISION environment variable, else "h3"."""
         import os
         precision = precision or os.environ.get("DM3D_PRECISION", "h3")
-        if precision not in ("fp32", "h3", "h3f8"):
-            raise ValueError("precision must be 'fp32', 'h3' or 'h3f8'")
-        # "h3f8": the H3 kernels with the two cross terms of the k3 / UpSample convs on float8 operands where the launch is large enough
-        # (dm3d_conv_desc.wpk_f8; eps error 5-9e-5 instead of 5-8e-6, activations clamped at 448 instead of 65504).  Everything else
-        # (GEMMs, attention, small grids) is plain "h3", which is what self.precision says from here on.
-        self.f8 = precision == "h3f8"
-        # precision "h3": k3 / stride-1 convs with Cout > 32 also carry the Winograd-x image; the library uses it where that form is faster
-        # (large grids, Cin >= 96: dm3d_conv_tile_form() == 10).  DM3D_CONV_WINO=0 in the environment at construction: no second image.
+        if precision not in ("fp32", "h3"):
+            raise ValueError("precision must be 'fp32' or 'h3'")
+        # precision "h3": k3 / stride-1 convs with Cout > 32 and Cin >= 32 also carry the Winograd-x image; the library uses it where that
+        # form is faster (large grids: dm3d_conv_tile_form() == 10).  DM3D_CONV_WINO=0 in the environment at construction: no second image.
         self.wino = precision == "h3" and os.environ.get("DM3D_CONV_WINO", "1") != "0"
         self.precision_name = precision
-        self.precision = "h3" if self.f8 else precision
+        self.precision = precision
         self.fuse_skip = os.environ.get("DM3D_FUSE_SKIP", "1") != "0"      # A/B switch: ResidualBlock 1x1 skip conv inside conv2's launch
         self.h2_handoff = os.environ.get("DM3D_H2_HANDOFF", "1") != "0"    # A/B switch: conv1 -> conv2 hand-off in DM3D_FMT_H2
         self.cfg = cfg
@@ -146,11 +141,7 @@ class UNet:
                 w_exp = 0 if wmax == 0.0 or not np.isfinite(wmax) else max(-100, min(100, int(13 - np.floor(np.log2(wmax)))))
                 wpk = torch.empty(lib().dm3d_packed_weight_up_h3_bytes(cin, cout) // 2, dtype=torch.float16, device=self.device)
                 check(lib().dm3d_pack_weights_up_h3(raw.data_ptr(), cin, cout, w_exp, wpk.data_ptr(), _stream()), "pack_weights_up_h3")
-                cv = _Conv(wpk, dbias, taps, cin, cout, _lib.PREC_H3, w_exp)
-                if self.f8 and lib().dm3d_conv_weight_layout(3, 1, 1, 0, cout) == _lib.WL_PAIR:
-                    cv.wpk_f8 = torch.empty(8 * lib().dm3d_packed_weight_h3f8_bytes(8, cin, cout) // 2, dtype=torch.float16, device=self.device)
-                    check(lib().dm3d_pack_weights_h3f8(raw.data_ptr(), 8, cin, cout, w_exp, None, cv.wpk_f8.data_ptr(), 1, _stream()), "pack_weights_h3f8")
-                return cv
+                return _Conv(wpk, dbias, taps, cin, cout, _lib.PREC_H3, w_exp)
             wpk = torch.empty(lib().dm3d_packed_weight_up_elems(cin, cout), dtype=torch.float32, device=self.device)
             check(lib().dm3d_pack_weights_up(raw.data_ptr(), cin, cout, wpk.data_ptr(), _stream()), "pack_weights_up")
             return _Conv(wpk, dbias, taps, cin, cout)
@@ -162,17 +153,10 @@ class UNet:
                 wpk = torch.empty(lib().dm3d_packed_weight_h3p_bytes(taps, cin, cout) // 2, dtype=torch.float16, device=self.device)
                 check(lib().dm3d_pack_weights_h3p(raw.data_ptr(), taps, cin, cout, w_exp, _ptr(in_scale), wpk.data_ptr(), 0,
                                                   _stream()), "pack_weights_h3p")
-                if self.wino and taps == 27 and stride == 1 and cout > 32:
+                if self.wino and taps == 27 and stride == 1 and cout > 32 and cin >= 32:       # (the library never takes the form below 32 input channels)
                     cv = _Conv(wpk, self._dev(bias) if bias is not None else None, taps, cin, cout, _lib.PREC_H3, w_exp)
                     cv.wpk_wino = torch.empty(lib().dm3d_packed_weight_h3w_bytes(cin, cout) // 2, dtype=torch.float16, device=self.device)
                     check(lib().dm3d_pack_weights_h3w(raw.data_ptr(), cin, cout, w_exp, _ptr(in_scale), cv.wpk_wino.data_ptr(), _stream()), "pack_weights_h3w")
-                    return cv
-                if self.f8 and taps == 27:
-                    f8img = torch.empty(lib().dm3d_packed_weight_h3f8_bytes(taps, cin, cout) // 2, dtype=torch.float16, device=self.device)
-                    check(lib().dm3d_pack_weights_h3f8(raw.data_ptr(), taps, cin, cout, w_exp, _ptr(in_scale), f8img.data_ptr(), 0,
-                                                       _stream()), "pack_weights_h3f8")
-                    cv = _Conv(wpk, self._dev(bias) if bias is not None else None, taps, cin, cout, _lib.PREC_H3, w_exp)
-                    cv.wpk_f8 = f8img
                     return cv
             else:
                 wpk = torch.empty(lib().dm3d_packed_weight_h3_bytes(taps, cin, cout) // 2, dtype=torch.float16, device=self.device)
@@ -252,16 +236,16 @@ class UNet:
         P["out.conv"] = self._pack(s["out.conv.kernel"], s["out.conv.bias"], conv=True)
         self.P = P
         self._prepared = True
-        self.range_limit = self._h3_range_limit()
+        self.range_limit = self._h3_range_limit()          # (a plan with a Winograd-x launch uses half of it: Plan.range_limit)
         if cfg.conditional:
             self._prepare_context_tables()
 
-    def _h3_range_limit(self) -> float:
+    def _h3_range_limit(self, winograd: bool = False) -> float:
         """Bound on |activation| below which no H3 operand path can leave the float16 range (include/dm3d.h, range_flag): a raw
         consumer clamps at 65504; a consumer behind a folded BatchNormalization sees silu(x*scale + shift), |.| <= |x| max|scale| +
-        max|shift|.  (GroupNormalization normalises per sample: |x_hat| <= sqrt(group size), no bound on x is needed.)"""
-        # the float8 cross-term form clamps activations at 448 (dm3d_h3.h); the Winograd-x form splits sums of two activations (dm3d.h, wpk_wino)
-        top = 448.0 if self.f8 else (32752.0 if self.wino else 65504.0)
+        max|shift|.  (GroupNormalization normalises per sample: |x_hat| <= sqrt(group size), no bound on x is needed.)
+        ``winograd``: some launch of the plan takes the Winograd-x form, which splits sums of two activations (dm3d.h, wpk_wino): half the range."""
+        top = 32752.0 if winograd else 65504.0
         lim = top
         if self.cfg.norm == "batch":
             s = self.state
@@ -275,24 +259,24 @@ class UNet:
                         lim = min(lim, (top - float(shift.max())) / smax)
         return max(lim, 1.0)
 
-    def check_range(self, plan: "Plan"):
+    def check_range(self, plan: "Plan", eps: bool = False):
         """Raises if any launch of ``plan`` since the last check produced a value an H3 consumer would have clamped (one 4-byte
-        device read: the only host synchronisation of a generate() call, at its end)."""
+        device read: the only host synchronisation of a generate() call, at its end).  ``eps``: also inspect the newest eps (a plain
+        forward call: nothing downstream of it would)."""
         if plan.range_flag is None:
             return
         # the newest x (a chain's final latent; nothing downstream would look at it) goes through the NaN-aware check as well: a NaN
-        # made anywhere in a step reaches x with the posterior update, and `amax > limit` alone is false for one
-        check(lib().dm3d_range_check(plan.x.data_ptr(), plan.x.numel(), 448.0 if self.f8 else 65504.0, plan.range_flag.data_ptr(),
-                                     torch.cuda.current_stream().cuda_stream), "range_check")
+        # made anywhere in a step — diverged weights, inf - inf — reaches x with the posterior update (dm3d_ddpm_update propagates it
+        # through the clip like tf.clip_by_value), where the next step's range op or this check sees it; `amax > limit` alone is false for one
+        for tns in ((plan.x, plan.eps) if eps else (plan.x,)):
+            check(lib().dm3d_range_check(tns.data_ptr(), tns.numel(), 65504.0, plan.range_flag.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream), "range_check")
         if int(plan.range_flag.item()) != 0:
             plan.range_flag.zero_()
-            if self.f8:
-                raise _lib.Dm3dError(
-                    f"an activation exceeded the range the float8 cross-term (precision='h3f8') kernels cover (|x| > {self.range_limit:.4g}); "
-                    "the result would differ from float32 arithmetic. Rebuild the model with precision='h3' (range 65504) or 'fp32'.")
             raise _lib.Dm3dError(
-                f"an activation exceeded the range the split-float16 (precision='h3') kernels represent exactly (|x| > {self.range_limit:.4g}); "
-                "the result would differ from float32 arithmetic. Rebuild the model with precision='fp32'.")
+                f"an activation exceeded the range the split-float16 (precision='h3') kernels represent exactly (|x| > {plan.range_limit:.4g}), "
+                "or a NaN was produced; the result would differ from float32 arithmetic. Rebuild the model with precision='fp32'"
+                + (" (or keep 'h3' and set DM3D_CONV_WINO=0: the direct conv form covers |x| <= 65504)." if plan.uses_wino else "."))
 
     def _prepare_attn(self, P, blk):
         s, n, u = self.state, blk.name, blk.cout
@@ -432,7 +416,7 @@ class UNet:
         plan.x.copy_(x.to(self.device))
         plan.run()
         out = plan.eps.clone()
-        self.check_range(plan)
+        self.check_range(plan, eps=True)
         return out
 
 
@@ -503,7 +487,17 @@ class Plan:
         self._gn_acc = None
         # H3 range guard (include/dm3d.h): every H3 launch of the plan reports into one flag; see UNet.check_range
         self.range_flag = torch.zeros(1, dtype=torch.int32, device=dev) if net.precision == "h3" else None
+        self.uses_wino = False                  # some conv of this plan takes the Winograd-x form (dm3d_conv_tile_form() == 10)
+        self.range_limit = net.range_limit
         self._build()
+        if self.range_flag is not None and self.uses_wino:
+            # the Winograd-x form splits sums of two activations: every producer of this plan guards half the range.  Decided per plan
+            # (a plan whose grids are too small for that form keeps the whole float16 range)
+            self.range_limit = net._h3_range_limit(winograd=True)
+            for d in self._keep:
+                for one in (d if isinstance(d, C.Array) else (d,)):
+                    if isinstance(one, (ConvDesc, GemmDesc)) and one.range_flag:
+                        one.range_limit = self.range_limit
         # one workspace for every conv that can split its Cin range (dm3d_conv_scratch_bytes): launches are stream-ordered
         need = max([lib().dm3d_conv_scratch_bytes(C.byref(d)) for d in self._keep if isinstance(d, ConvDesc)] + [0])
         if need:
@@ -565,12 +559,10 @@ class Plan:
             self._keep += [post[0], post[1]]
         d.out_fmt = _lib.FMT_H2 if out_h2 else _lib.FMT_F32
         d.x1_fmt = _lib.FMT_H2 if x1_h2 else _lib.FMT_F32
-        if w.wpk_f8 is not None:
-            d.wpk_f8 = w.wpk_f8.data_ptr()
         if w.wpk_wino is not None:
             d.wpk_wino = w.wpk_wino.data_ptr()
         if self.range_flag is not None and w.precision == _lib.PREC_H3:
-            d.range_flag, d.range_limit = self.range_flag.data_ptr(), self.net.range_limit
+            d.range_flag, d.range_limit = self.range_flag.data_ptr(), self.range_limit
         skip_flops = 0.0
         if skip is not None:
             sx1, sx2, sc1, sc2, simg = skip
@@ -585,9 +577,8 @@ class Plan:
             kind = "conv_k1"
         elif stride == 2:
             kind = "conv_k3s2"
-        elif form == 9:
-            kind = "conv_f8_up" if upsample else ("conv_f8_h2in" if x1_h2 else "conv_f8")    # conv3d_igemm_h3f8<KS, MODE>: float8 cross terms
         elif form == 10:
+            self.uses_wino = True
             kind = "conv_wino_h2in" if x1_h2 else "conv_wino"                                # conv3d_igemm_h3w<MODE>: Winograd F(2,3) along x
         elif upsample:
             kind = "conv_up"            # 8 parity 2x2x2 convs
@@ -605,16 +596,18 @@ class Plan:
                           # algorithmic; a fused 1x1 skip conv counts its own FLOPs here
                           "flops": 2.0 * w.taps * w.cin * w.cout * self.B * eo ** 3 + skip_flops,
                           # MFMA work actually issued: the upsample conv runs as 8 parity convs of 8 taps on the low-res grid
-                          # (float8 form: 1 float16 + 2/2.25 float8-rate units per product, counted in float16-MFMA-equivalent FLOPs;
-                          #  Winograd-x form: 40 k-steps per output pair — 36 + the zero pad tap — against 54, three passes each)
-                          "exec_flops": (2.0 * (8 if upsample else w.taps) * w.cin * w.cout * self.B * eo ** 3 + skip_flops)
-                                        * ((1 + 2 / 2.25 if form == 9 else (3 * 40 / 54 if form == 10 else 3)) if w.precision == _lib.PREC_H3 else 1),
+                          # (Winograd-x form: 40 k-steps per output pair — 36 + the zero pad tap — against 54, three passes each;
+                          #  "useful_flops" leaves the pad steps out: 36 / 54)
+                          "exec_flops": (2.0 * (8 if upsample else w.taps) * w.cin * w.cout * self.B * eo ** 3 * (40 / 54 if form == 10 else 1) + skip_flops)
+                                        * (3 if w.precision == _lib.PREC_H3 else 1),
+                          "useful_flops": (2.0 * (8 if upsample else w.taps) * w.cin * w.cout * self.B * eo ** 3 * (36 / 54 if form == 10 else 1) + skip_flops)
+                                          * (3 if w.precision == _lib.PREC_H3 else 1),
                           "bytes": 4.0 * self.B * (edge_in ** 3 * (w.cin + (skip[2] + skip[3] if skip is not None else 0))
                                                    + eo ** 3 * w.cout)}))
 
     def _guard(self, d: GemmDesc) -> GemmDesc:
         if self.range_flag is not None and d.precision == _lib.PREC_H3:
-            d.range_flag, d.range_limit = self.range_flag.data_ptr(), self.net.range_limit
+            d.range_flag, d.range_limit = self.range_flag.data_ptr(), self.range_limit
         return d
 
     def _gemm(self, **kw):
@@ -638,7 +631,7 @@ class Plan:
         P = net.P
         S = cfg.img_size
         if self.range_flag is not None:        # the caller's x_t is the one tensor on an H3 operand path that no dm3d kernel wrote
-            self.ops.append((lib().dm3d_range_check, (self.x.data_ptr(), self.x.numel(), 448.0 if self.net.f8 else 65504.0,
+            self.ops.append((lib().dm3d_range_check, (self.x.data_ptr(), self.x.numel(), 65504.0,
                                                        self.range_flag.data_ptr()), "range", {}))
         h = self._buf(B, S, S, S, cfg.first_conv_channels)
         self._conv(P["conv_in"], self.x, h, S)
@@ -911,7 +904,7 @@ class Plan:
                 check(lib().dm3d_gather_rows(tab.data_ptr(), tab.shape[0], ids.data_ptr(), buf.data_ptr(), buf.shape[0],
                                              buf.shape[1], st), "gather_rows")
 
-    _RANGE_OF = {"conv_wino": "conv", "conv_wino_h2in": "conv", "conv_f8": "conv", "conv_f8_h2in": "conv", "conv_f8_up": "conv", "conv_k3s1_td4": "conv", "conv_k1": "conv", "conv_k3s2": "conv", "conv_up": "conv", "conv_k3s1_n32": "conv", "conv_k3s1_h2in": "conv", "conv_k3s1": "conv",
+    _RANGE_OF = {"conv_wino": "conv", "conv_wino_h2in": "conv", "conv_k3s1_td4": "conv", "conv_k1": "conv", "conv_k3s2": "conv", "conv_up": "conv", "conv_k3s1_n32": "conv", "conv_k3s1_h2in": "conv", "conv_k3s1": "conv",
                  "gemm": "attn", "gemm_h3": "attn", "attn_fused": "attn", "softmax": "attn", "layernorm": "attn", "groupnorm": "norm", "affine": "norm",
                  "range": "guard"}
 

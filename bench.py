@@ -11,13 +11,16 @@ Contract (one JSON line from rank 0):  python bench.py --gpus N --steps K --warm
     scaling: B per GPU fixed).  Under torchrun (RANK/LOCAL_RANK/WORLD_SIZE set) this process is one rank; started plainly as
     `python bench.py --gpus N` it launches the N ranks itself as fresh child processes — before this process has touched the
     GPU — relays rank 0's JSON line and exits non-zero if any rank fails.
-  * roofline: the dominant kernel is the k3/stride-1 Conv3d implicit GEMM with the norm+SiLU prologue in its 8-slice form,
-    conv3d_igemm_h3v3<3, 1, 8, 4> (10 launches/step: the large-Cin convs of the 32^3 and 16^3 levels, ~39 % of the step; the 4-slice
-    form, the H2-input twin, conv_in/conv_out and the two UpSample convs are other instantiations, listed under per_kernel_kind);
+  * roofline: the dominant kernel is the k3/stride-1 Conv3d with the norm+SiLU prologue in its Winograd F(2,3)-along-x form,
+    conv3d_igemm_h3w<1, false> (19 launches/step at B = 32: the Cin >= 32 convs of the 32^3 / 16^3 levels without a fused skip conv and the
+    Cin >= 256 convs of the 8^3 level with their two-way Cin split, ~45 % of the step; persistent workgroups, one per CU); its MODE-2 twin
+    behind a DM3D_FMT_H2 hand-off, the direct kernel conv3d_igemm_h3v3 (launches with a long fused skip conv, small grids, conv_in /
+    conv_out, the UpSample parity convs) and the stride-2 convs are listed under per_kernel_kind;
     achieved = algorithmic FLOPs (2*27*Cin*Cout*B*Dout^3 per launch, plus those of a fused 1x1 skip conv) /
     HIP-event time of those launches, measured live on the launch stream; peak = the dense MFMA peak of the datatype the
     kernel multiplies in (MI355X_MICROARCH.md): float16 2500 TFLOP/s in the default h3 mode (three v_mfma_f32_16x16x32_f16
-    passes per algorithmic product: executed_mfma_tflops = 3 x achieved is reported beside it), float32 157.3 TFLOP/s with
+    passes per product: executed_mfma_tflops counts what is issued — 40/54 of the direct form's k-steps in the Winograd-x form, a tenth of
+    them against a zero pad tap; useful_mfma_tflops leaves the pad steps out), float32 157.3 TFLOP/s with
     --precision fp32 (v_mfma_f32_32x32x2_f32).  traffic = HBM bytes per launch from the committed rocprofv3 --pmc summary.
   * cpu_baseline: the CPU oracle (PyTorch-CPU restatement of the reference path; TensorFlow is not installed) on the
     host cores, a bounded sample of the same workload (rank 0, N=1 only).
@@ -60,12 +63,12 @@ def self_launch(n: int) -> int:
     relay rank 0's stdout (the JSON line) and every rank's stderr.  All children are polled: when one exits non-zero its siblings
     are terminated at once (a rank that dies before the rendezvous would otherwise leave the others in init_process_group until
     the collective timeout) and the parent returns non-zero.  A port that another process grabbed between the probe and the
-    children's bind shows up as such an early failure: one retry on a fresh port."""
+    children's bind makes the ranks exit with RC_RENDEZVOUS: one retry on a fresh port, for that failure only."""
     import socket
     import subprocess
     import threading
 
-    def attempt() -> int:
+    def attempt():
         with socket.socket() as so:
             so.bind(("127.0.0.1", 0))
             port = so.getsockname()[1]
@@ -97,17 +100,22 @@ def self_launch(n: int) -> int:
         reader.join(timeout=10)
         if bad:
             print(f"[bench] ranks failed (rank, exit code): {bad}; siblings terminated", file=sys.stderr)
-            return 1
+            return 1, [rc for _, rc in bad]
         sys.stdout.write(out0[0] if out0 else "")
         sys.stdout.flush()
-        return 0
+        return 0, []
 
-    t_start = time.time()
-    rc = attempt()
-    if rc != 0 and time.time() - t_start < 60 and os.environ.get("DM3D_BENCH_NO_RETRY") != "1":
-        print("[bench] early failure: one retry on a fresh rendezvous port", file=sys.stderr)
-        rc = attempt()
+    # One retry, and only for the failure it exists for: a rank that could not bind / reach the rendezvous port (another process grabbed
+    # it between the probe and the children's bind) exits with RC_RENDEZVOUS.  Any other failure — a signal, a GPU fault, an assertion —
+    # is reported as it is: a second attempt would run on the box again and could publish a clean line over the first one's evidence.
+    rc, codes = attempt()
+    if rc != 0 and codes and all(c == RC_RENDEZVOUS or c == 0 for c in codes) and os.environ.get("DM3D_BENCH_NO_RETRY") != "1":
+        print("[bench] rendezvous port was taken: one retry on a fresh port", file=sys.stderr)
+        rc, codes = attempt()
     return rc
+
+
+RC_RENDEZVOUS = 98      # exit code of a rank whose init_process_group failed to bind / connect (EADDRINUSE and kin)
 
 
 def csrc_digest() -> str:
@@ -148,11 +156,10 @@ def main():
     ap.add_argument("--norm", choices=["batch", "group"], default="batch",
                     help="batch = the reference's inference BatchNormalization (folded); group = its commented-out "
                          "GroupNormalization(8) variant (per-sample statistics computed on the device every step)")
-    ap.add_argument("--precision", choices=["h3", "h3f8", "fp32"], default="h3",
+    ap.add_argument("--precision", choices=["h3", "fp32"], default="h3",
                     help="Conv3d arithmetic: h3 = float16 hi+lo split, 3 MFMA passes, fp32 accumulate (default); "
                          "fp32 = exact float32 MFMA")
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the extra exact-float32 timing (N=1, h3 runs only)")
-    ap.add_argument("--no-h3f8-mode", action="store_true", help="skip the extra timing of the float8 cross-term conv form (N=1, h3 runs only)")
     ap.add_argument("--no-full-chain", action="store_true", help="skip the wall-clock timing of one whole T=1000 generate() (N=1 only)")
     ap.add_argument("--print-csrc-digest", action="store_true")
     args = ap.parse_args()
@@ -176,19 +183,32 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match the launcher's WORLD_SIZE={world}")
     # DM3D_BENCH_REHEARSAL=1: several ranks share GPU 0 and talk over gloo — only to rehearse the multi-process logic
     # on a one-GPU box (RCCL refuses two ranks on one device); the driver's real runs use one GPU per rank over RCCL.
-    rehearsal = os.environ.get("DM3D_BENCH_REHEARSAL") == "1"
+    # DM3D_BENCH_REHEARSAL=cpu: the launch path only, at any width, without a GPU — self-launch, rendezvous, weight broadcast, digests,
+    # gathers, barriers, max-over-ranks over gloo; the ranks build no model and time sleeps.  (The GPU boxes allow six GPU processes, so
+    # the eight-rank width of the driver's scaling run can only be rehearsed this way; the line says so and is not a measurement.)
+    rehearsal_mode = os.environ.get("DM3D_BENCH_REHEARSAL", "")
+    rehearsal, dry = rehearsal_mode in ("1", "cpu"), rehearsal_mode == "cpu"
     dev_index = 0 if rehearsal else local_rank
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    _lib.require_device()
+    dev = None
+    if not dry:
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
+        _lib.require_device()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         tmo = datetime.timedelta(seconds=int(os.environ.get("DM3D_BENCH_INIT_TIMEOUT", "180")))   # a dead sibling must not hold the box for the default 10 min
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
+        try:
+            if rehearsal:
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
+        except Exception as e:                  # (the parent retries on a fresh port for this exit code only)
+            msg = str(e)
+            if any(k in msg for k in ("EADDRINUSE", "Address already in use", "address already in use", "failed to bind", "Connection refused")):
+                print(f"[bench] rank {rank}: rendezvous failed: {msg[:300]}", file=sys.stderr)
+                sys.exit(RC_RENDEZVOUS)
+            raise
     comm_dev = torch.device("cpu") if rehearsal else dev
 
     B, S, Cc = args.batch, args.size, args.channels
@@ -200,13 +220,36 @@ def main():
     W = dm3d_amd.synthetic_weights(cfg, seed=0)
     W = parallel.broadcast_state(W if rank == 0 else None, spec, src=0, device=comm_dev)   # RCCL broadcast over xGMI (no-op at N=1)
     # every rank's identity: device, Philox seed, digest of the weights it holds after the broadcast (must all agree)
-    me = json.dumps({"rank": rank, "device": torch.cuda.get_device_name(dev_index), "device_index": dev_index,
+    me = json.dumps({"rank": rank, "device": "none (cpu rehearsal)" if dry else torch.cuda.get_device_name(dev_index), "device_index": dev_index,
                      "seed": parallel.rank_seed(1234, rank), "weights_sha": parallel.state_digest(W)})
     ranks_info = {"world_size": dist.get_world_size() if world > 1 else 1,
                   "backend": dist.get_backend() if world > 1 else None,
                   "per_rank": [json.loads(x) for x in parallel.gather_strings(me)]}
     if len({r["weights_sha"] for r in ranks_info["per_rank"]}) != 1:
         raise SystemExit("ranks hold different weights after the broadcast")
+    if dry:
+        K = args.steps
+        dist.barrier() if world > 1 else None
+        t0 = time.perf_counter()
+        for _ in range(K):
+            time.sleep(0.002 * (1 + rank % 3))                 # ranks differ: the maximum over ranks is what gets reported
+        if world > 1:
+            dist.barrier()
+        my_elapsed = time.perf_counter() - t0
+        elapsed = parallel.max_over_ranks(my_elapsed, comm_dev)
+        for r, ms_r in enumerate(parallel.gather_strings(f"{my_elapsed / K * 1e3:.4f}")):
+            ranks_info["per_rank"][r]["ms_per_step"] = float(ms_r)
+        if rank == 0:
+            print(json.dumps({"metric": "NOT A MEASUREMENT: cpu rehearsal of the multi-rank launch path", "value": 0.0, "unit": "volumes/s",
+                              "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none",
+                              "config": {"workload": "no kernels run: self-launch, rendezvous, broadcast, gathers and barriers only",
+                                         "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"batch-shard x{world} (CPU REHEARSAL, gloo)"},
+                              "roofline": None, "cpu_baseline": None, "ranks": ranks_info}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     margs = SimpleNamespace(timesteps=T_FULL, num_gpus=world, kernel_resize=False, bs=B * world)
     model = cdm.DiffusionModel(S, 1024, Cc, None, margs, device=dev, weights=W, precision=args.precision, norm=args.norm)
     smp = model.sampler((B, S, S, S, Cc), context_value=1, seed=parallel.rank_seed(1234, rank),
@@ -257,33 +300,30 @@ def main():
         acc = {}
         for _ in range(reps):
             for kind, meta, ms in plan.run_timed():
-                a = acc.setdefault(kind, [0, 0.0, 0.0, 0.0, 0.0])
+                a = acc.setdefault(kind, [0, 0.0, 0.0, 0.0, 0.0, 0.0])
                 a[0] += 1
                 a[1] += ms
                 a[2] += meta.get("flops", 0.0)
                 a[3] += meta.get("bytes", 0.0)
                 a[4] += meta.get("exec_flops", 0.0)
-        for kind, (n, ms, fl, by, ex) in acc.items():
+                a[5] += meta.get("useful_flops", meta.get("exec_flops", 0.0))
+        for kind, (n, ms, fl, by, ex, us) in acc.items():
             per_kind[kind] = {"launches_per_step": n // reps, "ms_per_step": round(ms / reps, 4),
                               "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if fl else None}
         # the dominant kernel: the 8-slice form where the grid is large enough for it (B = 32), else the 4-slice form (small batches)
         # (the kind with the most time per step among the k3 / stride-1 forms with the fused prologue; the float8 form wherever it runs)
-        dom = "conv_f8" if "conv_f8" in acc else max((k for k in ("conv_wino", "conv_k3s1", "conv_k3s1_td4") if k in acc), key=lambda k: acc[k][1])
+        dom = max((k for k in ("conv_wino", "conv_k3s1", "conv_k3s1_td4") if k in acc), key=lambda k: acc[k][1])
         wide = dom == "conv_k3s1"
-        n, ms, fl, by, ex = acc[dom]
+        n, ms, fl, by, ex, us = acc[dom]
         achieved = fl / (ms * 1e-3) / 1e12
-        if dom == "conv_f8":
-            kname = ("conv3d_igemm_h3f8<3, 1> (k3 stride-1 Conv3d with the fused norm+SiLU prologue, 8-slice bricks; float16 "
-                     "hi+lo split: hi.hi on v_mfma_f32_16x16x32_f16, both cross terms on one v_mfma_scale_f32_16x16x128_f8f6f4 "
-                     "stream (float8 e4m3 copies of the halves), fp32 accumulate)")
-            peak, passes = PEAK_F16_MFMA_TFLOPS, 1.5
-        elif dom == "conv_wino":
-            kname = ("conv3d_igemm_h3w<1> (k3 stride-1 Conv3d with the fused norm+SiLU prologue as Winograd F(2,3) along x: 8x8x8 bricks, one wave "
-                     "per SIMD with 256 accumulator registers, 40 k-steps per output pair instead of 54; float16 hi+lo split, 3 x "
-                     "v_mfma_f32_16x16x32_f16 per transformed product, fp32 accumulate; launches with Cin < 96 or small grids stay on the direct "
-                     "kernel conv3d_igemm_h3v3, listed as conv_k3s1 / conv_k3s1_td4)")
+        if dom == "conv_wino":
+            kname = ("conv3d_igemm_h3w<1, false> (k3 stride-1 Conv3d with the fused norm+SiLU prologue as Winograd F(2,3) along x: 8x8x8 bricks, one wave "
+                     "per SIMD with 256 accumulator registers, persistent workgroups (one per CU walks a list of bricks; the next brick's first image "
+                     "and weight steps are staged during the last chunk of the current one), 40 k-steps per output pair instead of 54; float16 hi+lo "
+                     "split, 3 x v_mfma_f32_16x16x32_f16 per transformed product, fp32 accumulate; launches with Cin < 32, a long fused skip conv or small "
+                     "grids stay on the direct kernel conv3d_igemm_h3v3, listed as conv_k3s1_h2in / conv_k3s1_td4 / conv_k3s1_n32)")
             peak, passes = PEAK_F16_MFMA_TFLOPS, round(3 * 40 / 54, 3)
-        elif args.precision in ("h3", "h3f8"):
+        elif args.precision == "h3":
             kname = ("conv3d_igemm_h3v3<3, 1, 8, 4> (k3 stride-1 Conv3d with the fused norm+SiLU prologue, 8-slice bricks, free-running "
                      "software-pipelined waves; float16 hi+lo split, 3 x v_mfma_f32_16x16x32_f16 per algorithmic product, fp32 accumulate; "
                      "its 4-slice form <3, 1, 4, 4> is listed as conv_k3s1_td4, the MODE-2 twin that reads pre-activated DM3D_FMT_H2 input as "
@@ -299,8 +339,11 @@ def main():
                     "mfma_passes_per_product": passes,
                     "executed_mfma_tflops": round(ex / (ms * 1e-3) / 1e12, 2),
                     "executed_mfma_frac_of_peak": round(ex / (ms * 1e-3) / 1e12 / peak, 4),
+                    "useful_mfma_tflops": round(us / (ms * 1e-3) / 1e12, 2),
+                    "useful_mfma_frac_of_peak": round(us / (ms * 1e-3) / 1e12 / peak, 4),
                     "note": "achieved = algorithmic FLOPs (2*27*Cin*Cout per output voxel) / time; executed counts the MFMA "
-                            "work issued: x3 passes in h3, and the two UpSample convs run as 8-tap parity convs (8/27 of the taps)",
+                            "work issued: x3 passes in h3, 40/54 of the k-steps in the Winograd-x form (36 + the zero pad tap; useful leaves "
+                            "the pad steps out: 36/54), and the two UpSample convs run as 8-tap parity convs (8/27 of the taps)",
                     "achieved_vs_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                     "avg_launch_ms": round(ms / n, 4), "launches_per_step": n // reps,
                     "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
@@ -313,8 +356,7 @@ def main():
     if roofline is not None:
         import csv
         import glob
-        want = "conv3d_igemm_h3f8<3, 1>" if "conv_f8" in per_kind else \
-            ("conv3d_igemm_h3w<1>" if roofline["kernel"].startswith("conv3d_igemm_h3w") else
+        want = ("conv3d_igemm_h3w<1, false>" if roofline["kernel"].startswith("conv3d_igemm_h3w") else
              "conv3d_igemm_h3v3<3, 1, 8, 4>" if "conv_k3s1" in per_kind else "conv3d_igemm_h3v3<3, 1, 4, 4>") if args.precision != "fp32" \
             else "conv3d_igemm_f32<4, 8, 8, 1, 3, 4, 1>"
         sig = f"batch={B} size={S} channels={Cc} norm={args.norm} precision={args.precision} csrc={csrc_digest()}"
@@ -416,51 +458,6 @@ def main():
         del s32, m32
         torch.cuda.empty_cache()
 
-    # ---- the same K steps with the float8 cross-term conv form (precision "h3f8": eps error ~4e-5 instead of ~7e-6, inside the 1e-3
-    # contract; NOT the headline: the headline stays the float32-grade three-pass arithmetic) ------
-    h3f8_mode = None
-    if rank == 0 and world == 1 and args.precision == "h3" and not args.no_h3f8_mode:
-        log("h3f8 mode: building the model")
-        m8 = cdm.DiffusionModel(S, 1024, Cc, None, margs, device=dev, weights=W, precision="h3f8", norm=args.norm)
-        s8 = m8.sampler((B, S, S, S, Cc), context_value=1, seed=parallel.rank_seed(1234, rank), use_graph=not args.no_graph)
-        s8.prepare()
-        s8.reset()
-        step8 = _restarting(s8)
-        for _ in range(max(1, Wm)):
-            step8()
-        torch.cuda.synchronize()
-        t8 = time.perf_counter()
-        for _ in range(K):
-            step8()
-        torch.cuda.synchronize()
-        sp8 = (time.perf_counter() - t8) / K
-        acc8 = {}
-        s8.plan.run_timed()
-        for kind, meta, ms in s8.plan.run_timed():
-            a = acc8.setdefault(kind, [0, 0.0, 0.0, 0.0])
-            a[0] += 1; a[1] += ms; a[2] += meta.get("flops", 0.0); a[3] += meta.get("exec_flops", 0.0)
-        h3f8_mode = {"ms_per_step": sp8 * 1e3, "value": B / (T_FULL * sp8), "unit": "volumes/s", "steps": K,
-                     "eps_error_note": "float8 (e4m3) cross terms: eps relative error ~4e-5 against the oracle (tests/test_gpu_unet.py::"
-                                       "test_unet_eps_h3f8_full_batch_32cube, bar 2e-4; contract 1e-3); activations limited to +-448",
-                     "per_kernel_kind": {k: {"launches_per_step": n, "ms_per_step": round(ms, 4),
-                                             "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if fl else None}
-                                         for k, (n, ms, fl, ex) in acc8.items() if k.startswith("conv")}}
-        h3f8_mode["f8_launches_per_step"] = sum(v[0] for k, v in acc8.items() if k.startswith("conv_f8"))
-        if h3f8_mode["f8_launches_per_step"] == 0:
-            h3f8_mode["note"] = ("no launch of this workload qualifies for the float8 cross-term form (it needs >= 512 workgroups of 8-slice bricks): "
-                                 "precision='h3f8' computes exactly what 'h3' computes here")
-        if "conv_f8" in acc8:
-            n, ms, fl, ex = acc8["conv_f8"]
-            a8 = fl / (ms * 1e-3) / 1e12
-            h3f8_mode["roofline"] = {"bound": "mfma", "kernel": "conv3d_igemm_h3f8<3, 1> (hi.hi on v_mfma_f32_16x16x32_f16, both cross "
-                                     "terms on v_mfma_scale_f32_16x16x128_f8f6f4)", "achieved": round(a8, 2), "peak": PEAK_F16_MFMA_TFLOPS,
-                                     "unit": "TFLOP/s", "frac": round(a8 / PEAK_F16_MFMA_TFLOPS, 4),
-                                     "executed_mfma_frac_of_peak": round(ex / (ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
-                                     "avg_launch_ms": round(ms / n, 4), "launches_per_step": n}
-        log(f"h3f8 mode: {sp8 * 1e3:.2f} ms/step")
-        del s8, m8
-        torch.cuda.empty_cache()
-
     # ---- one whole chain, wall clock: generate() of B volumes through all T steps (the K-step figure extrapolates to this) ------
     full_chain = None
     if rank == 0 and world == 1 and not args.no_full_chain:
@@ -514,12 +511,13 @@ def main():
                                    f"value = n_gpus*B/(T*s_per_step)",
                        "batch_per_gpu": B, "global_batch": B * world, "timesteps": T_FULL,
                        "weights": "seeded synthetic (seed 0), rank-0 broadcast", "parallelism": f"batch-shard x{world}" + (" (REHEARSAL: ranks share one GPU, gloo)" if rehearsal else "")},
-            "roofline": roofline, "cpu_baseline": cpu, "fp32_mode": fp32_mode, "h3f8_mode": h3f8_mode, "full_chain": full_chain,
+            "roofline": roofline, "cpu_baseline": cpu, "fp32_mode": fp32_mode, "full_chain": full_chain,
             "per_kernel_kind": per_kind,
             "per_kernel_kind_note": "eager launches with a HIP-event pair around each (event overhead included; the timed step is "
                                     "a HIP-graph replay, so these rows sum to slightly more than ms_per_step)",
             "ranks": ranks_info,
             "conv_mfma_util_pct": None if roofline is None else round(100 * roofline["executed_mfma_frac_of_peak"], 2),
+            "conv_mfma_useful_util_pct": None if roofline is None else round(100 * roofline["useful_mfma_frac_of_peak"], 2),
             "precision": args.precision, "norm": args.norm,
         }
         print(json.dumps(line), flush=True)

@@ -21,9 +21,10 @@
 extern "C" {
 #endif
 
-#define DM3D_VERSION 108          /* major*100 + minor; the descriptor structs grew in 101 (w_layout), 102 (scratch), 103 (skip_*),
+#define DM3D_VERSION 109          /* major*100 + minor; the descriptor structs grew in 101 (w_layout), 102 (scratch), 103 (skip_*),
                                      104 (dm3d_attention), 105 (x1_fmt / out_fmt / post_*), 106 (ddpm seed_dev; conv/gemm range_flag; the
-                                     training entries), 107 (conv wpk_f8: the float8 cross-term form), 108 (conv wpk_wino: the Winograd-x form): a host built against an older header must be rebuilt */
+                                     training entries), 107 (conv wpk_f8: a float8 cross-term form, removed again in 109), 108 (conv wpk_wino: the Winograd-x form), 109 (wpk_f8 and
+                                     dm3d_pack_weights_h3f8 are gone; the Winograd-x image pairs its taps differently): a host built against an older header must be rebuilt */
 
 #define DM3D_OK            0
 #define DM3D_EINVAL       -1      /* bad argument (shape, alignment, null pointer) */
@@ -103,13 +104,8 @@ int     dm3d_pack_weights_convt_h3(const float* keras_kernel, int32_t cin, int32
 int64_t dm3d_packed_weight_h3p_bytes(int32_t taps, int32_t cin, int32_t cout);
 int     dm3d_pack_weights_h3p(const float* keras_kernel, int32_t taps, int32_t cin, int32_t cout, int32_t w_exp,
                               const float* in_scale, void* packed, int32_t mode, void* stream);
-/* image for dm3d_conv_desc.wpk_f8: the DM3D_WL_PAIR geometry with taps padded to a multiple of 8 and records [hi16 c0-7 | hi16 c8-15 |
- * bl8 c0-7, bh8 c0-7 | bl8 c8-15, bh8 c8-15] (float8 e4m3: bl8 = fp8(lo * 4), bh8 = fp8(hi * 2^-11)); modes as dm3d_pack_weights_h3p */
-int64_t dm3d_packed_weight_h3f8_bytes(int32_t taps, int32_t cin, int32_t cout);
-int     dm3d_pack_weights_h3f8(const float* keras_kernel, int32_t taps, int32_t cin, int32_t cout, int32_t w_exp,
-                               const float* in_scale, void* packed, int32_t mode, void* stream);
 /* image for dm3d_conv_desc.wpk_wino from a [3,3,3,Cin,Cout] kernel: the DM3D_WL_PAIR record format, per 16-channel chunk 20 steps
- * (5 pairs of (dz, dy) taps, the tenth tap zero) x 4 transform terms u0 = g0, u1 = (g0+g1+g2)/2, u2 = (g0-g1+g2)/2, u3 = g2 of the x taps */
+ * (5 pairs of (dz, dy) taps — (dz, 0) | (dz, 1) for dz = 0, 1, 2; (0, 2) | zero; (1, 2) | (2, 2) —) x 4 transform terms u0 = g0, u1 = (g0+g1+g2)/2, u2 = (g0-g1+g2)/2, u3 = g2 of the x taps */
 int64_t dm3d_packed_weight_h3w_bytes(int32_t cin, int32_t cout);
 int     dm3d_pack_weights_h3w(const float* keras_kernel, int32_t cin, int32_t cout, int32_t w_exp, const float* in_scale, void* packed,
                               void* stream);
@@ -189,19 +185,12 @@ typedef struct dm3d_conv_desc {
        range_limit / 2).  The host reads the flag once per generate() / forward and raises instead of returning clamped results
        (rerun with DM3D_PREC_F32).  NULL: no check. */
     int32_t* range_flag; float range_limit;
-    /* Optional second weight image for the "H3F8" arithmetic (DM3D_PREC_H3 k3 / stride-1 / UpSample / Conv3DTranspose convs with cout > 32):
-       a.b = ah.bh on float16 MFMA as in H3, the two cross terms ah.bl + al.bh on float8 (e4m3) operands through
-       v_mfma_scale_f32_16x16x128_f8f6f4 (2.25x the float16 rate): 1.9 instead of 3 MFMA units per product.  The cross terms are 2^-11 of
-       a product, so their float8 rounding (2^-4) costs ~2^-15 relative per product — eps of the whole U-Net 5-9e-5 against the 1e-3 contract
-       (H3: 5-8e-6) — and activations are clamped at +-448 instead of +-65504 (range_limit must be <= 448 for such a launch's producers).
-       Packed by dm3d_pack_weights_h3f8 with THIS conv's w_exp.  The kernel uses it when the launch has enough bricks for its 8-slice form
-       (dm3d_conv_tile_form() == 9) and no fused skip conv / hand-off output; otherwise wpk serves the launch as before.  NULL: never. */
-    const void* wpk_f8;
     /* Optional weight image of the Winograd F(2,3)-along-x form of a DM3D_PREC_H3 k3 / stride-1 conv with cout > 32 (dm3d_pack_weights_h3w,
        packed with THIS conv's w_exp): two neighbouring outputs of a row from four transformed inputs — 36 instead of 54 MFMA k-steps per
        output pair, same split-float16 products and float32 accumulation (results differ from the direct form in the last bits only).
-       The kernel uses it when the volume is whole 8x8x8 bricks, Cin >= 32, the launch has no fused skip conv and enough bricks (a launch of
-       at most 128 of its workgroups with Cin >= 256 and a linear epilogue splits Cin two ways, the halves meeting by atomic add)
+       The kernel uses it when the volume is whole 8x8x8 bricks, Cin >= 32, a fused skip conv is short and there are enough bricks (a launch of
+       at most 128 of its work items with Cin >= 256 and a linear epilogue splits Cin two ways, the halves meeting by atomic add); without a
+       fused skip conv one persistent workgroup per CU walks the list of (brick, column tile, Cin part) items
        (dm3d_conv_tile_form() == 10); otherwise wpk serves the launch as before.  The transformed inputs are up to 2 max|x|: producers of
        such a conv must keep |x| <= 32752 (pass range_limit <= 32752 to them).  NULL: never. */
     const void* wpk_wino;
@@ -211,8 +200,8 @@ int     dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream);
 int64_t dm3d_conv_scratch_bytes(const dm3d_conv_desc* d);
 /* Which tile form of the 16x16x32 conv kernels serves this descriptor: 8 (8 z-slices per brick, 512 threads, one workgroup per CU — launches
  * with enough bricks to give every CU two such workgroups in turn), 4 (4 slices, 256 threads, two workgroups per CU: small grids, the parity
- * form, launches with a fused skip conv, Cout <= 32), 9 (the 8-slice H3F8 form: wpk_f8 given and eligible), 10 (the Winograd-x form: wpk_wino given and eligible; conv3d_igemm_h3w<MODE>), 0 (another kernel).  Profiling
- * harnesses use it to name the instantiation a launch runs (rocprofv3 lists conv3d_igemm_h3v3<KS, MODE, TD, NCT>; 9: conv3d_igemm_h3f8<KS, MODE>). */
+ * form, launches with a fused skip conv, Cout <= 32), 10 (the Winograd-x form: wpk_wino given and eligible; conv3d_igemm_h3w<MODE>), 0 (another kernel).  Profiling
+ * harnesses use it to name the instantiation a launch runs (rocprofv3 lists conv3d_igemm_h3v3<KS, MODE, TD, NCT> and conv3d_igemm_h3w<MODE, SKIP>). */
 int32_t dm3d_conv_tile_form(const dm3d_conv_desc* d);
 
 /* ---- Dense / einsum contractions: out[b][m][n] = act(alpha * sum_k A[b][m][k]*B[b][n][k] + bias) + res -------

@@ -222,7 +222,7 @@ def test_conv3d_h3_tap_layout_arm(dev):
     if os.environ.get("DM3D_CONV_PAIR") == "0":
         pytest.skip("already inside the tap-layout arm")
     env = dict(os.environ, DM3D_CONV_PAIR="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "(test_conv3d or random_shapes) and h3 and not h3f8",
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "(test_conv3d or random_shapes) and h3",
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -654,117 +654,7 @@ def test_gather_add_graph(dev):
     check(lib().dm3d_graph_destroy(g))
 
 
-F8_TOL = 1e-4      # per-kernel bar of the float8 cross-term form: the cross terms (2^-11 of a product) carry float8's 2^-4 rounding
-
-
-@pytest.mark.parametrize("case", ["plain", "prologue_vec_res", "upsample", "skip_phase"])
-def test_conv3d_h3f8_form(dev, case):
-    """The "H3F8" arithmetic (dm3d_conv_desc.wpk_f8: ah.bh on float16 MFMA, ah.bl + al.bh on float8 e4m3 through
-    v_mfma_scale_f32_16x16x128_f8f6f4) against the float64 oracle, on launches large enough for its 8-slice form."""
-    import ctypes as C
-    from dm3d_amd import ops, _lib
-    from oracle import ref_torch as rt
-    g = torch.Generator().manual_seed(hash(case) % 1000)
-    B, S, cin, cout = (8, 32, 48, 64) if case != "upsample" else (8, 16, 64, 64)
-    x = torch.randn(B, S, S, S, cin, generator=g)
-    k = torch.randn(3, 3, 3, cin, cout, generator=g) / (27 * cin) ** 0.5
-    bias = torch.randn(cout, generator=g) * 0.1
-    xd, kd = x.to(dev), k.to(dev)
-    kw = dict(bias=bias.to(dev), precision=_lib.PREC_H3)
-    if case == "upsample":
-        ref = rt._conv3d(rt._upsample2(x.double()), k.double(), bias.double())
-        wpk, w_exp = ops.pack_weights_up(kd, h3=True)
-        f8 = ops.pack_weights_h3f8(kd, w_exp, mode=1)
-        out3 = ops.conv3d(xd, wpk, cout, 3, upsample=True, w_exp=w_exp, **kw)
-        out = ops.conv3d(xd, wpk, cout, 3, upsample=True, w_exp=w_exp, wpk_f8=f8, **kw)
-    else:
-        wpk, w_exp = ops.pack_weights_h3(kd)
-        extra, ref_x = {}, x.double()
-        if case == "prologue_vec_res":
-            sc, sh = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.1
-            vec, res = torch.randn(B, cout, generator=g), torch.randn(B, S, S, S, cout, generator=g)
-            ref_x = torch.nn.functional.silu(x.double() * sc.double() + sh.double())
-            extra = dict(pro_scale=sc.to(dev), pro_shift=sh.to(dev), vec=vec.to(dev), res=res.to(dev))
-        ref = rt._conv3d(ref_x, k.double(), bias.double())
-        if case == "prologue_vec_res":
-            ref = ref + vec.double()[:, None, None, None, :] + res.double()
-        if case == "skip_phase":
-            sx = torch.randn(B, S, S, S, 32, generator=g)
-            sk = torch.randn(1, 1, 1, 32, cout, generator=g) / 32 ** 0.5
-            w_exp = ops.h3_weight_exponent(kd, sk.to(dev))
-            wpk, _ = ops.pack_weights_h3(kd, w_exp=w_exp)
-            extra = dict(skip=(sx.to(dev), None, ops.pack_weights_skip_h3p(sk.to(dev), w_exp)))
-            ref = ref + rt._conv3d(sx.double(), sk.double(), None)
-        f8 = ops.pack_weights_h3f8(kd, w_exp)
-        out3 = ops.conv3d(xd, wpk, cout, 3, w_exp=w_exp, **extra, **kw)
-        out = ops.conv3d(xd, wpk, cout, 3, w_exp=w_exp, wpk_f8=f8, **extra, **kw)
-    torch.cuda.synchronize()
-    e3, e8 = _rel(out3, ref), _rel(out, ref)
-    print(f"{case}: three-pass float16 {e3:.2e}, float8 cross terms {e8:.2e}")
-    assert e3 < 2e-5 and e8 < F8_TOL
-    assert not torch.equal(out, out3)                      # the float8 form really ran (its rounding differs)
-
-
-def test_conv3d_h3f8_handoff_pair(dev):
-    """The ResidualBlock interior of the float8 form: conv1 (float8 cross terms) stores DM3D_FMT_H2, conv2 builds its float8 operands
-    from the stored halves (h2_to_x8) — both against float64."""
-    from dm3d_amd import ops, _lib
-    from oracle import ref_torch as rt
-    g = torch.Generator().manual_seed(11)
-    B, S, cm, cout = 8, 32, 64, 64
-    x = torch.randn(B, S, S, S, cm, generator=g)
-    k1 = torch.randn(3, 3, 3, cm, cout, generator=g) / math.sqrt(cm * 27)
-    k2 = torch.randn(3, 3, 3, cout, cout, generator=g) / math.sqrt(cout * 27)
-    b1, b2 = torch.randn(cout, generator=g), torch.randn(cout, generator=g)
-    s2, t2 = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
-    h_ref = _conv_ref(x, k1, b1)
-    a_ref = rt._swish(h_ref * s2.double() + t2.double())
-    y_ref = _conv_ref(a_ref, k2, b2)
-    c = lambda t: t.to(dev).contiguous()
-    w1, e1 = ops.pack_weights_h3(c(k1))
-    w2, e2 = ops.pack_weights_h3(c(k2))
-    f1, f2 = ops.pack_weights_h3f8(c(k1), e1), ops.pack_weights_h3f8(c(k2), e2)
-    H3 = dict(precision=_lib.PREC_H3)
-    a_h2 = ops.conv3d(c(x), w1, cout, 3, bias=c(b1), w_exp=e1, post=(c(s2), c(t2)), out_h2=True, wpk_f8=f1, **H3)
-    a_dec = ops.h2_to_f32(a_h2.reshape(-1, cout), cout).reshape(B, S, S, S, cout)
-    ea = _rel(a_dec, a_ref)
-    y = ops.conv3d(a_h2, w2, cout, 3, bias=c(b2), w_exp=e2, x1_h2_channels=cout, wpk_f8=f2, **H3)
-    y3 = ops.conv3d(a_h2, w2, cout, 3, bias=c(b2), w_exp=e2, x1_h2_channels=cout, **H3)
-    torch.cuda.synchronize()
-    ey, ey3 = _rel(y, y_ref), _rel(y3, y_ref)
-    print(f"hand-off pair: conv1 {ea:.2e}, conv2 float8 {ey:.2e}, conv2 three-pass on the same input {ey3:.2e}")
-    assert ea < F8_TOL and ey < F8_TOL
-
-
-def test_conv3d_h3f8_ragged_extent_concat_and_channel_masks(dev):
-    """The float8 form on a launch whose bricks are not all full (30 x 32 x 28 voxels: the scalar epilogue with its bounds checks), with a
-    concatenated input whose second part is not a multiple of 16 channels (32 + 20: zero-masked pieces in the staging) and Cout = 72 (a masked
-    second column tile), prologue + vec + relu + residual — against float64 and against the three-pass form of the same launch."""
-    from dm3d_amd import ops, _lib
-    g = torch.Generator().manual_seed(77)
-    B, dims, c1, c2, cout = 8, (30, 32, 28), 32, 20, 72
-    x1 = torch.randn(B, *dims, c1, generator=g)
-    x2 = torch.randn(B, *dims, c2, generator=g)
-    k = torch.randn(3, 3, 3, c1 + c2, cout, generator=g) / math.sqrt(27 * (c1 + c2))
-    bias, vec = torch.randn(cout, generator=g) * 0.1, torch.randn(B, cout, generator=g)
-    sc, sh = torch.rand(c1 + c2, generator=g) + 0.5, torch.randn(c1 + c2, generator=g) * 0.1
-    res = torch.randn(B, *dims, cout, generator=g)
-    ref = _conv_ref(x1, k, bias, x2=x2, pro=(sc, sh), vec=vec, relu=True, res=res)
-    c = lambda t: t.to(dev).contiguous()
-    wpk, w_exp = ops.pack_weights_h3(c(k))
-    f8 = ops.pack_weights_h3f8(c(k), w_exp)
-    kw = dict(x2=c(x2), bias=c(bias), vec=c(vec), pro_scale=c(sc), pro_shift=c(sh), relu=True, res=c(res), precision=_lib.PREC_H3, w_exp=w_exp)
-    out3 = ops.conv3d(c(x1), wpk, cout, 3, **kw)
-    out8 = ops.conv3d(c(x1), wpk, cout, 3, wpk_f8=f8, **kw)
-    torch.cuda.synchronize()
-    e3, e8 = _rel(out3, ref), _rel(out8, ref)
-    print(f"ragged: three-pass {e3:.2e}, float8 cross terms {e8:.2e}")
-    assert e3 < 2e-5 and e8 < F8_TOL
-    assert not torch.equal(out3, out8)
-
-
-@pytest.mark.parametrize("f8", [False, True], ids=["three_pass", "float8"])
-def test_conv3d_h2_handoff_on_a_grid_of_half_8_slice_bricks(dev, f8):
+def test_conv3d_h2_handoff_on_a_grid_of_half_8_slice_bricks(dev):
     """D = 12: whole 4-slice bricks (what the hand-off output needs) but not whole 8-slice bricks, on a launch large enough for the 8-slice
     forms (B = 16: 512 workgroups).  The fused output (norm + swish + DM3D_FMT_H2 store) lives in the full-brick epilogue, so such a launch
     must stay on the 4-slice form — it once went to the 8-slice kernel, whose partial bricks stored plain float32 into the H2 tensor."""
@@ -779,8 +669,7 @@ def test_conv3d_h2_handoff_on_a_grid_of_half_8_slice_bricks(dev, f8):
     a_ref = rt._swish(_conv_ref(x, k1, b1) * s2.double() + t2.double())
     c = lambda t: t.to(dev).contiguous()
     w1, e1 = ops.pack_weights_h3(c(k1))
-    kw = dict(wpk_f8=ops.pack_weights_h3f8(c(k1), e1)) if f8 else {}
-    a_h2 = ops.conv3d(c(x), w1, cout, 3, bias=c(b1), w_exp=e1, post=(c(s2), c(t2)), out_h2=True, precision=_lib.PREC_H3, **kw)
+    a_h2 = ops.conv3d(c(x), w1, cout, 3, bias=c(b1), w_exp=e1, post=(c(s2), c(t2)), out_h2=True, precision=_lib.PREC_H3)
     a_dec = ops.h2_to_f32(a_h2.reshape(-1, cout), cout).reshape(B, *dims, cout)
     torch.cuda.synchronize()
     assert _rel(a_dec, a_ref) < 2e-5

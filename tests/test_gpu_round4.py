@@ -1,0 +1,244 @@
+"""Round-4 parity cases: the PERSISTENT Winograd-x conv — workgroups that walk a list of work items,
+staging the next item's first image during the last chunk of the current one — against float64 at item lists of two to four items per
+workgroup (column tile, Cin part, sample and brick all changing between items; uneven lists; one chunk and odd chunk counts; every kernel
+MODE), the same kernel at real 32^3 shapes without the policy knobs, a NaN born INSIDE the U-Net, and the launch path of bench.py at four ranks.
+All through the C ABI (ctypes); the oracle / float64 torch is the checker only."""
+import json
+import os
+import subprocess
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from dm3d_amd import _lib
+    _lib.require_device()
+    torch.cuda.set_device(0)
+    return torch.device("cuda:0")
+
+
+def _ref_conv(x, k, bias=None, pro=None, res=None):
+    xd = x.double()
+    if pro is not None:
+        xd = xd * pro[0].double() + pro[1].double()
+        xd = xd * torch.sigmoid(xd)
+    y = F.conv3d(xd.permute(0, 4, 1, 2, 3), k.double().permute(4, 3, 0, 1, 2), padding=1).permute(0, 2, 3, 4, 1)
+    if bias is not None:
+        y = y + bias.double()
+    if res is not None:
+        y = y + res.double()
+    return y
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+
+
+def _args(T, bs=1):
+    return SimpleNamespace(timesteps=T, num_gpus=1, kernel_resize=False, bs=bs)
+
+
+# name, B, dims, c1, c2, cout, prologue, residual, workgroups (DM3D_CONV_WINO_GRID), what the list exercises
+PERSIST = [
+    ("two bricks per workgroup, 16^3 32->64", 2, (16, 16, 16), 32, 0, 64, 1, 1, 8),
+    ("one chunk, four items per workgroup, plain", 1, (16, 16, 16), 16, 0, 64, 0, 0, 2),
+    ("three chunks (odd), column tile changes between items", 1, (16, 16, 16), 48, 0, 128, 1, 0, 8),
+    ("uneven lists: 6 items on 4 workgroups", 3, (8, 8, 8), 32, 0, 128, 1, 1, 4),
+    ("concat + ragged Cin, 12 items on 5 workgroups", 1, (8, 16, 24), 32, 24, 128, 1, 0, 5),
+    ("sample changes between items (per-sample prologue rows are not used, temb-free)", 4, (8, 8, 8), 64, 0, 64, 1, 1, 2),
+]
+
+
+@pytest.mark.parametrize("case", PERSIST, ids=[c[0] for c in PERSIST])
+def test_persistent_winograd_item_lists(dev, monkeypatch, case):
+    """conv3d_igemm_h3w<MODE, false> with fewer workgroups than work items: every workgroup multiplies one item while it stages the next
+    one's first image and weight steps, the epilogue of an item runs between two items' chunk loops (conditional_dm3d.py:254-268)."""
+    from dm3d_amd import ops, _lib
+    name, B, dims, c1, c2, cout, pro, res, grid = case
+    monkeypatch.setenv("DM3D_CONV_WIDE_WGS", "1")
+    monkeypatch.setenv("DM3D_CONV_WINO_MINCHUNKS", "1")
+    torch.manual_seed(11)
+    x1 = torch.randn(B, *dims, c1, device=dev)
+    x2 = torch.randn(B, *dims, c2, device=dev) if c2 else None
+    cin = c1 + c2
+    k = torch.randn(3, 3, 3, cin, cout, device=dev) * 0.05
+    wpk, w_exp = ops.pack_weights_h3(k)
+    wino = ops.pack_weights_h3w(k, w_exp)
+    bias = torch.randn(cout, device=dev)
+    ps = (torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.1) if pro else None
+    r = torch.randn(B, *dims, cout, device=dev) if res else None
+    kw = dict(x2=x2, bias=bias, pro_scale=ps[0] if pro else None, pro_shift=ps[1] if pro else None, res=r, precision=_lib.PREC_H3, w_exp=w_exp)
+    y_one = ops.conv3d(x1, wpk, cout, 3, wpk_wino=wino, **kw)                 # one item per workgroup
+    y_direct = ops.conv3d(x1, wpk, cout, 3, **kw)
+    monkeypatch.setenv("DM3D_CONV_WINO_GRID", str(grid))
+    y_list = ops.conv3d(x1, wpk, cout, 3, wpk_wino=wino, **kw)                # the same launch as item lists
+    torch.cuda.synchronize()
+    yr = _ref_conv(torch.cat([x1, x2], -1) if c2 else x1, k, bias, ps, r)
+    assert not torch.equal(y_one, y_direct), "the Winograd form did not run"
+    assert torch.equal(y_list, y_one), "an item of a list must compute exactly what it computes alone"
+    assert _rel(y_list, yr) < 2e-5
+
+
+def test_persistent_winograd_cin_split_lists(dev, monkeypatch):
+    """The two-way Cin split under item lists: 64 items (8 bricks x 4 column tiles x 2 Cin parts) on 16 workgroups — the chunk range, the column
+    tile and the brick change between a workgroup's items, the halves meet by atomic add (8^3 level, Cin = 256)."""
+    from dm3d_amd import ops, _lib
+    for v in ("DM3D_CONV_WINO_MINCHUNKS", "DM3D_CONV_WINO", "DM3D_CONV_WINO_SPLIT"):
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.setenv("DM3D_CONV_WIDE_WGS", "1")                  # (the policy wants 256 items for the split form; this batch has 64)
+    torch.manual_seed(5)
+    B, e, cin, cout = 8, 8, 256, 256
+    x = torch.randn(B, e, e, e, cin, device=dev)
+    k = torch.randn(3, 3, 3, cin, cout, device=dev) * 0.05
+    wpk, w_exp = ops.pack_weights_h3(k)
+    wino = ops.pack_weights_h3w(k, w_exp)
+    ps = (torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.1)
+    r = torch.randn(B, e, e, e, cout, device=dev)
+    kw = dict(bias=torch.randn(cout, device=dev), pro_scale=ps[0], pro_shift=ps[1], res=r, precision=_lib.PREC_H3, w_exp=w_exp)
+    y_direct = ops.conv3d(x, wpk, cout, 3, **kw)
+    monkeypatch.setenv("DM3D_CONV_WINO_GRID", "16")
+    y = ops.conv3d(x, wpk, cout, 3, wpk_wino=wino, **kw)
+    torch.cuda.synchronize()
+    yr = _ref_conv(x, k, kw["bias"], ps, r)
+    assert not torch.equal(y, y_direct), "the Winograd form did not run"
+    assert _rel(y, yr) < 2e-5
+
+
+def test_persistent_winograd_hand_off_lists(dev, monkeypatch):
+    """Kernel MODE 2 (input in DM3D_FMT_H2 behind conv1's fused norm + swish) and the hand-off OUTPUT form under item lists."""
+    from dm3d_amd import ops, _lib
+    monkeypatch.setenv("DM3D_CONV_WIDE_WGS", "1")
+    monkeypatch.setenv("DM3D_CONV_WINO_MINCHUNKS", "1")
+    B, e, c, cm, co = 2, 16, 64, 128, 64
+    torch.manual_seed(2)
+    x = torch.randn(B, e, e, e, c, device=dev)
+    ka, kb = torch.randn(3, 3, 3, c, cm, device=dev) * 0.05, torch.randn(3, 3, 3, cm, co, device=dev) * 0.05
+    wa, ea = ops.pack_weights_h3(ka)
+    wb, eb = ops.pack_weights_h3(kb)
+    wwa, wwb = ops.pack_weights_h3w(ka, ea), ops.pack_weights_h3w(kb, eb)
+    post = (torch.rand(cm, device=dev) + 0.5, torch.randn(cm, device=dev) * 0.1)
+    pro = (torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.1)
+    outs = []
+    for grid in (None, "8"):
+        if grid:
+            monkeypatch.setenv("DM3D_CONV_WINO_GRID", grid)
+        a = ops.conv3d(x, wa, cm, 3, bias=torch.zeros(cm, device=dev), pro_scale=pro[0], pro_shift=pro[1], precision=_lib.PREC_H3, w_exp=ea,
+                       post=post, out_h2=True, wpk_wino=wwa)
+        outs.append(ops.conv3d(a, wb, co, 3, precision=_lib.PREC_H3, w_exp=eb, x1_h2_channels=cm, wpk_wino=wwb))
+    mid = _ref_conv(x, ka, None, pro)
+    mid = mid * post[0].double() + post[1].double()
+    mid = mid * torch.sigmoid(mid)
+    yr = _ref_conv(mid.float(), kb)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    assert _rel(outs[1], yr) < 2e-5
+
+
+REAL = [("32^3 192->64, B=8 (two items per workgroup)", 8, 32, 128, 64, 64, 0), ("32^3 64->64 + residual, B=4 (one item per CU)", 4, 32, 64, 0, 64, 1),
+        ("16^3 384->128, B=32 (four items per workgroup)", 32, 16, 256, 128, 128, 0)]
+
+
+@pytest.mark.parametrize("case", REAL, ids=[c[0] for c in REAL])
+def test_winograd_real_shapes_without_policy_knobs(dev, monkeypatch, case):
+    """The U-Net's own k3 shapes at the batch sizes where the launch policy picks the Winograd-x form by itself (no DM3D_CONV_* knobs), against
+    float64 on the first and last sample (the conv is per sample) and against the direct kernel on all of them."""
+    from dm3d_amd import ops, _lib
+    for v in ("DM3D_CONV_WIDE_WGS", "DM3D_CONV_WINO_MINCHUNKS", "DM3D_CONV_WINO", "DM3D_CONV_WINO_SPLIT", "DM3D_CONV_WINO_GRID", "DM3D_CONV_WINO_PERSIST"):
+        monkeypatch.delenv(v, raising=False)
+    name, B, e, c1, c2, cout, res = case
+    torch.manual_seed(21)
+    x1 = torch.randn(B, e, e, e, c1, device=dev)
+    x2 = torch.randn(B, e, e, e, c2, device=dev) if c2 else None
+    cin = c1 + c2
+    k = torch.randn(3, 3, 3, cin, cout, device=dev) * 0.05
+    wpk, w_exp = ops.pack_weights_h3(k)
+    wino = ops.pack_weights_h3w(k, w_exp)
+    bias = torch.randn(cout, device=dev)
+    ps = (torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.1)
+    r = torch.randn(B, e, e, e, cout, device=dev) if res else None
+    kw = dict(x2=x2, bias=bias, pro_scale=ps[0], pro_shift=ps[1], res=r, precision=_lib.PREC_H3, w_exp=w_exp)
+    y_direct = ops.conv3d(x1, wpk, cout, 3, **kw)
+    y = ops.conv3d(x1, wpk, cout, 3, wpk_wino=wino, **kw)
+    torch.cuda.synchronize()
+    assert not torch.equal(y, y_direct), "the Winograd form did not run"
+    assert _rel(y, y_direct) < 2e-5
+    for b in (0, B - 1):
+        xx = torch.cat([x1[b:b + 1], x2[b:b + 1]], -1) if c2 else x1[b:b + 1]
+        yr = _ref_conv(xx, k, bias, ps, r[b:b + 1] if res else None)
+        assert _rel(y[b:b + 1], yr) < 2e-5
+
+
+def test_ddpm_update_propagates_nan_like_clip_by_value(dev):
+    """tf.clip_by_value(mean, -1, 1) keeps a NaN (conditional_dm3d.py:572); fminf / fmaxf would turn it into -1."""
+    import ctypes as C
+    import dm3d_amd
+    from dm3d_amd._lib import lib, check
+    from dm3d_amd.networks import conditional_dm3d as cdm
+    from oracle import ref_torch as rt
+    T = 50
+    cfg = dm3d_amd.UNetConfig(img_size=8, img_channels=4)
+    m = cdm.DiffusionModel(8, 1024, 4, None, _args(T, 2), weights=dm3d_amd.synthetic_weights(cfg, seed=0))
+    g = torch.Generator().manual_seed(0)
+    x, eps, z = (torch.randn(2, 8, 8, 8, 4, generator=g) for _ in range(3))
+    eps[1, 2, 2, 2, 1] = float("nan")
+    t = torch.tensor([7, 30])
+    want = rt.ddpm_step(rt.Betas(T), x, eps, t, z)
+    xd = x.to(dev).clone()
+    d = m._ddpm_desc(xd, eps.to(dev), t.to(torch.int32).to(dev), 1, noise=z.to(dev))
+    check(lib().dm3d_ddpm_update(C.byref(d), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    got = xd.cpu()
+    assert torch.isnan(want[1, 2, 2, 2, 1]) and torch.isnan(got[1, 2, 2, 2, 1])
+    ok = ~torch.isnan(want)
+    assert torch.equal(torch.isnan(got), torch.isnan(want)) and float((got[ok] - want[ok]).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("where", ["out.conv.bias", "conv_in.kernel", "mid"])
+def test_nan_born_inside_the_unet_raises(dev, where):
+    """A NaN made INSIDE a step (a diverged checkpoint: NaN in a weight) must not come back as plausible clipped latents: the forward call
+    raises on its eps, and a chain raises at its end — the NaN reaches x through the posterior update, whose clip propagates it like
+    tf.clip_by_value, and the per-step range op / the end-of-chain check see it there."""
+    import dm3d_amd
+    from dm3d_amd import _lib
+    from dm3d_amd.networks import conditional_dm3d as cdm
+    cfg = dm3d_amd.UNetConfig(img_size=8, img_channels=4)
+    W = dict(dm3d_amd.synthetic_weights(cfg, seed=1))
+    key = where if where != "mid" else "down1.res0.conv2.bias"
+    W[key] = W[key].copy()
+    W[key].reshape(-1)[0] = np.nan
+    m = cdm.DiffusionModel(8, 1024, 4, None, _args(4, 2), weights=W)
+    x = torch.randn(2, 8, 8, 8, 4, generator=torch.Generator().manual_seed(3))
+    with pytest.raises(_lib.Dm3dError, match="NaN"):
+        m.network([x.to(dev), torch.tensor([1, 3]), torch.tensor([[[1]]])])
+    with pytest.raises(_lib.Dm3dError, match="NaN"):
+        m.generate((2, 8, 8, 8, 4), context_value=1, seed=2)
+    smp = m.sampler((2, 8, 8, 8, 4), context_value=1, seed=3, use_graph=False)
+    smp.reset()
+    with pytest.raises(_lib.Dm3dError):
+        for _ in range(4):
+            smp.step()
+
+
+def test_bench_four_rank_rehearsal(dev):
+    """`python bench.py --gpus 4` in rehearsal mode: four rank processes on GPU 0 over gloo (the boxes allow six GPU processes, so this is the
+    widest rehearsal that touches the card; the eight-rank width of the driver's run is rehearsed without a GPU in tests/test_host.py)."""
+    env = dict(os.environ, DM3D_BENCH_REHEARSAL="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--size", "8", "--channels", "4", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 4 and line["config"]["global_batch"] == 8 and line["scaling"] == "weak"
+    ranks = line["ranks"]
+    assert ranks["world_size"] == 4 and [p["seed"] for p in ranks["per_rank"]] == [1234, 1235, 1236, 1237]
+    assert len({p["weights_sha"] for p in ranks["per_rank"]}) == 1 and all(p["ms_per_step"] > 0 for p in ranks["per_rank"])

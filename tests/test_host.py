@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol(built_library):
         assert hasattr(handle, name), f"{name} declared in include/dm3d.h but not exported"
     from dm3d_amd import _lib
     assert set(_lib.SIGNATURES) == declared
-    assert _lib.lib().dm3d_version() == _lib.ABI_VERSION == 108
+    assert _lib.lib().dm3d_version() == _lib.ABI_VERSION == 109
     assert _lib.lib().dm3d_packed_weight_elems(27, 96, 64) == 27 * 64 * 96
     assert _lib.lib().dm3d_packed_weight_elems(1, 8, 8) == 64 * 16
 
@@ -275,3 +275,27 @@ def test_bench_self_launch_fails_fast_when_a_rank_dies(built_library):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "ranks failed" in r.stderr, r.stderr[-2000:]
     assert r.stdout.strip() == "" and time.time() - t0 < 120
+
+
+def test_bench_launch_path_at_eight_ranks_without_a_gpu():
+    """The width the driver's scaling run uses: `python bench.py --gpus 8` self-launches eight rank processes, which rendezvous over gloo,
+    broadcast rank 0's weights, compare digests, gather per-rank records, time between barriers and reduce the maximum — in
+    DM3D_BENCH_REHEARSAL=cpu mode, where no rank touches a GPU (the GPU boxes admit six GPU processes; tests/test_gpu_round4.py rehearses four
+    ranks on the card).  The line says what it is; a rank that dies takes its siblings down and the parent fails."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, DM3D_BENCH_REHEARSAL="cpu")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--batch", "2",
+                        "--size", "8", "--channels", "4"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["metric"].startswith("NOT A MEASUREMENT") and line["value"] == 0.0
+    ranks = line["ranks"]
+    assert ranks["world_size"] == 8 and ranks["backend"] == "gloo"
+    assert [p["seed"] for p in ranks["per_rank"]] == list(range(1234, 1242))
+    assert len({p["weights_sha"] for p in ranks["per_rank"]}) == 1
+    per = [p["ms_per_step"] for p in ranks["per_rank"]]
+    assert max(per) <= line["ms_per_step"] * 1.5 and line["ms_per_step"] >= 5.9       # the slowest ranks sleep 6 ms per step: the maximum is reported

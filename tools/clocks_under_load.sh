@@ -6,9 +6,9 @@
 out=${1:-gpurun_out/clocks_under_load.log}
 mkdir -p "$(dirname "$out")"; : > "$out"
 for wino in 1 0; do
-  echo "=== DM3D_CONV_WINO=$wino: python3 bench.py --steps 3000 --warmup 20 --no-cpu-baseline --no-fp32-mode --no-h3f8-mode --no-full-chain" >> "$out"
+  echo "=== DM3D_CONV_WINO=$wino: python3 bench.py --steps 3000 --warmup 20 --no-cpu-baseline --no-fp32-mode --no-full-chain" >> "$out"
   SECONDS=0
-  DM3D_CONV_WINO=$wino timeout -k 10 300 python3 bench.py --steps 3000 --warmup 20 --no-cpu-baseline --no-fp32-mode --no-h3f8-mode \
+  DM3D_CONV_WINO=$wino timeout -k 10 300 python3 bench.py --steps 3000 --warmup 20 --no-cpu-baseline --no-fp32-mode \
       --no-full-chain 2>&1 | while IFS= read -r line; do printf '%4d s  %s\n' "$SECONDS" "$line"; done > "$out.bench$wino" &
   pid=$!
   sleep 10

@@ -1,4 +1,4 @@
-"""Micro-benchmark of dm3d_conv3d_ndhwc on the layer shapes of the 32^3 U-Net.  usage: python tools/conv_bench.py [h3|h3f8|fp32] [B] [only-k3s1]"""
+"""Micro-benchmark of dm3d_conv3d_ndhwc on the layer shapes of the 32^3 U-Net.  usage: python tools/conv_bench.py [h3|fp32] [B] [only-k3s1]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -28,11 +28,9 @@ for name, e, c1, c2, cout, ks, stride, ups, pro, res, vec in CASES:
     k = torch.randn(ks, ks, ks, c1 + c2, cout, device=dev) * 0.05
     if len(sys.argv) > 3 and (ks != 3 or stride != 1 or cout < 64):
         continue
-    if prec in ("h3", "h3f8"):
+    if prec == "h3":
         wpk, w_exp = ops.pack_weights_up(k, h3=True) if ups else ops.pack_weights_h3(k, stride=stride)
         kw = dict(precision=_lib.PREC_H3, w_exp=w_exp)
-        if prec == "h3f8" and ks == 3 and stride == 1 and cout >= 64:
-            kw["wpk_f8"] = ops.pack_weights_h3f8(k, w_exp, mode=1 if ups else 0)
     else:
         wpk, kw = (ops.pack_weights_up(k) if ups else ops.pack_weights(k)), {}
     eo = e * (2 if ups else 1) // stride

@@ -10,15 +10,14 @@ tail -2 $out/${tag}_gpu_tests.log
 bash tools/profile_round.sh ${tag}_h3 h3
 mkdir -p $out/keep && cp $out/${tag}_h3_pmc_hbm.csv $out/${tag}_h3_sq.csv $out/${tag}_h3_clock.csv $out/${tag}_h3_clockv3.csv profiles/      # so that the bench below attaches them
 python3 bench.py --steps 30 --warmup 5 2> $out/${tag}_h3_bench.log | tail -1 > $out/${tag}_h3_bench.json
-python3 bench.py --batch 4 --channels 4 --steps 50 --warmup 5 --no-fp32-mode --no-h3f8-mode 2> /dev/null | tail -1 > $out/${tag}_h3_config2_bench.json
-python3 bench.py --batch 1 --steps 50 --warmup 5 --no-cpu-baseline --no-fp32-mode --no-h3f8-mode --no-full-chain 2> /dev/null | tail -1 > $out/${tag}_h3_b1_bench.json
-python3 bench.py --precision h3f8 --steps 30 --warmup 5 --no-cpu-baseline --no-fp32-mode 2> /dev/null | tail -1 > $out/${tag}_h3f8_bench.json
-python3 bench.py --norm group --steps 20 --warmup 3 --no-cpu-baseline --no-fp32-mode --no-h3f8-mode --no-full-chain 2> /dev/null | tail -1 > $out/${tag}_h3_groupnorm_bench.json
+python3 bench.py --batch 4 --channels 4 --steps 50 --warmup 5 --no-fp32-mode 2> /dev/null | tail -1 > $out/${tag}_h3_config2_bench.json
+python3 bench.py --batch 1 --steps 50 --warmup 5 --no-cpu-baseline --no-fp32-mode --no-full-chain 2> /dev/null | tail -1 > $out/${tag}_h3_b1_bench.json
+python3 bench.py --norm group --steps 20 --warmup 3 --no-cpu-baseline --no-fp32-mode --no-full-chain 2> /dev/null | tail -1 > $out/${tag}_h3_groupnorm_bench.json
 python3 tools/e2e_config5.py > $out/${tag}_e2e_config5.log 2>&1 || tail -5 $out/${tag}_e2e_config5.log
 python3 tools/chain_repeatability.py > $out/${tag}_chain_repeatability.log 2>&1 || tail -5 $out/${tag}_chain_repeatability.log
 python3 -c "
 import json
-for f in ('h3_bench','h3_config2_bench','h3_b1_bench','h3f8_bench','h3_groupnorm_bench'):
+for f in ('h3_bench','h3_config2_bench','h3_b1_bench','h3_groupnorm_bench'):
     d=json.load(open('$out/${tag}_'+f+'.json')); r=d.get('roofline') or {}
     print(f, round(d['ms_per_step'],3), round(d['value'],4), r.get('achieved'), r.get('traffic'), r.get('mfma_busy_frac'), r.get('clock_ghz'))"
 tail -3 $out/${tag}_e2e_config5.log; tail -3 $out/${tag}_chain_repeatability.log

@@ -13,19 +13,19 @@ out=$PWD/gpurun_out
 mkdir -p $out
 python3 bench.py --precision $prec --steps 30 --warmup 5 2> $out/${tag}_bench.log | tail -1 > $out/${tag}_bench.json
 echo "bench done: $(cut -c1-160 $out/${tag}_bench.json)"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_stats -o run -- python3 bench.py --precision $prec --steps 10 --warmup 2 --no-cpu-baseline --no-fp32-mode --no-h3f8-mode --no-full-chain > $out/prof_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_stats -o run -- python3 bench.py --precision $prec --steps 10 --warmup 2 --no-cpu-baseline --no-fp32-mode --no-full-chain > $out/prof_stats.log 2>&1
 cp $(find $out/prof_stats -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats.csv
 echo "stats done: $(sed -n 2p $out/${tag}_kernel_stats.csv | cut -c1-200)"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/prof_$c -o run -- python3 bench.py --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-h3f8-mode --no-full-chain --no-graph > $out/prof_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/prof_$c -o run -- python3 bench.py --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-full-chain --no-graph > $out/prof_$c.log 2>&1
   mkdir -p $out/pmc_$c && cp $(find $out/prof_$c -name "*counter_collection.csv" | head -1) $out/pmc_$c/pmc_counter_collection.csv
 done
 python3 profiles/summarize_pmc.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/${tag}_pmc_hbm.csv \
   "$tag: rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph (B=32, 32^3x8ch); KB per launch" \
   "batch=32 size=32 channels=8 norm=batch precision=$prec csrc=$(python3 bench.py --print-csrc-digest)" | head -8
 # 4. SQ counters of the same command (two passes, 8 SQ slots each) -> <tag>_sq.csv (profiles/summarize_sq.py)
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/prof_sqA -o run -- python3 bench.py --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-h3f8-mode --no-full-chain --no-graph > $out/prof_sqA.log 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/prof_sqB -o run -- python3 bench.py --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-h3f8-mode --no-full-chain --no-graph > $out/prof_sqB.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/prof_sqA -o run -- python3 bench.py --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-full-chain --no-graph > $out/prof_sqA.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/prof_sqB -o run -- python3 bench.py --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-full-chain --no-graph > $out/prof_sqB.log 2>&1
 python3 profiles/summarize_sq.py $out/${tag}_sq.csv \
   "$tag: rocprofv3 --pmc <8 SQ counters> GRBM_GUI_ACTIVE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph (B=32, 32^3x8ch; two passes); averages per launch" \
   "batch=32 size=32 channels=8 norm=batch precision=$prec csrc=$(python3 bench.py --print-csrc-digest)" $out/prof_sqA $out/prof_sqB | head -6 | cut -c1-400
