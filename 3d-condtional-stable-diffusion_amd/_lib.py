@@ -52,6 +52,18 @@ class GemmDesc(C.Structure):
     ]
 
 
+class MlpDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int64),
+        ("w0", C.c_void_p), ("b0", _f32p),
+        ("w1", C.c_void_p), ("b1", _f32p),
+        ("res", _f32p), ("res2", _f32p), ("ldr", C.c_int64),
+        ("out", C.c_void_p), ("ldo", C.c_int64), ("out_fmt", C.c_int32),
+        ("m", C.c_int32), ("units", C.c_int32),
+        ("range_flag", C.c_void_p), ("range_limit", C.c_float),
+    ]
+
+
 class AttentionDesc(C.Structure):
     _fields_ = [
         ("q", _f32p), ("ldq", C.c_int64),
@@ -111,6 +123,8 @@ SIGNATURES = {
     "dm3d_conv3d_ndhwc": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "dm3d_gemm_tn": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "dm3d_gemm_tn_group": (C.c_int, [C.POINTER(GemmDesc), C.c_int32, C.c_void_p]),
+    "dm3d_mlp_fused": (C.c_int, [C.POINTER(MlpDesc), C.c_void_p]),
+    "dm3d_pack_mlp_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "dm3d_split_h2": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "dm3d_layernorm3_h2": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_float] + [_f32p] * 9 + [C.c_void_p]),
     "dm3d_softmax_rows_h2": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]),

@@ -68,6 +68,7 @@ class DiffusionModel:
         self._stream = None
         self._trainer = None
         self._trainer_dirty = False
+        self._pending_optimizer = None          # Adam slots of a loaded checkpoint, applied when the Trainer is first built
         self.network._before_use = self._sync_from_trainer
         self.network._training_engine = self._engine_for_training_forward
 
@@ -122,8 +123,20 @@ class DiffusionModel:
         self.network.load_state_dict({k: v for k, v in sd.items() if not k.startswith("optimizer/")}, strict)
         self._drop_graphs()
         self._trainer, self._trainer_dirty = None, False          # Adam moments belong to the weights they were built for
+        # the slots wait until a Trainer exists (an inference-only load builds none: theta, gradients and moments are four copies of the
+        # weights); validated now, so that a checkpoint with partial slots fails at load time with a message
+        self._pending_optimizer = None
         if opt:
-            self.trainer.load_optimizer_state(opt)
+            missing = [k for k in ["optimizer/iter"] + [f"optimizer/{slot}/{n}" for n in self._trainable_names() for slot in ("m", "v")] if k not in opt]
+            if missing:
+                raise ValueError(f"checkpoint carries optimizer state but {len(missing)} entries are missing (first: {missing[:3]}); "
+                                 "drop every optimizer/ entry to load the weights alone")
+            self._pending_optimizer = opt
+
+    def _trainable_names(self):
+        """Names of the parameters Adam updates (everything but the BatchNormalization moving statistics)."""
+        from .train import is_trainable
+        return [n for n in self.network.spec if is_trainable(n)]
 
     def load_weights(self, path, root=("network",)):
         """keras ``model.load_weights(ckpt)`` (main_conditional_dm.py:207-213): reads the U-Net from a TF2 checkpoint prefix
@@ -144,10 +157,14 @@ class DiffusionModel:
         if str(path).endswith(".npz"):
             # the Adam slots travel with the weights (as in the reference's save_weights_only TF checkpoints); the TF-format writer
             # below stores the network only
-            opt = self._trainer.optimizer_state() if self._trainer is not None and self._trainer.step_count > 0 else {}
+            opt = self._trainer.optimizer_state() if self._trainer is not None and self._trainer.step_count > 0 else (getattr(self, "_pending_optimizer", None) or {})
             np.savez(path, **self.network.state_dict(), **opt)
             return
         from . import tf_checkpoint as tc
+        if (self._trainer is not None and self._trainer.step_count > 0) or getattr(self, "_pending_optimizer", None):
+            import warnings
+            warnings.warn("save_weights: the TF-checkpoint writer stores the network only; the Adam slots and step count of this trained model "
+                          "are NOT written (a resume from this file restarts the bias correction). Save to an .npz path to keep them.")
         tc.save_unet_checkpoint(str(path), self.network.state_dict(), self.network.cfg, root=tuple(root))
 
     def _drop_graphs(self):
@@ -179,6 +196,9 @@ class DiffusionModel:
         if self._trainer is None:
             from .train import Trainer
             self._trainer = Trainer(self.network.cfg, self.network.state_dict(), self.device, lr=self._learning_rate())
+            if getattr(self, "_pending_optimizer", None):
+                self._trainer.load_optimizer_state(self._pending_optimizer)
+                self._pending_optimizer = None
         return self._trainer
 
     def _engine_for_training_forward(self):

@@ -327,3 +327,25 @@ def gather_rows(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     check(lib().dm3d_gather_rows(table.data_ptr(), table.shape[0], idx.data_ptr(), out.data_ptr(), idx.numel(), table.shape[1],
                                  _st()), "gather_rows")
     return out
+
+
+def pack_mlp_weights(w_h2: torch.Tensor, units: int, which: int) -> torch.Tensor:
+    """DM3D_FMT_H2 weights of the MLP (which = 0: [4 units, units]; 1: [units, 4 units]) -> the operand-fragment image dm3d_mlp_fused reads."""
+    out = torch.empty_like(w_h2)
+    check(lib().dm3d_pack_mlp_weights(w_h2.data_ptr(), units, which, out.data_ptr(), _st()), "pack_mlp_weights")
+    return out
+
+
+def mlp_fused(x_h2: torch.Tensor, w0_t: torch.Tensor, b0: torch.Tensor, w1_t: torch.Tensor, b1: torch.Tensor, units: int,
+              res: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None, out_h2: bool = False) -> torch.Tensor:
+    """Dense(units)(relu(Dense(4 units)(x))) + res + res2 in one launch (dm3d_mlp_fused): x [m, units] as a DM3D_FMT_H2 buffer (split_h2),
+    w0_t / w1_t from pack_mlp_weights, biases / residuals float32.  Returns [m, units] float32, or a DM3D_FMT_H2 buffer with ``out_h2``."""
+    from ._lib import MlpDesc
+    m = x_h2.numel() // units
+    out = torch.empty(m, units, dtype=torch.float32, device=x_h2.device)
+    d = MlpDesc()
+    d.x, d.ldx, d.w0, d.b0, d.w1, d.b1 = x_h2.data_ptr(), units, w0_t.data_ptr(), b0.data_ptr(), w1_t.data_ptr(), b1.data_ptr()
+    d.res, d.res2, d.ldr = _p(res), _p(res2), units
+    d.out, d.ldo, d.out_fmt, d.m, d.units = out.data_ptr(), units, (_lib.FMT_H2 if out_h2 else _lib.FMT_F32), m, units
+    check(lib().dm3d_mlp_fused(C.byref(d), _st()), "mlp_fused")
+    return out

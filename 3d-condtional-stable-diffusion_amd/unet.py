@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, ConvDesc, GemmDesc, check, lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, ConvDesc, GemmDesc, MlpDesc, check, lib
 from .betas import time_embedding_table
 from .weights import UNetConfig, keras_init_weights, upsample_parity_kernels, walk
 
@@ -67,7 +67,6 @@ class UNet:
         """``precision``: arithmetic of the Conv3d kernels — "fp32" (exact float32 MFMA) or "h3" (float16 hi+lo split,
         three 16-bit MFMA passes, float32 accumulate: float32-grade results, see include/dm3d.h).  Default: the
         DM3D_PRECISION environment variable, else "h3"."""
-        import os
         precision = precision or os.environ.get("DM3D_PRECISION", "h3")
         if precision not in ("fp32", "h3"):
             raise ValueError("precision must be 'fp32' or 'h3'")
@@ -298,6 +297,11 @@ class UNet:
                 P[f"{n}.{ln}"] = (self._dev(s[f"{n}.{ln}.gamma"]), self._dev(s[f"{n}.{ln}.beta"]))
             P[f"{n}.mlp.0"] = self._with_h2(self._pack(s[f"{n}.mlp.0.kernel"], s[f"{n}.mlp.0.bias"]))
             P[f"{n}.mlp.1"] = self._with_h2(self._pack(s[f"{n}.mlp.1.kernel"], s[f"{n}.mlp.1.bias"]))
+            for i, w in enumerate((P[f"{n}.mlp.0"], P[f"{n}.mlp.1"])):        # operand-fragment images for dm3d_mlp_fused (u = 256 only)
+                w.tiled = None
+                if w.h2 is not None and u == 256:
+                    w.tiled = torch.empty_like(w.h2)
+                    check(lib().dm3d_pack_mlp_weights(w.h2.data_ptr(), u, i, w.tiled.data_ptr(), _stream()), "pack_mlp_weights")
             P[f"{n}.key"] = self._pack(s[f"{n}.key.kernel"], s[f"{n}.key.bias"])
         else:
             P[f"{n}.norm"] = self._fold_bn(f"{n}.norm")
@@ -496,7 +500,7 @@ class Plan:
             self.range_limit = net._h3_range_limit(winograd=True)
             for d in self._keep:
                 for one in (d if isinstance(d, C.Array) else (d,)):
-                    if isinstance(one, (ConvDesc, GemmDesc)) and one.range_flag:
+                    if isinstance(one, (ConvDesc, GemmDesc, MlpDesc)) and one.range_flag:
                         one.range_limit = self.range_limit
         # one workspace for every conv that can split its Cin range (dm3d_conv_scratch_bytes): launches are stream-ordered
         need = max([lib().dm3d_conv_scratch_bytes(C.byref(d)) for d in self._keep if isinstance(d, ConvDesc)] + [0])
@@ -804,22 +808,25 @@ class Plan:
         self.ops.append((lib().dm3d_layernorm3_h2, (y.data_ptr(), M, u, LN_EPS, g1.data_ptr(), b1.data_ptr(), n1.data_ptr(),
                                                     g2.data_ptr(), b2.data_ptr(), n2.data_ptr(), g3.data_ptr(), b3.data_ptr(),
                                                     n3.data_ptr()), "layernorm", {}))
-        qkb, v_t, q2, hid = self._buf(M, 2 * u), self._buf(u, M), self._buf(M, u), self._buf(M, 4 * u)
+        # the MLP (Dense(4u, relu) -> Dense(u), :132-133) as ONE launch with the hidden activation in LDS (dm3d_mlp_fused, round 4) where the
+        # kernel's shape fits (u = 256 and enough row tiles to fill the chip); otherwise its first Dense joins the grouped launch below
+        mlp_fused = u == 256 and M >= 64 * 128 and getattr(m0, "tiled", None) is not None and os.environ.get("DM3D_MLP_FUSED", "1") != "0"
+        qkb, v_t, q2 = self._buf(M, 2 * u), self._buf(u, M), self._buf(M, u)
+        hid = None if mlp_fused else self._buf(M, 4 * u)
         self._gemm_group([
             dict(a=n1, lda=u, b=qk.h2, ldb=qk.cin_pad, out=qkb, ldo=2 * u, m=M, n=2 * u, k=u, bias=qk.bias, out_h2=True, **hh),
             dict(a=val.h2, lda=val.cin_pad, b=n1, ldb=u, out=v_t, ldo=M, m=u, n=M, k=u, bias=val.bias, bias_along_m=1,
                  out_h2=True, **hh),
             dict(a=n2, lda=u, b=qk.h2, ldb=qk.cin_pad, out=q2, ldo=u, m=M, n=u, k=u, bias=qk.bias, out_h2=True, **hh),
+        ] + ([] if mlp_fused else [
             dict(a=n3, lda=u, b=m0.h2, ldb=m0.cin_pad, out=hid, ldo=4 * u, m=M, n=4 * u, k=u, bias=m0.bias, act=ACT_RELU,
-                 out_h2=True, **hh),
-        ])
+                 out_h2=True, **hh)]))
         rows = B if self.per_sample_context else 1
         kctx, vctx_t = self._buf(rows, L * u), self._buf(rows, u * L)
         self.ctx_bufs[n] = (kctx, vctx_t)
         ks, vs = (L * u, u * L) if self.per_sample_context else (0, 0)
         a1, a2 = self._buf(M, u), self._buf(M, u)
         scale = float(u) ** -0.5
-        import os
         # (the fused kernel runs one 4-wave workgroup per 128 queries: it needs >= ~128 workgroups to beat the GEMM form, i.e. B >= 16 at L = 512;
         # measured B = 1 / 4 / 8: 2.80 / 3.85 / 5.74 ms per step fused against 2.5 / 3.5 / 5.3 with the three launches)
         if os.environ.get("DM3D_ATTN_FUSED", "1") != "0" and u == 256 and L % 128 == 0 and 2 * B * (L // 128) >= 128:
@@ -854,8 +861,18 @@ class Plan:
                      m=L, n=u, k=L, batch=B, **hh),
             ])
         a3 = self._buf(M, u)
-        self._gemm(a=hid, lda=4 * u, b=m1.h2, ldb=m1.cin_pad, out=a3, ldo=u, m=M, n=u, k=4 * u, bias=m1.bias, res=a1, res2=a2,
-                   ldr=u, out_h2=True, **hh)
+        if mlp_fused:
+            d = MlpDesc()
+            d.x, d.ldx, d.w0, d.b0, d.w1, d.b1 = _ptr(n3), u, m0.tiled.data_ptr(), _ptr(m0.bias), m1.tiled.data_ptr(), _ptr(m1.bias)
+            d.res, d.res2, d.ldr, d.out, d.ldo, d.out_fmt, d.m, d.units = _ptr(a1), _ptr(a2), u, _ptr(a3), u, _lib.FMT_H2, M, u
+            if self.range_flag is not None:
+                d.range_flag, d.range_limit = self.range_flag.data_ptr(), self.range_limit
+            self._keep.append(d)
+            self.ops.append((lib().dm3d_mlp_fused, (C.byref(d),), "mlp_fused",
+                             {"desc": f"mlp_fused m={M} u={u} hidden={4 * u}", "flops": 2 * 2.0 * M * u * 4 * u}))
+        else:
+            self._gemm(a=hid, lda=4 * u, b=m1.h2, ldb=m1.cin_pad, out=a3, ldo=u, m=M, n=u, k=4 * u, bias=m1.bias, res=a1, res2=a2,
+                       ldr=u, out_h2=True, **hh)
         out = self._buf(B, edge, edge, edge, u)
         self._gemm(a=a3, lda=u, b=pout.h2, ldb=pout.cin_pad, out=out, ldo=u, m=M, n=u, k=u, bias=pout.bias, act=ACT_RELU,
                    res=x, ldr=u, **hh)
@@ -905,7 +922,7 @@ class Plan:
                                              buf.shape[1], st), "gather_rows")
 
     _RANGE_OF = {"conv_wino": "conv", "conv_wino_h2in": "conv", "conv_k3s1_td4": "conv", "conv_k1": "conv", "conv_k3s2": "conv", "conv_up": "conv", "conv_k3s1_n32": "conv", "conv_k3s1_h2in": "conv", "conv_k3s1": "conv",
-                 "gemm": "attn", "gemm_h3": "attn", "attn_fused": "attn", "softmax": "attn", "layernorm": "attn", "groupnorm": "norm", "affine": "norm",
+                 "gemm": "attn", "gemm_h3": "attn", "mlp_fused": "attn", "attn_fused": "attn", "softmax": "attn", "layernorm": "attn", "groupnorm": "norm", "affine": "norm",
                  "range": "guard"}
 
     def run(self, stream: Optional[int] = None):

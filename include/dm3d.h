@@ -24,7 +24,7 @@ extern "C" {
 #define DM3D_VERSION 109          /* major*100 + minor; the descriptor structs grew in 101 (w_layout), 102 (scratch), 103 (skip_*),
                                      104 (dm3d_attention), 105 (x1_fmt / out_fmt / post_*), 106 (ddpm seed_dev; conv/gemm range_flag; the
                                      training entries), 107 (conv wpk_f8: a float8 cross-term form, removed again in 109), 108 (conv wpk_wino: the Winograd-x form), 109 (wpk_f8 and
-                                     dm3d_pack_weights_h3f8 are gone; the Winograd-x image pairs its taps differently): a host built against an older header must be rebuilt */
+                                     dm3d_pack_weights_h3f8 are gone; the Winograd-x image pairs its taps differently; dm3d_mlp_fused): a host built against an older header must be rebuilt */
 
 #define DM3D_OK            0
 #define DM3D_EINVAL       -1      /* bad argument (shape, alignment, null pointer) */
@@ -230,6 +230,25 @@ int dm3d_gemm_tn(const dm3d_gemm_desc* d, void* stream);
  * batches).  The attention blocks' GEMMs are small (m = B*L rows, one workgroup per CU each); issuing the independent ones
  * together (q|k, v^T, q2 and the MLP hidden layer; the two score products; the two P.V products) fills the chip. */
 int dm3d_gemm_tn_group(const dm3d_gemm_desc* descs, int32_t count, void* stream);
+
+/* ---- the MLP of a CrossAttentionBlock in one launch (round 4): out = Dense_1(relu(Dense_0(x))) + res + res2
+ * (conditional_dm3d.py:132-133 `keras.Sequential([Dense(units * 4, relu), Dense(units)])` applied at :194 with the residual adds of
+ * :193-195).  DM3D_PREC_H3 arithmetic; x [m][units] in DM3D_FMT_H2 (ldx in 4-byte elements, a multiple of 16); w0 / w1 = the images
+ * dm3d_pack_mlp_weights makes of the DM3D_FMT_H2 matrices [4 units][units] (which = 0) and [units][4 units] (which = 1), same byte size:
+ * every (32-row tile, 16-k record, hi | lo) operand fragment contiguous in lane order, so that the kernel streams weights with plain
+ * coalesced loads; biases and residuals float32 (16-byte aligned, ldr % 4 == 0); out float32 or DM3D_FMT_H2.  The 4 units-wide hidden
+ * activation stays in LDS.  units == 256 only (DM3D_EINVAL otherwise: issue the two dm3d_gemm_tn calls instead). */
+int dm3d_pack_mlp_weights(const void* w_h2, int32_t units, int32_t which, void* tiled, void* stream);
+typedef struct dm3d_mlp_desc {
+    const void* x; int64_t ldx;
+    const void* w0; const float* b0;
+    const void* w1; const float* b1;
+    const float* res; const float* res2; int64_t ldr;      /* optional float32 residuals [m][units] (res2 needs res) */
+    void* out; int64_t ldo; int32_t out_fmt;
+    int32_t m, units;
+    int32_t* range_flag; float range_limit;                /* as in dm3d_gemm_desc */
+} dm3d_mlp_desc;
+int dm3d_mlp_fused(const dm3d_mlp_desc* d, void* stream);
 
 /* dst(H2) = split(src * 2^exp2): one-time conversion of static operands (weights, context keys/values). k % 16 == 0 is
  * not required of src: columns k..round_up(k,16) of dst are zero filled; ld_dst % 16 == 0, ld_dst >= round_up(k,16). */

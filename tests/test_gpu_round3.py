@@ -229,7 +229,10 @@ def test_optimizer_state_survives_save_and_load(dev, tmp_path):
     b = cdm.DiffusionModel(8, 1024, 4, None, _args(T, B), weights=W)
     b.compile(optimizer=SimpleNamespace(learning_rate=1e-4))
     b.load_weights(str(tmp_path / "ck.npz"))
-    assert b.trainer.step_count == 2
+    assert b._trainer is None and b._pending_optimizer is not None      # an inference-only load builds no training buffers
+    b.generate((1, 8, 8, 8, 4), context_value=1, seed=1, steps=1)
+    assert b._trainer is None
+    assert b.trainer.step_count == 2 and b._pending_optimizer is None   # ... the slots land when the Trainer is first built
     run(b, [2])
     sa, sb = a.network.state_dict(), b.network.state_dict()
     worst = max(float(np.abs(sa[k] - sb[k]).max()) for k in sa)
@@ -240,6 +243,13 @@ def test_optimizer_state_survives_save_and_load(dev, tmp_path):
     run(c, [2])                                          # without the slots Adam restarts at step 1: a different update
     sc = c.network.state_dict()
     assert max(float(np.abs(sa[k] - sc[k]).max()) for k in sa) > 1e-6
+    # a checkpoint with partial slots fails at load time with a message, not with a KeyError inside the first train_step
+    part = dict(np.load(tmp_path / "ck.npz"))
+    del part[next(k for k in part if k.startswith("optimizer/v/"))]
+    with pytest.raises(ValueError, match="optimizer state"):
+        c.load_state_dict(part)
+    with pytest.warns(UserWarning, match="Adam slots"):                 # the TF-format writer stores the network only and says so
+        a.save_weights(str(tmp_path / "tfck"))
 
 
 def test_data_parallel_train_step_two_ranks(dev, tmp_path):

@@ -242,3 +242,31 @@ def test_bench_four_rank_rehearsal(dev):
     ranks = line["ranks"]
     assert ranks["world_size"] == 4 and [p["seed"] for p in ranks["per_rank"]] == [1234, 1235, 1236, 1237]
     assert len({p["weights_sha"] for p in ranks["per_rank"]}) == 1 and all(p["ms_per_step"] > 0 for p in ranks["per_rank"])
+
+
+@pytest.mark.parametrize("m", [64, 200, 2048], ids=["one tile", "partial last tile", "32 tiles"])
+@pytest.mark.parametrize("out_h2", [False, True], ids=["f32 out", "H2 out"])
+def test_mlp_fused_against_float64(dev, m, out_h2):
+    """dm3d_mlp_fused: Dense(u)(relu(Dense(4u)(x))) + res + res2 with the hidden activation kept in LDS (conditional_dm3d.py:132-133, 193-195)
+    against float64, u = 256; float32 and DM3D_FMT_H2 outputs, row counts that are not whole 64-row tiles."""
+    from dm3d_amd import ops
+    u = 256
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(m, u, generator=g)
+    w0, b0 = torch.randn(4 * u, u, generator=g) / 16.0, torch.randn(4 * u, generator=g) * 0.1
+    w1, b1 = torch.randn(u, 4 * u, generator=g) / 32.0, torch.randn(u, generator=g) * 0.1
+    r1, r2 = torch.randn(m, u, generator=g), torch.randn(m, u, generator=g)
+    ref = torch.relu(x.double() @ w0.double().T + b0.double()) @ w1.double().T + b1.double() + r1.double() + r2.double()
+    c = lambda t: t.to(dev).contiguous()
+    w0t, w1t = ops.pack_mlp_weights(ops.split_h2(c(w0)), u, 0), ops.pack_mlp_weights(ops.split_h2(c(w1)), u, 1)
+    out = ops.mlp_fused(ops.split_h2(c(x)), w0t, c(b0), w1t, c(b1), u, res=c(r1), res2=c(r2), out_h2=out_h2)
+    if out_h2:
+        out = ops.h2_to_f32(out, u)
+    torch.cuda.synchronize()
+    err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+    print(f"mlp_fused m={m} out_h2={out_h2}: {err:.2e}")
+    assert err < 2e-5
+    # without residuals
+    out = ops.mlp_fused(ops.split_h2(c(x)), w0t, c(b0), w1t, c(b1), u)
+    ref0 = ref - r1.double() - r2.double()
+    assert float((out.cpu().double() - ref0).abs().max() / ref0.abs().max()) < 2e-5
