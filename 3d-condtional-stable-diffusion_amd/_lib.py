@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
         ("skip_x1", _f32p), ("skip_x2", _f32p), ("skip_c1", C.c_int32), ("skip_c2", C.c_int32), ("skip_wpk", C.c_void_p),
         ("x1_fmt", C.c_int32), ("out_fmt", C.c_int32), ("post_scale", _f32p), ("post_shift", _f32p),
         ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64),
-        ("range_flag", C.c_void_p), ("range_limit", C.c_float), ("wpk_wino", C.c_void_p),
+        ("range_flag", C.c_void_p), ("range_limit", C.c_float), ("wpk_wino", C.c_void_p), ("skip_wpk_frag", C.c_void_p),
     ]
 
 
@@ -108,6 +108,7 @@ SIGNATURES = {
     "dm3d_pack_weights_h3w": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, _f32p, C.c_void_p, C.c_void_p]),
     "dm3d_packed_weight_skip_h3p_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
     "dm3d_pack_weights_skip_h3p": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "dm3d_pack_weights_skip_h3f": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "dm3d_conv_scratch_bytes": (C.c_int64, [C.POINTER(ConvDesc)]),
     "dm3d_conv_tile_form": (C.c_int32, [C.POINTER(ConvDesc)]),
     "dm3d_conv_weight_layout": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

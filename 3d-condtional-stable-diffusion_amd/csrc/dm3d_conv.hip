@@ -311,6 +311,8 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
         DM3D_REQUIRE(dm3d_aligned16(d->skip_x1) && dm3d_aligned16(d->skip_x2) && dm3d_aligned16(d->skip_wpk), "conv: skip pointers must be 16-byte aligned");
         a.sx1 = d->skip_x1; a.sx2 = d->skip_x2; a.sc1 = d->skip_c1; a.sc2 = d->skip_c2; a.swpk = d->skip_wpk;
         a.s_npairs = (int)(dm3d_round_up(d->skip_c1 + d->skip_c2, 32) / 32);
+        DM3D_REQUIRE(dm3d_aligned16(d->skip_wpk_frag), "conv: skip_wpk_frag must be 16-byte aligned");
+        a.swpk_f = d->skip_wpk_frag;
     }
     DM3D_REQUIRE(dm3d_aligned16(d->scratch) && d->scratch_bytes >= 0, "conv: scratch must be 16-byte aligned");
     a.batch = d->batch;
@@ -342,6 +344,12 @@ extern "C" int dm3d_pack_weights_skip_h3p(const float* keras_kernel, int32_t cin
     return dm3d_pack_skip_h3v2(keras_kernel, cin, cout, w_exp, packed, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int dm3d_pack_weights_skip_h3f(const float* keras_kernel, int32_t cin, int32_t cout, int32_t w_exp, void* packed, void* stream) {
+    DM3D_REQUIRE(keras_kernel && packed && cin > 0 && cout > 0, "pack_weights_skip_h3f: bad arguments");
+    DM3D_REQUIRE(w_exp >= -100 && w_exp <= 100 && dm3d_aligned16(packed), "pack_weights_skip_h3f: w_exp out of range or packed unaligned");
+    return dm3d_pack_skip_h3f(keras_kernel, cin, cout, w_exp, packed, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int32_t dm3d_conv_tile_form(const dm3d_conv_desc* d) {
     if (!d || d->precision != DM3D_PREC_H3) return 0;
     if (dm3d_conv_weight_layout(d->ksize, d->stride, d->upsample, d->transpose, d->cout) != DM3D_WL_PAIR) return 0;
@@ -351,6 +359,7 @@ extern "C" int32_t dm3d_conv_tile_form(const dm3d_conv_desc* d) {
     a.coutpad = (int)dm3d_round_up(d->cout, DM3D_COUT_PAD);
     a.parity = par_mode ? 1 : 0;
     a.s_npairs = d->skip_wpk ? (int)(dm3d_round_up(d->skip_c1 + d->skip_c2, 32) / 32) : 0;
+    a.swpk_f = d->skip_wpk ? d->skip_wpk_frag : nullptr; a.sc1 = d->skip_c1; a.sc2 = d->skip_c2;
     a.wpk_wino = d->wpk_wino; a.cout = d->cout; a.c1 = d->c1; a.c2 = d->c2; a.ind = d->in_d; a.inh = d->in_h; a.inw = d->in_w;
     a.nchunks = (int)(dm3d_round_up(d->c1 + d->c2, DM3D_CIN_PAD) / 16);
     a.x1 = d->x1; a.x2 = d->x2; a.out = d->out; a.res = d->res; a.relu = d->relu; a.relu_out = d->relu_out; a.prelu = d->prelu_alpha;      // (the Cin split

@@ -31,7 +31,8 @@ struct ConvArgs {
     int out_h2;               // h3v2: store the output in DM3D_FMT_H2 (full bricks, cout % 64 == 0 only)
     int x_h2;                 // h3v2: x1 arrives in DM3D_FMT_H2 (c1 % 16 == 0, no x2, no prologue)
     // h3v2 only: a 1x1 conv over a second (raw, un-normalised) input accumulated into the same tile (ResidualBlock skip path)
-    const float* sx1; const float* sx2; int sc1, sc2; const void* swpk; int s_npairs;   // s_npairs = round_up(sc1+sc2, 32) / 32
+    const float* sx1; const float* sx2; int sc1, sc2; const void* swpk; int s_npairs;
+    const void* swpk_f;                      // optional: the skip weights as operand fragments (dm3d_pack_weights_skip_h3f): the Winograd-x form's tail   // s_npairs = round_up(sc1+sc2, 32) / 32
     const void* wpk_wino;                    // optional weight image of the Winograd-x form (dm3d_conv_h3w.hip)
     int* range_flag; float range_limit;      // H3 range guard (include/dm3d.h): *range_flag = 1 if any |output| > range_limit
     int epi_vec4;                            // h3v2: every epilogue operand is 16-byte aligned (cout, vec_ld % 4 == 0): 16-byte epilogue accesses
@@ -49,7 +50,8 @@ int dm3d_h3v2_post_launch(const ConvArgs& a, const H3v2Launch& L, hipStream_t st
 int dm3d_conv_h3v2_ksplit(const ConvArgs& a, bool with_scratch);
 int dm3d_conv_h3v3_td(const ConvArgs& a);              // z-slices per brick (4 or 8) the free-running kernel takes for this launch
 int64_t dm3d_h3v2_skip_image_bytes(int cin, int cout);
-int dm3d_pack_skip_h3v2(const float* keras_kernel, int cin, int cout, int w_exp, void* packed, hipStream_t st);       // split factor the launch would choose
+int dm3d_pack_skip_h3v2(const float* keras_kernel, int cin, int cout, int w_exp, void* packed, hipStream_t st);
+int dm3d_pack_skip_h3f(const float* keras_kernel, int cin, int cout, int w_exp, void* packed, hipStream_t st);      // operand-fragment order       // split factor the launch would choose
 int64_t dm3d_h3v2_image_bytes(int taps, int cin, int cout);
 int dm3d_pack_h3v2(const float* keras_kernel, int taps, int cin, int cout, int w_exp, const float* in_scale, void* packed, int mode,
                    hipStream_t st);

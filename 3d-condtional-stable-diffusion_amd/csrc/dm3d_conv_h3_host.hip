@@ -201,7 +201,36 @@ __global__ __launch_bounds__(256) void pack_skip_h3v2_kernel(const float* __rest
     }
 }
 
+// the same 1x1 kernel as MFMA operand fragments: [coutpad/64][npairs][4 column tiles][hi | lo][64 lanes][8 halfs]; lane (column c = lane & 15,
+// k group = lane >> 4: chunk 2 pair + (k group >> 1), channels 8 (k group & 1) .. + 7 of it) holds its 8 consecutive k of output channel
+// 64 ntile + 16 tile + c — what the v_mfma_f32_16x16x32_f16 B operand of that lane is
+__global__ __launch_bounds__(256) void pack_skip_h3f_kernel(const float* __restrict__ w, int cin, int cout, int npairs, int ntiles,
+                                                            float scale, _Float16* __restrict__ out) {
+    const long npieces = (long)ntiles * npairs * 4 * 2 * 64;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npieces * 8; i += (long)gridDim.x * 256) {
+        const int j = (int)(i & 7);
+        long q = i >> 3;
+        const int lane = (int)(q & 63); q >>= 6;
+        const int hilo = (int)(q & 1); q >>= 1;
+        const int ni = (int)(q & 3); q >>= 2;
+        const int pair = (int)(q % npairs);
+        const int nt = (int)(q / npairs);
+        const int kg = lane >> 4;
+        const int ci = (pair * 2 + (kg >> 1)) * 16 + (kg & 1) * 8 + j, co = nt * 64 + ni * 16 + (lane & 15);
+        const float v = (ci < cin && co < cout) ? w[(long)ci * cout + co] * scale : 0.0f;
+        const _Float16 hi = (_Float16)v;
+        out[i] = hilo ? (_Float16)(v - (float)hi) : hi;
+    }
+}
+
 }  // namespace
+
+int dm3d_pack_skip_h3f(const float* keras_kernel, int cin, int cout, int w_exp, void* packed, hipStream_t st) {
+    const int npairs = (int)(dm3d_round_up(cin, 32) / 32), ntiles = (int)(dm3d_round_up(cout, 64) / 64);
+    hipLaunchKernelGGL(pack_skip_h3f_kernel, dim3(1024), dim3(256), 0, st, keras_kernel, cin, cout, npairs, ntiles, ldexpf(1.0f, w_exp),
+                       static_cast<_Float16*>(packed));
+    return dm3d_launch_check("pack_skip_h3f_kernel");
+}
 
 int64_t dm3d_h3v2_skip_image_bytes(int cin, int cout) {
     return (int64_t)(dm3d_round_up(cin, 32) / 32) * 2 * dm3d_round_up(cout, 64) * REC * (int64_t)sizeof(_Float16);

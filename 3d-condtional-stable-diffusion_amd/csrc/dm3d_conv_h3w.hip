@@ -75,10 +75,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // MODE 0: float32 input as is; 1: float32 input through the fused norm + SiLU prologue; 2: x1 already activated and split (DM3D_FMT_H2)
-// SKIP: the launch carries a fused 1x1 skip conv (its tail phase and the LDS-staged epilogue overlay the main loop's images: one work item
-// per workgroup); otherwise the workgroup is PERSISTENT: it walks a list of work items, and the next item's first image and weight steps are
-// staged during the last chunk of the current one
-template <int MODE, bool SKIP>
+// The workgroup is PERSISTENT: it walks a list of work items, and the next item's first image and weight steps are staged during the last
+// chunk of the current one.  A fused 1x1 skip conv runs between an item's chunk loop and its epilogue WITHOUT touching LDS (skip_tail below).
+template <int MODE>
 __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
     constexpr int TD = 8, TH = 8, TW = 8, CK = 16, NT = 64, NW = 4;
     constexpr int HD = TD + 2, HH = TH + 2, HROWS = HD * HH;
@@ -97,7 +96,6 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform: DMA destinations, M0, stay in scalar registers)
-    const int half = lane >> 5, q = (lane >> 4) & 1, row = lane & 15;
 
     // ---- work items.  An item = (brick, column tile, Cin part); item w = brick * ny + by, by = ntile + ntiles * khalf (column tile fastest:
     // the column tiles of one brick share all of its halo voxels).  XCD-aware as in dm3d_conv_h3v3.hip: dispatch ids d and d + 8 share an
@@ -140,16 +138,52 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
 
     // ---- staging: thread t owns 16-byte piece t & 1 (8 channels) of halo row t >> 1 = (hz, hy): ten voxels in, sixteen records out.
     // (neighbouring lanes take the two pieces of one voxel: a wave's load instruction touches 32 cache lines, not 64)
-    const int piece = tid & 1;
-    const bool s_act = (tid >> 1) < HROWS;
-    const int srow = s_act ? (tid >> 1) : HROWS - 1;
-    const int hz = srow / HH, hy = srow % HH;
+    // The lane constants of the step loop — staging piece and LDS store address, operand bases, DMA lane offset — are RE-MADE at the top of
+    // every item from an opaque copy of the thread number (lane_setup): defined once in front of the item loop they would be live across
+    // the skip tail and the epilogue as well, where every register is taken, and hipcc then spills the whole live range — reloading such
+    // a value at each of its uses INSIDE the step loop, behind a vmcnt(0) that drains the weight DMA.
+    int piece = 0;
+    bool s_act = false;
+    unsigned st_addr = 0u, a_pair[2] = {0u, 0u}, wb_hi = 0u;
+    int w_voff = 0;
+    constexpr int DZB = HH * RREC * REC * 2, DYB = RREC * REC * 2;        // bytes to the halo row one z / one y further
+    const unsigned in_addr = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)lds_in;
+    const unsigned w_addr = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)lds_w;
+    auto lane_setup = [&]() {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const int ln = t & 63, half = ln >> 5, q = (ln >> 4) & 1, row = ln & 15;
+        // staging: halo row t >> 1, piece t & 1; record k = term * 4 + x-pair of the row sits k * REC halfs further; lo piece: ^ 16 halfs
+        piece = t & 1;
+        s_act = (t >> 1) < HROWS;
+        const int srow = s_act ? (t >> 1) : HROWS - 1;
+        st_addr = in_addr + (unsigned)(srow * RREC * REC + ((piece ^ ((srow % HH) & 3)) << 3)) * 2u;
+        // operand addressing: lane (half, q, row): row = 4 * xpair + y inside a group, half = tap of the pair, q = 8-channel piece.
+        // A step's tap pair = two (dz, dy) taps, the lane half picks one: pairs 0-2 = (dz, 0) | (dz, 1) for dz = 0, 1, 2; pair 3 = (0, 2) | the
+        // pad (the voxels of (1, 2) against zero weights); pair 4 = (1, 2) | (2, 2).  So TWO lane-dependent bases serve all five (the swizzled
+        // slot depends on dy only) and the pair is an immediate: a_pair[0] + dz * DZB, a_pair[1] + {0, DZB}; hi piece (lo: ^ 32)
+        const int ay = row & 3;
+        const unsigned a_base = in_addr + (unsigned)((((2 * wave) * HH + ay) * RREC + (row >> 2)) * (REC * 2));
+        unsigned sl[3];                                                 // physical slot (bytes) of piece q in a row with y = ay + dy
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) sl[dy] = (unsigned)((q ^ ((ay + dy) & 3)) << 4);
+        a_pair[0] = a_base + (half ? DYB + sl[1] : sl[0]);
+        a_pair[1] = a_base + 2 * DYB + sl[2] + (half ? DZB : 0);
+        const int b_pos = pi_pos(row);
+        wb_hi = w_addr + (unsigned)((half * NT + b_pos) * REC + ((q ^ swz(b_pos)) << 3)) * 2u;       // hi piece (lo: ^ 32)
+        w_voff = wave * 1024 + ln * 16;
+    };
+    lane_setup();
     // the staging state always describes the image being staged — the next chunk's, which in a persistent workgroup's last chunk is the
     // NEXT item's first image: sample, whether this thread's halo row lies inside the volume, whether halo columns 0 / 9 do, and the voxel
     // index of halo column 0 (rows outside the volume: a clamped row, masked later)
     int sb, gv0;
     bool row_in, x_lo, x_hi;
     auto stage_setup = [&](const Item& it) {
+        // (the halo row from an opaque copy of the thread number, once per item: two registers that do not live across the step loop)
+        int tid_s = tid;
+        asm volatile("" : "+v"(tid_s));
+        const int sr = (tid_s >> 1) < HROWS ? (tid_s >> 1) : HROWS - 1, hz = sr / HH, hy = sr % HH;
         const int iz = it.oz0 - 1 + hz, iy = it.oy0 - 1 + hy;
         row_in = iz >= 0 && iz < p.ind && iy >= 0 && iy < p.inh;
         x_lo = it.ox0 > 0; x_hi = it.ox0 + TW < p.inw;
@@ -158,37 +192,21 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
         sb = it.b;
     };
     stage_setup(cur);
-    const int st_base = srow * RREC * REC + ((piece ^ (hy & 3)) << 3);  // halfs: record k = t * 4 + xpair sits k * REC further; lo piece: ^ 16
-
-    // ---- operand addressing: lane (half, q, row): row = 4 * xpair + y inside a group, half = tap of the pair, q = 8-channel piece
-    const int ay = row & 3;
-    const unsigned in_addr = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)lds_in;
-    const unsigned w_addr = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)lds_w;
-    unsigned a_base = in_addr + (unsigned)((((2 * wave) * HH + ay) * RREC + (row >> 2)) * (REC * 2));
-    unsigned sl[3];                                                     // physical slot (bytes) of piece q in a row with y = ay + dy
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy) sl[dy] = (unsigned)((q ^ ((ay + dy) & 3)) << 4);
-    const int b_pos = pi_pos(row);
-    const int b_hi = (half * NT + b_pos) * REC + ((q ^ swz(b_pos)) << 3);
-
     f32x4v acc[4][4][4];                                                // [t][2 * slice + row group][column tile]; zeroed in the prologue
 
     // weights: the packed image IS the LDS image, a step of a column tile is a linear 8 KB copy; wave w moves the 1 KB pieces w, w + 4.
-    // Source = a per-lane pointer into the image of the chunk being multiplied + a uniform offset (the steps of the chunk behind it — in an
-    // item's last chunk the next item's first — lie w_jump further).
-    auto w_chunk = [&](int ntile_, int ch_) {
-        return reinterpret_cast<const char*>(static_cast<const _Float16*>(p.wpk) + ((size_t)ntile_ * p.nchunks + ch_) * (NS * WPAIR));
-    };
-    const char* wcur = w_chunk(cur.ntile, c_lo);                          // (uniform)
-    const char* wlane = wcur + (wave * 1024 + lane * 16);                 // this lane's 16 bytes of step 0 of the chunk being multiplied
-    long w_jump = 0;                                                      // (uniform) bytes from that chunk's image to the image of the chunk behind it
-    auto fetch_w1 = [&](const long off, int slot, const int i) {
+    // Buffer form of the LDS-DMA (buffer_load_dwordx4 ... lds): the image's descriptor in scalar registers, ONE constant lane offset, the
+    // step as a scalar byte offset — no per-lane 64-bit pointer to keep (two registers the step loop does not have) or to add to.
+    const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wpk), (short)0, (int)((long)ntiles * p.nchunks * (NS * WPAIR * 2)), 0x00020000);
+    auto w_chunk = [&](int ntile_, int ch_) { return (unsigned)((ntile_ * p.nchunks + ch_) * (NS * WPAIR * 2)); };      // byte offset of a chunk's 20 steps
+    unsigned w_cur = w_chunk(cur.ntile, c_lo), w_nxt = w_cur;            // (uniform) the chunk being multiplied / the chunk behind it
+    auto fetch_w1 = [&](const unsigned off, int slot, const int i) {
         char* dst = reinterpret_cast<char*>(lds_w) + slot * (WPAIR * 2) + wave * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wlane + (off + i * (NW * 1024))),
-                                         (__attribute__((address_space(3))) void*)(dst + i * (NW * 1024)), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(dst + i * (NW * 1024)), 16, w_voff,
+                                                 (int)(off + i * (NW * 1024)), 0, 0);
     };
 #pragma unroll
-    for (int i = 0; i < RING; ++i) { fetch_w1(i * (WPAIR * 2), i, 0); fetch_w1(i * (WPAIR * 2), i, 1); }      // the ring starts full; pass B of step s refills s's buffer with step s + 4  (NS % RING == 0: slot = step & 3)
+    for (int i = 0; i < RING; ++i) { fetch_w1(w_cur + i * (WPAIR * 2), i, 0); fetch_w1(w_cur + i * (WPAIR * 2), i, 1); }      // the ring starts full; pass B of step s refills s's buffer with step s + 4  (NS % RING == 0: slot = step & 3)
 
     f32x4 va[10][2];                                     // the row's ten voxels: raw -> activated float32, in place
     u32x4 oh[4], ol[4];                                  // one transform term's four records (x-pairs), hi and lo pieces
@@ -297,7 +315,6 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
     };
     // (inline asm with the lo address made on the spot: as C++ stores hipcc keeps both addresses in registers for the whole loop — and, the
     // register file being full, spills them and reloads them at every store site behind a vmcnt(0))
-    const unsigned st_addr = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)lds_in + (unsigned)st_base * 2u;
     auto store_record = [&](const int t, const int xt) {
         if (s_act) {
             unsigned lo_addr;
@@ -363,14 +380,6 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
     // moved accumulator tiles between AGPRs, VGPRs and scratch around the term blocks, and every scratch reload inside the loop is
     // followed by vmcnt(0), which drains the weight DMA and halo requests in flight.
     h8 ah[4], al[4], bh[4], bl[4];
-    // per-lane operand bases.  A step's tap pair = two (dz, dy) taps, the lane half picks one: pairs 0-2 = (dz, 0) | (dz, 1) for dz = 0, 1, 2;
-    // pair 3 = (0, 2) | the pad (the voxels of (1, 2) against zero weights); pair 4 = (1, 2) | (2, 2).  So TWO lane-dependent bases serve
-    // all five (the swizzled slot depends on dy only) and the pair is an immediate: a_pair[0] + dz * DZ, a_pair[1] + {0, DZ}; hi piece (lo: ^ 32)
-    constexpr int DZB = HH * RREC * REC * 2, DYB = RREC * REC * 2;        // bytes to the halo row one z / one y further
-    unsigned a_pair[2];
-    a_pair[0] = a_base + (half ? DYB + sl[1] : sl[0]);
-    a_pair[1] = a_base + 2 * DYB + sl[2] + (half ? DZB : 0);
-    const unsigned wb_hi = w_addr + (unsigned)b_hi * 2u;                   // hi piece (lo: ^ 32)
     // the lo-piece addresses are made where they are used (one v_xor_b32 per step and operand), not kept: registers
     auto lo_of = [](const unsigned a) { unsigned r; asm volatile("v_xor_b32 %0, 32, %1" : "=v"(r) : "v"(a)); return r; };
 #define DM3D_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
@@ -407,7 +416,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
     //   576 .. 623     term 0: unit u = x-pair u >> 2, channel pair u & 3 at 576 + 3 u: the term, hi = f16(x) and x0 - hi, x1 - hi and lo.
     //   624 .. 671     term 1                The steps are term-major, so the image's records of term t are dead once every wave is past
     //   688 .. 735     term 2 (pass 43 on)   the barrier of step 5t + 4: a finished record goes to LDS at the head of the next pass (one or
-    //   736 .. 783     term 3 (kept)         two transient records in registers, not the whole image); only the four t = 3 records wait in
+    //   880 .. 927     term 3 (passes 55-57) two transient records in registers, not the whole image); only the four t = 3 records wait in
     //                                        registers for the barrier of the last step (pass 58).
     f32x4 g_y, g_z;
     float g_x0 = 0.f, g_x1 = 0.f, g_r0 = 0.f;
@@ -505,9 +514,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
             }
             return;
         }
-        if ((G >= 576 && G < 672) || (G >= 688 && G < 784)) {
+        // (term 3 last, right in front of the barrier that frees its place: its four records then live three passes, not twelve, beside the
+        // ten voxels they are made from — the step loop's register peak)
+        if ((G >= 576 && G < 672) || (G >= 688 && G < 736) || (G >= 880 && G < 928)) {
             const int t = G < 624 ? 0 : (G < 672 ? 1 : (G < 736 ? 2 : 3));
-            const int q = G - (t == 0 ? 576 : (t == 1 ? 624 : (t == 2 ? 688 : 736)));
+            const int q = G - (t == 0 ? 576 : (t == 1 ? 624 : (t == 2 ? 688 : 880)));
             const int u = q / 3, st = q % 3, xt = u >> 2, j = u & 3, h = j >> 1, c = 2 * (j & 1);
             if (st == 0) {
                 auto d = [&](const int k, const int e) { return va[2 * xt + k][h][c + e]; };
@@ -527,9 +538,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
 #define DM3D_MFMA(T, PI, NI, A, B) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[T][PI][NI]) : "v"(A[PI]), "v"(B[NI]))
 #define DM3D_WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(n) : "memory")
 
-    // ---- the item loop (persistent form; SKIP: one pass)
-    bool has_next = !SKIP && item + item_step < item_end;
+    // ---- the item loop
+    bool has_next = item + item_step < item_end;
     for (;;) {
+    lane_setup();
     // (requested here, not carried over from the previous item's last step: the epilogue wants the registers)
     {
         const unsigned a_lo0 = lo_of(a_hi(0));
@@ -545,13 +557,13 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
         // the chunk staged during this one: the item's next chunk; in its last chunk the NEXT item's first (the staging state moves on to
         // that item's brick: nothing of this item is staged any more); behind the last item the same chunk again (unconditional like the DMAs)
         int ch_next;
-        if (ch + 1 < c_hi) { ch_next = ch + 1; w_jump = NS * WPAIR * 2; }
+        if (ch + 1 < c_hi) { ch_next = ch + 1; w_nxt = w_cur + NS * WPAIR * 2; }
         else if (has_next) {
             // (decoded here, once per item: the next item's coordinates do not live in registers across the chunk loop)
             const Item n = decode(item + item_step);
-            stage_setup(n); ch_next = n.khalf * cpp; w_jump = w_chunk(n.ntile, ch_next) - w_chunk(cur.ntile, ch);
+            stage_setup(n); ch_next = n.khalf * cpp; w_nxt = w_chunk(n.ntile, ch_next);
         }
-        else { ch_next = ch; w_jump = 0; }
+        else { ch_next = ch; w_nxt = w_cur; }
         // (a generic lambda over integral constants, not `#pragma unroll`: hipcc unrolls a 20-step body of this size only in part, and a step
         // index that is not a constant turns acc[t] into scratch memory)
         static_for<NS>([&](auto S_) {
@@ -605,7 +617,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
                 asm volatile("" ::: "memory");
             }
             __builtin_amdgcn_sched_barrier(0);
-            const long w_src = s + RING < NS ? (long)((s + RING) * (WPAIR * 2)) : w_jump + (s + RING - NS) * (WPAIR * 2);      // step s + 4
+            const unsigned w_src = s + RING < NS ? w_cur + (s + RING) * (WPAIR * 2) : w_nxt + (s + RING - NS) * (WPAIR * 2);      // step s + 4
             fetch_w1(w_src, ws, 0);                  // into the buffer step s just left (an LDS-DMA piece costs ~60 cycles of issue: the second one two gaps on)
             head_stores(3 * s + 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -631,7 +643,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         });
-        wlane += w_jump;
+        w_cur = w_nxt;
     }
 #undef DM3D_MFMA
 #undef DM3D_WAIT_LGKM
@@ -639,14 +651,107 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
 #undef DM3D_DSR
     STAMP(28);
     const Brick br = {cur.b, cur.oz0, cur.oy0, cur.ox0, p.ooz, p.ooy, p.oox, cur.ntile, cur.khalf};
-    if constexpr (!SKIP) {
+    {
         // (this wait must stay the first instruction behind the loop: an asm ds_read returns at once, and its destination — dead to hipcc
         // after the last step — is hipcc's to reuse before the data has landed.  The vector-memory counter is left alone: what is in
         // flight are DMA pieces of the next item's first steps, on their way into ring buffers nobody reads before the next barrier.)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         STAMP(20);
-        // ---- output transform and the shared epilogue, one slice at a time straight from the accumulators (the LDS holds the next item's
-        // image and weights): tile (2g + parity, ni) of slice s = rows 4g .. 4g+3, x = 2 * x-pair + parity.
+        const bool skip = p.s_npairs > 0;
+        if (skip) {
+            // ---- fused 1x1 conv over a second, raw input (ResidualBlock: out = conv2(...) + Conv3D(width, 1)(concat(x, skip)),
+            // conditional_dm3d.py:243-248, 268).  First the output transform, IN PLACE in the accumulator file (y0 over m0, y1 over m1):
+            // the skip products are ordinary ones and accumulate into the transformed tiles.
+#pragma unroll
+            for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const f32x4v m0 = acc[0][pi][ni], m1 = acc[1][pi][ni], m2 = acc[2][pi][ni], m3 = acc[3][pi][ni];
+                    acc[0][pi][ni] = (m0 + m1) + m2;
+                    acc[1][pi][ni] = (m1 - m2) - m3;
+                    asm volatile("" : "+a"(acc[0][pi][ni]), "+a"(acc[1][pi][ni]));
+                }
+            // The tail, register-direct.  K = 32 per MFMA = two 16-channel chunks of the SAME voxel (the lane half picks the chunk, q the
+            // 8-channel piece).  A wave's A operands are ITS OWN brick voxels — nobody else in the workgroup needs them — so they do not
+            // pass through LDS: every lane loads the 8 float32 channels of its voxel for each of the wave's eight tiles (slice s, row
+            // group g, column parity: rows = (y, x-pair)), splits them in registers and multiplies.  The weights come as operand fragments
+            // (dm3d_pack_weights_skip_h3f: 1 KB per (16-column tile, hi | lo), lane-ordered) by plain coalesced loads.  No LDS, no barrier:
+            // the next item's image and weight ring stay where they are, and launches with a skip conv are persistent like the others.
+            // (The first form of this tail staged voxels and weights through LDS behind two barriers per pair: 8 000 cycles per pair for
+            // 1 536 of MFMA, and one work item per workgroup.)
+            // (a Cin-split launch spreads the pairs over its parts as it spreads the main loop's chunks: the skip sum is linear like them)
+            const int p_lo = p.s_npairs * cur.khalf / p.ksplit, np = p.s_npairs * (cur.khalf + 1) / p.ksplit;
+            // (from an opaque copy of the lane number: hipcc otherwise computes the tail's lane constants in front of the item loop and
+            // keeps — spills — them across the step loop, which has no register to spare)
+            int lane_t = lane;
+            asm volatile("" : "+v"(lane_t));
+            const int kq = lane_t >> 4, lhalf = kq >> 1, cq = (kq & 1) * 8, row_t = lane_t & 15;
+            unsigned sv[8];                                     // voxel index of this lane's row in tile t = 4 s + 2 g + parity
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int z = 2 * wave + (t >> 2), y = 4 * ((t >> 1) & 1) + (row_t & 3), x = 2 * (row_t >> 2) + (t & 1);
+                sv[t] = (unsigned)(((cur.b * p.ind + cur.oz0 + z) * p.inh + cur.oy0 + y) * p.inw + cur.ox0 + x);
+            }
+            const char* swf = reinterpret_cast<const char*>(p.swpk_f) + (size_t)cur.ntile * p.s_npairs * 8192 + lane_t * 16;
+            f32x4 ar0[2][8], ar1[2][8];
+            h8 bw[2][8];
+            float lim0[2], lim1[2];
+            auto t_load = [&](auto SET, int pp) {
+                constexpr int S = decltype(SET)::value;
+                const int c0 = (pp * 2 + lhalf) * CK;
+                const float* src;
+                int ldc, cb;
+                if (c0 < p.sc1) { src = p.sx1; ldc = p.sc1; cb = c0; } else { src = p.sx2; ldc = p.sc2; cb = c0 - p.sc1; }
+                const int cpos = cb + cq;
+                const bool real = src != nullptr && cb < ldc && pp < np;      // a pad chunk past the last channel (or pair) multiplies zeros
+                const bool k0 = real && cpos < ldc, k1 = real && cpos + 4 < ldc;
+                lim0[S] = k0 ? 65504.0f : 0.0f;
+                lim1[S] = k1 ? 65504.0f : 0.0f;
+                const char* base = reinterpret_cast<const char*>(real ? src : p.sx1);
+                const unsigned ld4 = (unsigned)(real ? ldc : p.sc1) * 4u, o0 = (unsigned)(k0 ? cpos : 0) * 4u, o1 = (unsigned)(k1 ? cpos + 4 : 0) * 4u;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    ar0[S][t] = *reinterpret_cast<const f32x4*>(base + (sv[t] * ld4 + o0));
+                    ar1[S][t] = *reinterpret_cast<const f32x4*>(base + (sv[t] * ld4 + o1));
+                }
+                const char* ws = swf + (size_t)(pp < p.s_npairs ? pp : p.s_npairs - 1) * 8192;
+#pragma unroll
+                for (int f = 0; f < 8; ++f) bw[S][f] = *reinterpret_cast<const h8*>(ws + f * 1024);
+            };
+#define DM3D_TMFMA(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
+            auto t_step = [&](auto SET) {
+                constexpr int S = decltype(SET)::value;
+                h8 ahi[8], alo[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) split8(ar0[S][t], ar1[S][t], lim0[S], lim1[S], ahi[t], alo[t]);
+                // pass-major: an accumulator tile is touched once per 32 MFMAs; tile t = 4 s + 2 g + parity -> acc[parity][2 s + g][ni]
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) DM3D_TMFMA(acc[t & 1][t >> 1][ni], alo[t], bw[S][2 * ni]);
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) DM3D_TMFMA(acc[t & 1][t >> 1][ni], ahi[t], bw[S][2 * ni + 1]);
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) DM3D_TMFMA(acc[t & 1][t >> 1][ni], ahi[t], bw[S][2 * ni]);
+            };
+#undef DM3D_TMFMA
+            const std::integral_constant<int, 0> S0;
+            const std::integral_constant<int, 1> S1;
+            t_load(S0, p_lo);
+            for (int pp = p_lo; pp < np; pp += 2) {            // whole rounds of two pairs: a step past the last pair multiplies zeros
+                t_load(S1, pp + 1);
+                t_step(S0);
+                t_load(S0, pp + 2);
+                t_step(S1);
+            }
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // (asm MFMAs: hipcc's hazard pass does not know the accumulators were just written)
+        }
+        // ---- the shared epilogue, one slice at a time straight from the accumulators (the LDS holds the next item's image and weights):
+        // tile (2g + parity, ni) of slice s = rows 4g .. 4g+3, x = 2 * x-pair + parity; without a skip conv the output transform happens here.
         static_for<2>([&](auto S_) {
             constexpr int s = decltype(S_)::value;
             __builtin_amdgcn_sched_barrier(0);
@@ -659,14 +764,21 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
                 for (int g = 0; g < 2; ++g)
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni) asm volatile("" : "+a"(acc[t][2 * s + g][ni]));
+            if (skip) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
+                for (int g = 0; g < 2; ++g)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    const f32x4v m0 = acc[0][2 * s + g][ni], m1 = acc[1][2 * s + g][ni], m2 = acc[2][2 * s + g][ni], m3 = acc[3][2 * s + g][ni];
-                    e[2 * g][ni] = (m0 + m1) + m2;
-                    e[2 * g + 1][ni] = (m1 - m2) - m3;
-                }
+                    for (int ni = 0; ni < 4; ++ni) { e[2 * g][ni] = acc[0][2 * s + g][ni]; e[2 * g + 1][ni] = acc[1][2 * s + g][ni]; }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        const f32x4v m0 = acc[0][2 * s + g][ni], m1 = acc[1][2 * s + g][ni], m2 = acc[2][2 * s + g][ni], m3 = acc[3][2 * s + g][ni];
+                        e[2 * g][ni] = (m0 + m1) + m2;
+                        e[2 * g + 1][ni] = (m1 - m2) - m3;
+                    }
+            }
             epilogue<TD, 4>(p, e, br, 2 * wave + s, 1, 2 * (lane >> 4));
         });
         STAMP(29);
@@ -688,164 +800,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
         c_lo = cur.khalf * cpp; c_hi = c_lo + cpp;
         has_next = item + item_step < item_end;
         STAMP(0);
-        continue;
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // the redundant tail fetches / reads (first behind the loop: see above)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    // ---- output transform: tile (2g + parity, ni) of slice s = rows 4g .. 4g+3, x = 2 * xpair + parity
-    const int b = cur.b, oz0 = cur.oz0, oy0 = cur.oy0, ox0 = cur.ox0, ntile = cur.ntile;
-    f32x4v e[2][4][4];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const f32x4v m0 = acc[0][2 * s + g][ni], m1 = acc[1][2 * s + g][ni], m2 = acc[2][2 * s + g][ni], m3 = acc[3][2 * s + g][ni];
-                e[s][2 * g][ni] = (m0 + m1) + m2;
-                e[s][2 * g + 1][ni] = (m1 - m2) - m3;
-            }
-
-    // ---- fused 1x1 conv over a second, raw input (ResidualBlock: out = conv2(...) + Conv3D(width, 1)(x), conditional_dm3d.py:243-248, 268)
-    // on the transformed tiles.  The arithmetic and the weight image (dm3d_pack_weights_skip_h3p) are those of the direct kernel's tail phase
-    // (dm3d_conv_h3v2_parts.h): K = 32 per MFMA = two 16-channel chunks of the SAME voxel, chunk 2i in LDS region 0, chunk 2i + 1 in
-    // region 1 (brick voxels only), the lane half picks the region; here a wave owns two slices and its tile rows are (y, x-pair) of one
-    // column parity.  Per pair of chunks: voxels through registers (the next pair's requests fly beside this pair's 96 MFMAs), weights by
-    // LDS-DMA into one of two buffers, two barriers (the old image is read / the new one is visible).
-    if (p.s_npairs > 0) {
-        constexpr int SROWP = 9, SREC = TD * TH * SROWP;                        // 8 voxels + 1 pad record per brick row; 576 records per region
-        _Float16* lds_sa = smem_w;                                              // [2][SREC][REC]            (72 KB)
-        _Float16* lds_sw = smem_w + 2 * SREC * REC;                             // [2 buffers][2][NT][REC]   (16 KB)
-        const int np = p.s_npairs;
-        int sgv[8], sst[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int it = tid + j * 256, t = it >> 10, iv = (it & 1023) >> 1, pc = it & 1;
-            const int z = iv >> 6, y = (iv >> 3) & 7, x = iv & 7;
-            sgv[j] = ((b * p.ind + oz0 + z) * p.inh + oy0 + y) * p.inw + ox0 + x;
-            const int v = (z * TH + y) * SROWP + x;
-            sst[j] = (t * SREC + v) * REC + ((pc ^ ((x >> 1) & 3)) << 3);
-        }
-        f32x4 sr0[8], sr1[8];
-        bool sk0[8], sk1[8];
-        auto sload = [&](int pp) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int it = tid + j * 256, pc = it & 1;
-                const int c0 = (pp * 2 + (it >> 10)) * CK;
-                const float* src;
-                int ldc, cb;
-                if (c0 < p.sc1) { src = p.sx1; ldc = p.sc1; cb = c0; } else { src = p.sx2; ldc = p.sc2; cb = c0 - p.sc1; }
-                const int cpos = cb + pc * 8;
-                const bool real = src != nullptr && cb < ldc && pp < np;     // a pad chunk past the last channel reads zeros
-                sk0[j] = real && cpos < ldc;
-                sk1[j] = real && cpos + 4 < ldc;
-                const float* qp = (real ? src : p.sx1) + (size_t)sgv[j] * (real ? ldc : p.sc1);
-                sr0[j] = *reinterpret_cast<const f32x4*>(qp + (sk0[j] ? cpos : 0));
-                sr1[j] = *reinterpret_cast<const f32x4*>(qp + (sk1[j] ? cpos + 4 : 0));
-            }
-        };
-        const char* sw_img = reinterpret_cast<const char*>(p.swpk) + (size_t)ntile * p.s_npairs * (2 * NT * REC * 2) + wave * 1024 + lane * 16;
-        auto sdma = [&](int pp, int buf) {
-            const char* src = sw_img + (size_t)(pp < np ? pp : np - 1) * (2 * NT * REC * 2);
-            char* dst = reinterpret_cast<char*>(lds_sw) + buf * (2 * NT * REC * 2) + wave * 1024;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * (NW * 1024)),
-                                                 (__attribute__((address_space(3))) void*)(dst + i * (NW * 1024)), 16, 0, 0);
-        };
-        // fragment addresses: row i of a tile = (y = i & 3, x-pair i >> 2); hi piece at slot q ^ (x-pair & 3) (lo: ^ 2)
-        const unsigned sa_addr = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)lds_sa
-                                 + (unsigned)((((2 * wave) * TH + ay) * SROWP + 2 * (row >> 2) + half * SREC) * (REC * 2) + ((q ^ ((row >> 2) & 3)) << 4));
-        const unsigned sw_addr = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)lds_sw + (unsigned)b_hi * 2u;
-        sdma(0, 0);
-        sload(0);
-        for (int pp = 0; pp < np; ++pp) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0): this pair's voxels and weights have landed
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {                                      // in place: the registers become the two 16-byte pieces
-                h8 hi_, lo_;
-                split8(sr0[j], sr1[j], sk0[j] ? 65504.0f : 0.0f, sk1[j] ? 65504.0f : 0.0f, hi_, lo_);
-                sr0[j] = __builtin_bit_cast(f32x4, hi_);
-                sr1[j] = __builtin_bit_cast(f32x4, lo_);
-            }
-            lds_barrier();                                                     // everyone has left the previous image
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                *reinterpret_cast<f32x4*>(lds_sa + sst[j]) = sr0[j];
-                *reinterpret_cast<f32x4*>(lds_sa + (sst[j] ^ 16)) = sr1[j];
-            }
-            lds_barrier();                                                     // the image and this pair's weights are visible
-            sdma(pp + 1, (pp + 1) & 1);                                        // (past the end: the last pair again, into the buffer nobody reads)
-            sload(pp + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned wa = sw_addr + (unsigned)((pp & 1) * (2 * NT * REC * 2));
-            h8 sbh[4], sbl[4];
-#define DM3D_SDSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-            DM3D_SDSR(sbh[0], wa, 0); DM3D_SDSR(sbh[1], wa, 16 * REC * 2); DM3D_SDSR(sbh[2], wa, 32 * REC * 2); DM3D_SDSR(sbh[3], wa, 48 * REC * 2);
-            {
-                const unsigned wl = wa ^ 32u;
-                DM3D_SDSR(sbl[0], wl, 0); DM3D_SDSR(sbl[1], wl, 16 * REC * 2); DM3D_SDSR(sbl[2], wl, 32 * REC * 2); DM3D_SDSR(sbl[3], wl, 48 * REC * 2);
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int pi = 0; pi < 4; ++pi) {
-                    h8 sah, sal;
-                    const unsigned aa = sa_addr;
-                    switch (s * 4 + pi) {          // slice s, row group pi >> 1, column parity pi & 1
-#define DM3D_SA(k_) case k_: DM3D_SDSR(sah, aa, (((k_) >> 2) * TH + 4 * (((k_) >> 1) & 1)) * SROWP * REC * 2 + ((k_) & 1) * REC * 2); \
-                             DM3D_SDSR(sal, aa ^ 32u, (((k_) >> 2) * TH + 4 * (((k_) >> 1) & 1)) * SROWP * REC * 2 + ((k_) & 1) * REC * 2); break;
-                        DM3D_SA(0) DM3D_SA(1) DM3D_SA(2) DM3D_SA(3) DM3D_SA(4) DM3D_SA(5) DM3D_SA(6) DM3D_SA(7)
-#undef DM3D_SA
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) {
-                        f32x4v& c_ = e[s][pi][ni];
-                        c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(sal, sbh[ni], c_, 0, 0, 0);
-                        c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(sah, sbl[ni], c_, 0, 0, 0);
-                        c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(sah, sbh[ni], c_, 0, 0, 0);
-                    }
-                }
-#undef DM3D_SDSR
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // the tail requests: nothing may land in LDS the staging below reuses
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    }
-
-    // The finished tiles go through LDS (each thread reads back only what it wrote: no barrier): with the outputs and the epilogue's own
-    // operands (64 registers of residual per slice) alive beside the accumulators hipcc spilled registers INSIDE the step loop — and every
-    // scratch reload there waits vmcnt(0), i.e. for the weight DMA and halo requests in flight.
-    f32x4v* lds_e = reinterpret_cast<f32x4v*>(smem_w);                    // [32 tiles][256 threads] x 16 bytes = 128 KB
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int pi = 0; pi < 4; ++pi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) lds_e[((s * 4 + pi) * 4 + ni) * 256 + tid] = e[s][pi][ni];
-    STAMP(20);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (s == 1) STAMP(21);
-        f32x4v e[4][4];
-#pragma unroll
-        for (int pi = 0; pi < 4; ++pi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) e[pi][ni] = lds_e[((s * 4 + pi) * 4 + ni) * 256 + tid];
-        epilogue<TD, 4>(p, e, br, 2 * wave + s, 1, 2 * (lane >> 4));
-    }
-    STAMP(29);
-    break;
     }       // items
 }
 
-template <int MODE, bool SKIP>
+template <int MODE>
 int launch_w(ConvArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)(4 * 2 * 64 * REC + 10 * 10 * 17 * REC) * sizeof(_Float16);      // 32 KB of weights + 106 KB of image
     static_assert(lds <= 160 * 1024, "one workgroup per CU");
@@ -855,7 +814,7 @@ int launch_w(ConvArgs& a, hipStream_t st) {
     DM3D_HIP(hipGetDevice(&dev));
     DM3D_REQUIRE(dev >= 0 && dev < 64, "conv: device ordinal %d", dev);
     if (cus[dev] == 0) {
-        DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3w<MODE, SKIP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3w<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int n = 0;
         DM3D_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
         cus[dev] = n > 0 ? n : 256;
@@ -863,17 +822,17 @@ int launch_w(ConvArgs& a, hipStream_t st) {
     H3v2Launch L;
     if (int rc = dm3d_h3v2_pre_launch(a, 8, L, st, dm3d_conv_h3w_ksplit(a))) return rc;
     L.k.wpk = a.wpk_wino;
-    // work items = bricks x column tiles x Cin parts.  With a fused skip conv every workgroup takes one (its tail phase overlays the
-    // images); otherwise one persistent workgroup per CU walks its share of the list (DM3D_CONV_WINO_PERSIST=0: one item per workgroup)
+    // work items = bricks x column tiles x Cin parts; one persistent workgroup per CU walks its share of the list
+    // (DM3D_CONV_WINO_PERSIST=0: one item per workgroup)
     const long items = (long)a.batch * a.bd * a.bh * a.bw * (a.coutpad / 64) * a.ksplit;
     static const bool persist = [] { const char* e = getenv("DM3D_CONV_WINO_PERSIST"); return !(e && e[0] == '0'); }();
     long g = items;
-    if (!SKIP && persist && items > cus[dev]) g = (items % 8 == 0) ? (cus[dev] / 8 * 8) : cus[dev];
-    if (!SKIP && persist) {                  // test knob (read per call): at most this many workgroups, so that small shapes walk item lists too
+    if (persist && items > cus[dev]) g = (items % 8 == 0) ? (cus[dev] / 8 * 8) : cus[dev];
+    if (persist) {                           // test knob (read per call): at most this many workgroups, so that small shapes walk item lists too
         const char* cap = getenv("DM3D_CONV_WINO_GRID");
         if (cap && atol(cap) > 0 && atol(cap) < g) g = atol(cap);
     }
-    hipLaunchKernelGGL((conv3d_igemm_h3w<MODE, SKIP>), dim3((unsigned)g), dim3(256), lds, st, L.k);
+    hipLaunchKernelGGL((conv3d_igemm_h3w<MODE>), dim3((unsigned)g), dim3(256), lds, st, L.k);
     if (int rc = dm3d_launch_check("conv3d_igemm_h3w")) return rc;
     return dm3d_h3v2_post_launch(a, L, st);
 }
@@ -888,11 +847,11 @@ int launch_w(ConvArgs& a, hipStream_t st) {
 // call): never.
 bool dm3d_conv_h3w_serves(const ConvArgs& a, int which) {
     if (!a.wpk_wino || which != DM3D_CONV_K3S1 || a.parity || a.cout <= 32) return false;
-    // (a fused skip conv: its tail phase here keeps one pair of chunks in flight, the direct kernel's two — behind a main loop of only four
-    // chunks the direct kernel wins from three pairs on: profiles/r03_list_convs.log)
-    {
-        static const int skipmax = [] { const char* e = getenv("DM3D_CONV_WINO_SKIPMAX"); return e ? atoi(e) : 2; }();      // (A/B knob)
-        if (a.s_npairs > skipmax && a.nchunks < 8) return false;
+    // (a fused skip conv needs its weights as operand fragments: dm3d_conv_desc.skip_wpk_frag; raw skip inputs below 4 GB: 32-bit lane offsets)
+    if (a.s_npairs > 0) {
+        if (!a.swpk_f) return false;
+        const long long svox = (long long)a.batch * a.ind * a.inh * a.inw;
+        if (svox * (a.sc1 > a.sc2 ? a.sc1 : a.sc2) * 4 >= (1ll << 32)) return false;
     }
     if (a.od % 8 != 0 || a.oh % 8 != 0 || a.ow % 8 != 0 || a.padz != 1 || a.pady != 1 || a.padx != 1) return false;
     const char* e = getenv("DM3D_CONV_WINO");
@@ -912,10 +871,11 @@ bool dm3d_conv_h3w_serves(const ConvArgs& a, int which) {
 // Cin split of the Winograd form: two workgroups per brick and column tile where one would leave at least half of the CUs without work
 // (the 8^3 level at B = 32: 32 bricks x 4 column tiles), each contracting half of the chunks (at least eight), their partial sums meeting
 // in the shared epilogue (atomic add into the zeroed output when the epilogue is linear, else scratch + reduce launch: dm3d_h3v2_pre_launch).
-// The fused output forms (hand-off format, post-activation) live in the 16-byte epilogue and are not split.  DM3D_CONV_WINO_SPLIT=0: never.
+// The fused output forms (hand-off format, post-activation) live in the 16-byte epilogue and are not split; a fused skip conv's pairs are
+// spread over the two parts like the chunks.  DM3D_CONV_WINO_SPLIT=0: never.
 int dm3d_conv_h3w_ksplit(const ConvArgs& a) {
     static const bool off = [] { const char* e = getenv("DM3D_CONV_WINO_SPLIT"); return e && e[0] == '0'; }();
-    if (off || a.out_h2 || a.post_scale || a.s_npairs > 0 || a.nchunks % 2 != 0 || a.nchunks < 16) return 1;
+    if (off || a.out_h2 || a.post_scale || a.nchunks % 2 != 0 || a.nchunks < 16) return 1;
     if (a.relu || a.prelu || a.relu_out || a.res == a.out || a.x1 == a.out || a.x2 == a.out) return 1;      // (a linear epilogue: the halves may meet by atomic add)
     const long wgs = (long)a.batch * (a.od / 8) * (a.oh / 8) * (a.ow / 8) * (a.coutpad / 64);
     return wgs <= 128 ? 2 : 1;
@@ -923,10 +883,6 @@ int dm3d_conv_h3w_ksplit(const ConvArgs& a) {
 
 int dm3d_conv_launch_h3w(ConvArgs& a, int which, hipStream_t st) {
     (void)which;
-    if (a.s_npairs > 0) {
-        if (a.x_h2) return launch_w<2, true>(a, st);
-        return a.pscale ? launch_w<1, true>(a, st) : launch_w<0, true>(a, st);
-    }
-    if (a.x_h2) return launch_w<2, false>(a, st);
-    return a.pscale ? launch_w<1, false>(a, st) : launch_w<0, false>(a, st);
+    if (a.x_h2) return launch_w<2>(a, st);
+    return a.pscale ? launch_w<1>(a, st) : launch_w<0>(a, st);
 }

@@ -57,6 +57,15 @@ def pack_weights_skip_h3p(kernel: torch.Tensor, w_exp: int) -> torch.Tensor:
     return out
 
 
+def pack_weights_skip_h3f(kernel: torch.Tensor, w_exp: int) -> torch.Tensor:
+    """The same 1x1 kernel as MFMA operand fragments: conv3d(skip=(x1, x2, image, fragments)) lets the Winograd-x form serve the launch."""
+    _f32c(kernel, "kernel")
+    cin, cout = kernel.shape[-2], kernel.shape[-1]
+    out = torch.empty(lib().dm3d_packed_weight_skip_h3p_bytes(cin, cout) // 2, dtype=torch.float16, device=kernel.device)
+    check(lib().dm3d_pack_weights_skip_h3f(kernel.data_ptr(), cin, cout, w_exp, out.data_ptr(), _st()), "pack_weights_skip_h3f")
+    return out
+
+
 def pack_weights_h3(kernel: torch.Tensor, in_scale: Optional[torch.Tensor] = None, stride: int = 1, w_exp: Optional[int] = None):
     """Keras kernel -> (float16 hi/lo image for the H3 conv kernels, w_exp).  max|w|*2^w_exp lands in [2^13, 2^14).
     ``stride`` is the stride of the conv that will read the image: it selects the layout (dm3d_conv_weight_layout)."""
@@ -134,7 +143,7 @@ def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False
            vec=None, vec_idx=None, relu=False, res=None, precision=_lib.PREC_F32, w_exp=0, prelu_alpha=None,
            relu_out=False, transpose=False, skip=None, x1_h2_channels=None, out_h2=False, post=None, wpk_wino=None) -> torch.Tensor:
     """Conv3D(padding="same") on NDHWC with the fused prologue / concat / upsample / epilogue of dm3d_conv3d_ndhwc.
-    ``skip=(sx1, sx2_or_None, skip_wpk)``: also accumulate Conv3D(cout, 1) of the raw concat(sx1, sx2) (H3, k3, stride 1).
+    ``skip=(sx1, sx2_or_None, skip_wpk[, skip_wpk_frag])``: also accumulate Conv3D(cout, 1) of the raw concat(sx1, sx2) (H3, k3, stride 1).
     ``post=(scale, shift)``: out = silu(out*scale[c] + shift[c]) at the very end; ``out_h2``: store DM3D_FMT_H2;
     ``x1_h2_channels=c``: x1 is a DM3D_FMT_H2 buffer of c logical channels (as written by ``out_h2``)."""
     _f32c(x1, "x1")
@@ -176,7 +185,9 @@ def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False
     if wpk_wino is not None:
         d.wpk_wino = wpk_wino.data_ptr()
     if skip is not None:
-        sx1, sx2, swpk = skip
+        sx1, sx2, swpk = skip[:3]
+        if len(skip) > 3 and skip[3] is not None:
+            d.skip_wpk_frag = skip[3].data_ptr()
         _f32c(sx1, "skip x1")
         d.skip_x1, d.skip_x2, d.skip_c1, d.skip_c2, d.skip_wpk = sx1.data_ptr(), _p(sx2), sx1.shape[-1], (sx2.shape[-1] if sx2 is not None else 0), swpk.data_ptr()
     need = lib().dm3d_conv_scratch_bytes(C.byref(d))

@@ -215,6 +215,10 @@ class UNet:
                     img = torch.empty(lib().dm3d_packed_weight_skip_h3p_bytes(cin_s, cout_s) // 2, dtype=torch.float16, device=self.device)
                     check(lib().dm3d_pack_weights_skip_h3p(ks.data_ptr(), cin_s, cout_s, e, img.data_ptr(), _stream()), "pack_weights_skip_h3p")
                     P[f"{n}.skip_fused"] = img
+                    if self.wino:           # the same kernel as operand fragments: the Winograd-x form's register-direct tail (dm3d.h, skip_wpk_frag)
+                        frag = torch.empty_like(img)
+                        check(lib().dm3d_pack_weights_skip_h3f(ks.data_ptr(), cin_s, cout_s, e, frag.data_ptr(), _stream()), "pack_weights_skip_h3f")
+                        P[f"{n}.skip_frag"] = frag
                 else:
                     if f"{n}.skip.kernel" in s:
                         P[f"{n}.skip"] = self._pack(s[f"{n}.skip.kernel"], s[f"{n}.skip.bias"], conv=True)
@@ -569,8 +573,10 @@ class Plan:
             d.range_flag, d.range_limit = self.range_flag.data_ptr(), self.range_limit
         skip_flops = 0.0
         if skip is not None:
-            sx1, sx2, sc1, sc2, simg = skip
+            sx1, sx2, sc1, sc2, simg, sfrag = skip
             d.skip_x1, d.skip_x2, d.skip_c1, d.skip_c2, d.skip_wpk = _ptr(sx1), _ptr(sx2), sc1, sc2, simg.data_ptr()
+            if sfrag is not None:
+                d.skip_wpk_frag = sfrag.data_ptr()
             skip_flops = 2.0 * (sc1 + sc2) * w.cout * self.B * edge_in ** 3
         self._keep.append(d)
         up = 2 if upsample else 1
@@ -682,7 +688,7 @@ class Plan:
         P, B, n, w = self.net.P, self.B, blk.name, blk.cout
         skip = None
         if f"{n}.skip_fused" in P:
-            res, skip = None, (x1, x2, c1, c2, P[f"{n}.skip_fused"])
+            res, skip = None, (x1, x2, c1, c2, P[f"{n}.skip_fused"], P.get(f"{n}.skip_frag"))
         elif f"{n}.skip" in P:
             res = self._buf(B, edge, edge, edge, w)
             self._conv(P[f"{n}.skip"], x1, res, edge, x2=x2, c1=c1, c2=c2)

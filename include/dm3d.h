@@ -24,7 +24,7 @@ extern "C" {
 #define DM3D_VERSION 109          /* major*100 + minor; the descriptor structs grew in 101 (w_layout), 102 (scratch), 103 (skip_*),
                                      104 (dm3d_attention), 105 (x1_fmt / out_fmt / post_*), 106 (ddpm seed_dev; conv/gemm range_flag; the
                                      training entries), 107 (conv wpk_f8: a float8 cross-term form, removed again in 109), 108 (conv wpk_wino: the Winograd-x form), 109 (wpk_f8 and
-                                     dm3d_pack_weights_h3f8 are gone; the Winograd-x image pairs its taps differently; dm3d_mlp_fused): a host built against an older header must be rebuilt */
+                                     dm3d_pack_weights_h3f8 are gone; the Winograd-x image pairs its taps differently; dm3d_mlp_fused; conv skip_wpk_frag): a host built against an older header must be rebuilt */
 
 #define DM3D_OK            0
 #define DM3D_EINVAL       -1      /* bad argument (shape, alignment, null pointer) */
@@ -114,6 +114,9 @@ int32_t dm3d_conv_weight_layout(int32_t ksize, int32_t stride, int32_t upsample,
 /* image of a 1x1 kernel [cin, cout] for dm3d_conv_desc.skip_wpk (two 16-channel chunks per MFMA k-step) */
 int64_t dm3d_packed_weight_skip_h3p_bytes(int32_t cin, int32_t cout);
 int     dm3d_pack_weights_skip_h3p(const float* keras_kernel, int32_t cin, int32_t cout, int32_t w_exp, void* packed, void* stream);
+/* the same kernel as MFMA operand fragments (same byte size): [cout tile of 64][pair of 16-channel chunks][16-column tile][hi | lo][lane][16 B],
+ * for dm3d_conv_desc.skip_wpk_frag — the Winograd-x form reads its skip weights with plain coalesced loads, without LDS */
+int     dm3d_pack_weights_skip_h3f(const float* keras_kernel, int32_t cin, int32_t cout, int32_t w_exp, void* packed, void* stream);
 
 /* ---- Conv3D(padding="same") as implicit GEMM on MFMA ---------------------------------------------------------
  * Replaces layers.Conv3D for k=3/s=1 (:257-259, :348-353, :412-414), k=3/s=2 (DownSample :274-285, TF SAME pad 0
@@ -194,6 +197,10 @@ typedef struct dm3d_conv_desc {
        (dm3d_conv_tile_form() == 10); otherwise wpk serves the launch as before.  The transformed inputs are up to 2 max|x|: producers of
        such a conv must keep |x| <= 32752 (pass range_limit <= 32752 to them).  NULL: never. */
     const void* wpk_wino;
+    /* Optional second image of the fused skip conv's kernel (dm3d_pack_weights_skip_h3f, THIS conv's w_exp), beside skip_wpk: with it the
+       Winograd-x form also serves launches that carry a skip conv — as a register-direct tail between an item's chunk loop and its
+       epilogue (no LDS: such launches are persistent like the others); without it they stay on the direct kernel.  NULL: never. */
+    const void* skip_wpk_frag;
 } dm3d_conv_desc;
 
 int     dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream);

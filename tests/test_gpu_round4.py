@@ -143,6 +143,73 @@ def test_persistent_winograd_hand_off_lists(dev, monkeypatch):
     assert _rel(outs[1], yr) < 2e-5
 
 
+SKIPL = [("8^3 64->64 + k1(32), 4 items on 2 workgroups", 4, 8, 64, 32, 0, 64, 2), ("16^3 128->128 + k1(64+32): 16 items on 8 workgroups", 1, 16, 128, 64, 32, 128, 8),
+         ("8^3 32->96 + k1(40), ragged: 6 items on 4 workgroups", 3, 8, 32, 40, 0, 96, 4), ("16^3 64->64 + k1(192): six pairs, 8 items on 4 workgroups", 1, 16, 64, 128, 64, 64, 4)]
+
+
+@pytest.mark.parametrize("case", SKIPL, ids=[c[0] for c in SKIPL])
+def test_persistent_winograd_skip_tail_lists(dev, monkeypatch, case):
+    """conv2(silu(bn(h))) + Conv3D(width, 1)(concat(x, skip)) (conditional_dm3d.py:243-248, 268) with the 1x1 conv as the Winograd kernel's
+    register-direct tail: the skip products accumulate into the transformed tiles between an item's chunk loop and its epilogue, without LDS —
+    so the launch walks item lists like the others.  Odd pair counts, ragged channel ends, a concat boundary inside a pair."""
+    from dm3d_amd import ops, _lib
+    name, B, e, cm, s1, s2, cout, grid = case
+    monkeypatch.setenv("DM3D_CONV_WIDE_WGS", "1")
+    monkeypatch.setenv("DM3D_CONV_WINO_MINCHUNKS", "1")
+    torch.manual_seed(7)
+    h = torch.randn(B, e, e, e, cm, device=dev)
+    x1 = torch.randn(B, e, e, e, s1, device=dev)
+    x2 = torch.randn(B, e, e, e, s2, device=dev) if s2 else None
+    k = torch.randn(3, 3, 3, cm, cout, device=dev) * 0.05
+    ks = torch.randn(1, 1, 1, s1 + s2, cout, device=dev) * 0.2
+    w_exp = ops.h3_weight_exponent(k.cpu(), ks.cpu())
+    wpk, _ = ops.pack_weights_h3(k, w_exp=w_exp)
+    wino = ops.pack_weights_h3w(k, w_exp)
+    swpk, sfrag = ops.pack_weights_skip_h3p(ks, w_exp), ops.pack_weights_skip_h3f(ks, w_exp)
+    bias = torch.randn(cout, device=dev)
+    ps = (torch.rand(cm, device=dev) + 0.5, torch.randn(cm, device=dev) * 0.1)
+    r = torch.randn(B, e, e, e, cout, device=dev)
+    kw = dict(bias=bias, pro_scale=ps[0], pro_shift=ps[1], res=r, precision=_lib.PREC_H3, w_exp=w_exp)
+    y_direct = ops.conv3d(h, wpk, cout, 3, skip=(x1, x2, swpk), **kw)
+    y_one = ops.conv3d(h, wpk, cout, 3, wpk_wino=wino, skip=(x1, x2, swpk, sfrag), **kw)
+    monkeypatch.setenv("DM3D_CONV_WINO_GRID", str(grid))
+    y_list = ops.conv3d(h, wpk, cout, 3, wpk_wino=wino, skip=(x1, x2, swpk, sfrag), **kw)
+    torch.cuda.synchronize()
+    xs = torch.cat([x1, x2], -1) if s2 else x1
+    yr = _ref_conv(h, k, bias, ps, r) + torch.einsum("bdhwc,co->bdhwo", xs.double(), ks.double()[0, 0, 0])
+    assert not torch.equal(y_one, y_direct), "the Winograd form did not run"
+    assert torch.equal(y_list, y_one)
+    assert _rel(y_list, yr) < 2e-5 and _rel(y_direct, yr) < 2e-5
+
+
+def test_winograd_cin_split_with_a_skip_tail(dev, monkeypatch):
+    """The 8^3-level conv2 + skip launches (256 -> 256 + k1(384)): two workgroups per brick and column tile, each contracting half of the chunks
+    AND half of the skip conv's pairs (an odd number of pairs here: 12 + 1 ragged), the halves meeting by atomic add."""
+    from dm3d_amd import ops, _lib
+    for v in ("DM3D_CONV_WINO_MINCHUNKS", "DM3D_CONV_WINO", "DM3D_CONV_WINO_SPLIT"):
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.setenv("DM3D_CONV_WIDE_WGS", "1")
+    monkeypatch.setenv("DM3D_CONV_WINO_GRID", "24")
+    torch.manual_seed(9)
+    B, e, cm, s1, s2, cout = 4, 8, 256, 256, 136, 256
+    h = torch.randn(B, e, e, e, cm, device=dev)
+    x1, x2 = torch.randn(B, e, e, e, s1, device=dev), torch.randn(B, e, e, e, s2, device=dev)
+    k = torch.randn(3, 3, 3, cm, cout, device=dev) * 0.05
+    ks = torch.randn(1, 1, 1, s1 + s2, cout, device=dev) * 0.1
+    w_exp = ops.h3_weight_exponent(k.cpu(), ks.cpu())
+    wpk, _ = ops.pack_weights_h3(k, w_exp=w_exp)
+    wino = ops.pack_weights_h3w(k, w_exp)
+    swpk, sfrag = ops.pack_weights_skip_h3p(ks, w_exp), ops.pack_weights_skip_h3f(ks, w_exp)
+    ps = (torch.rand(cm, device=dev) + 0.5, torch.randn(cm, device=dev) * 0.1)
+    kw = dict(bias=torch.randn(cout, device=dev), pro_scale=ps[0], pro_shift=ps[1], precision=_lib.PREC_H3, w_exp=w_exp)
+    y_direct = ops.conv3d(h, wpk, cout, 3, skip=(x1, x2, swpk), **kw)
+    y = ops.conv3d(h, wpk, cout, 3, wpk_wino=wino, skip=(x1, x2, swpk, sfrag), **kw)
+    torch.cuda.synchronize()
+    yr = _ref_conv(h, k, kw["bias"], ps) + torch.einsum("bdhwc,co->bdhwo", torch.cat([x1, x2], -1).double(), ks.double()[0, 0, 0])
+    assert not torch.equal(y, y_direct), "the Winograd form did not run"
+    assert _rel(y, yr) < 2e-5 and _rel(y_direct, yr) < 2e-5
+
+
 REAL = [("32^3 192->64, B=8 (two items per workgroup)", 8, 32, 128, 64, 64, 0), ("32^3 64->64 + residual, B=4 (one item per CU)", 4, 32, 64, 0, 64, 1),
         ("16^3 384->128, B=32 (four items per workgroup)", 32, 16, 256, 128, 128, 0)]
 

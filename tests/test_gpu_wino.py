@@ -109,7 +109,7 @@ SKIP_CASES = [("8^3 64->64 + k1(32)", 2, 8, 64, 32, 0, 64), ("16^3 128->128 + k1
 @pytest.mark.parametrize("case", SKIP_CASES, ids=[c[0] for c in SKIP_CASES])
 def test_winograd_fused_skip_conv(dev, small_grids, case):
     """ResidualBlock tail in one launch: conv_k3(silu(bn(h))) + bias + Conv3D(width, 1)(concat(x, skip)) (conditional_dm3d.py:243-248, 268)
-    with the 1x1 conv as the tail phase of the Winograd kernel, on the transformed tiles."""
+    with the 1x1 conv as the register-direct tail of the Winograd kernel (dm3d_conv_desc.skip_wpk_frag), on the transformed tiles."""
     from dm3d_amd import ops, _lib
     name, B, e, cm, s1, s2, cout = case
     torch.manual_seed(7)
@@ -121,12 +121,13 @@ def test_winograd_fused_skip_conv(dev, small_grids, case):
     w_exp = ops.h3_weight_exponent(k.cpu(), ks.cpu())
     wpk, _ = ops.pack_weights_h3(k, w_exp=w_exp)
     wino = ops.pack_weights_h3w(k, w_exp)
-    swpk = ops.pack_weights_skip_h3p(ks, w_exp)
+    swpk, sfrag = ops.pack_weights_skip_h3p(ks, w_exp), ops.pack_weights_skip_h3f(ks, w_exp)
     bias = torch.randn(cout, device=dev)
     ps = (torch.rand(cm, device=dev) + 0.5, torch.randn(cm, device=dev) * 0.1)
-    kw = dict(bias=bias, pro_scale=ps[0], pro_shift=ps[1], precision=_lib.PREC_H3, w_exp=w_exp, skip=(x1, x2, swpk))
-    y_direct = ops.conv3d(h, wpk, cout, 3, **kw)
-    y_wino = ops.conv3d(h, wpk, cout, 3, wpk_wino=wino, **kw)
+    kw = dict(bias=bias, pro_scale=ps[0], pro_shift=ps[1], precision=_lib.PREC_H3, w_exp=w_exp)
+    y_direct = ops.conv3d(h, wpk, cout, 3, skip=(x1, x2, swpk), **kw)
+    assert torch.equal(y_direct, ops.conv3d(h, wpk, cout, 3, wpk_wino=wino, skip=(x1, x2, swpk), **kw))      # without the fragment image: the direct kernel
+    y_wino = ops.conv3d(h, wpk, cout, 3, wpk_wino=wino, skip=(x1, x2, swpk, sfrag), **kw)
     xs = torch.cat([x1, x2], -1) if s2 else x1
     yr = _ref_conv(h, k, bias, ps) + torch.einsum("bdhwc,co->bdhwo", xs.double(), ks.double()[0, 0, 0])
     assert not torch.equal(y_wino, y_direct), "the Winograd form did not run"
@@ -160,8 +161,8 @@ def test_winograd_cin_split_on_a_small_grid(dev, monkeypatch):
 
 
 def test_winograd_launch_policy(dev, monkeypatch):
-    """dm3d_conv_tile_form() names the Winograd form (10) only with the second image, whole 8x8x8 bricks, Cin >= 32, a large grid (or its Cin split) and at most a short
-    fused skip conv; DM3D_CONV_WINO=0 switches it off per call."""
+    """dm3d_conv_tile_form() names the Winograd form (10) only with the second image, whole 8x8x8 bricks, Cin >= 32, a large grid (or its Cin split) and, behind a
+    fused skip conv, that conv's fragment image; DM3D_CONV_WINO=0 switches it off per call."""
     from dm3d_amd import _lib
     from dm3d_amd._lib import ConvDesc, lib
     for v in ("DM3D_CONV_WIDE_WGS", "DM3D_CONV_WINO_MINCHUNKS", "DM3D_CONV_WINO", "DM3D_CONV_V3_TD", "DM3D_CONV_WINO_SPLIT"):
@@ -178,6 +179,8 @@ def test_winograd_launch_policy(dev, monkeypatch):
             d.wpk_wino = buf.data_ptr()
         if skip:
             d.skip_wpk, d.skip_x1, d.skip_c1 = buf.data_ptr(), buf.data_ptr(), skip_c
+            if skip != "no fragments":
+                d.skip_wpk_frag = buf.data_ptr()
         return lib().dm3d_conv_tile_form(C.byref(d))
 
     assert form() == 10
@@ -190,8 +193,9 @@ def test_winograd_launch_policy(dev, monkeypatch):
     assert form(e=8, c1=128, cout=256) != 10     # too few chunks to split
     assert form(ed=36) != 10                     # not whole 8-slice bricks
     assert form(cout=32) != 10
-    assert form(skip=True) == 10                 # a fused skip conv of two pairs of chunks behind eight chunks of main loop
-    assert form(c1=64, skip=True, skip_c=192) == 4 and form(c1=64, skip=True, skip_c=32) == 10      # four chunks of main loop: short skip convs only
+    assert form(skip=True) == 10                 # a fused skip conv: its tail is register-direct, the launch persistent like the others
+    assert form(c1=64, skip=True, skip_c=192) == 10 and form(c1=64, skip=True, skip_c=32) == 10
+    assert form(skip="no fragments") == 4        # ... given the skip weights as operand fragments (skip_wpk_frag); else the direct kernel
     monkeypatch.setenv("DM3D_CONV_WINO", "0")
     assert form() == 8
 

@@ -73,12 +73,12 @@ for name, B, e, cm, s1, s2, cout in [("skip 8^3 64->64 + k1(32)", 2, 8, 64, 32, 
     w_exp = ops.h3_weight_exponent(k.cpu(), ks.cpu())
     wpk, _ = ops.pack_weights_h3(k, w_exp=w_exp)
     wino = ops.pack_weights_h3w(k, w_exp)
-    swpk = ops.pack_weights_skip_h3p(ks, w_exp)
+    swpk, sfrag = ops.pack_weights_skip_h3p(ks, w_exp), ops.pack_weights_skip_h3f(ks, w_exp)
     bias = torch.randn(cout, device=dev)
     ps = (torch.rand(cm, device=dev) + 0.5, torch.randn(cm, device=dev) * 0.1)
-    kw = dict(bias=bias, pro_scale=ps[0], pro_shift=ps[1], precision=_lib.PREC_H3, w_exp=w_exp, skip=(x1, x2, swpk))
-    y0 = ops.conv3d(h, wpk, cout, 3, **kw)
-    y1 = ops.conv3d(h, wpk, cout, 3, wpk_wino=wino, **kw)
+    kw = dict(bias=bias, pro_scale=ps[0], pro_shift=ps[1], precision=_lib.PREC_H3, w_exp=w_exp)
+    y0 = ops.conv3d(h, wpk, cout, 3, skip=(x1, x2, swpk), **kw)
+    y1 = ops.conv3d(h, wpk, cout, 3, wpk_wino=wino, skip=(x1, x2, swpk, sfrag), **kw)
     xs = torch.cat([x1, x2], -1) if s2 else x1
     yr = ref_conv(h, k, bias, ps) + torch.einsum("bdhwc,co->bdhwo", xs.double(), ks.double()[0, 0, 0])
     e0, e1 = rel(y0, yr), rel(y1, yr)
