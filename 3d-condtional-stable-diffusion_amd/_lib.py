@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
         ("skip_x1", _f32p), ("skip_x2", _f32p), ("skip_c1", C.c_int32), ("skip_c2", C.c_int32), ("skip_wpk", C.c_void_p),
         ("x1_fmt", C.c_int32), ("out_fmt", C.c_int32), ("post_scale", _f32p), ("post_shift", _f32p),
         ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64),
-        ("range_flag", C.c_void_p), ("range_limit", C.c_float), ("wpk_wino", C.c_void_p), ("skip_wpk_frag", C.c_void_p),
+        ("range_flag", C.c_void_p), ("range_limit", C.c_float), ("wpk_wino", C.c_void_p), ("skip_wpk_frag", C.c_void_p), ("gn_stats", C.c_void_p),
     ]
 
 
@@ -133,6 +133,10 @@ SIGNATURES = {
     "dm3d_groupnorm_stats": (C.c_int, [_f32p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dm3d_groupnorm_finalize": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_float, _f32p, _f32p, _f32p,
                                            _f32p, C.c_void_p]),
+    "dm3d_groupnorm_finalize2": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_float, _f32p, _f32p,
+                                          _f32p, _f32p, C.c_void_p]),
+    "dm3d_groupnorm_partials": (C.c_int, [_f32p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "dm3d_groupnorm_partials_bytes": (C.c_int64, [C.c_int32, C.c_int64, C.c_int32]),
     "dm3d_affine_act_batched": (C.c_int, [_f32p, _f32p, C.c_int32, C.c_int64, C.c_int32, _f32p, _f32p, C.c_int32, C.c_void_p]),
     "dm3d_softmax_rows": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]),
     "dm3d_affine_act": (C.c_int, [_f32p, _f32p, C.c_int64, C.c_int32, _f32p, _f32p, C.c_int32, C.c_void_p]),

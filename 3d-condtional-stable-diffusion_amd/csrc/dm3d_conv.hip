@@ -324,10 +324,21 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
                                : (d->ksize == 1 ? DM3D_CONV_K1 : (d->ksize == 4 ? DM3D_CONV_K4S2 : (d->stride == 2 ? DM3D_CONV_K3S2 : DM3D_CONV_K3S1)));
     if (par_mode) a.w_parity_stride = d->precision == DM3D_PREC_H3
         ? dm3d_packed_weight_h3_bytes(8, cin, d->cout) / 2 : dm3d_packed_weight_elems(8, cin, d->cout);
-    if (d->precision != DM3D_PREC_H3) return dm3d_conv_launch_f32(a, which, st);
+    // Fused GroupNormalization statistics of the output (gn_stats): the 16x16x32 kernels' full-brick epilogue accumulates them; behind every
+    // other kernel or form the stand-alone statistics kernel reads the finished output once (same buffer, same result up to summation order).
+    if (d->gn_stats) {
+        DM3D_REQUIRE(d->out_fmt == DM3D_FMT_F32 && d->cout % 4 == 0 && dm3d_aligned16(d->gn_stats),
+                     "conv: gn_stats needs a float32 output, cout %% 4 == 0 and a 16-byte aligned buffer");
+        a.gn_stats = d->gn_stats;
+    }
+    auto stats_behind = [&](int rc) {
+        if (rc != DM3D_OK || !a.gn_stats) return rc;
+        return dm3d_groupnorm_partials(a.out, a.batch, (int64_t)a.fd * a.fh * a.fw, a.cout, a.gn_stats, stream);
+    };
+    if (d->precision != DM3D_PREC_H3) return stats_behind(dm3d_conv_launch_f32(a, which, st));
     const int layout = dm3d_conv_weight_layout(d->ksize, d->stride, d->upsample, d->transpose, d->cout);
     DM3D_REQUIRE(d->w_layout == layout, "conv: w_layout %d but this geometry reads layout %d (dm3d_conv_weight_layout)", d->w_layout, layout);
-    if (layout != DM3D_WL_PAIR) return dm3d_conv_launch_h3(a, which, st);
+    if (layout != DM3D_WL_PAIR) return stats_behind(dm3d_conv_launch_h3(a, which, st));
     // same arguments and epilogue: the Winograd-x form (dm3d_conv_h3w.hip, its own weight image) where it is eligible, else the
     // free-running direct form (dm3d_conv_h3v3.hip)
     if (dm3d_conv_h3w_serves(a, which)) return dm3d_conv_launch_h3w(a, which, st);

@@ -35,6 +35,7 @@ struct ConvArgs {
     const void* swpk_f;                      // optional: the skip weights as operand fragments (dm3d_pack_weights_skip_h3f): the Winograd-x form's tail   // s_npairs = round_up(sc1+sc2, 32) / 32
     const void* wpk_wino;                    // optional weight image of the Winograd-x form (dm3d_conv_h3w.hip)
     int* range_flag; float range_limit;      // H3 range guard (include/dm3d.h): *range_flag = 1 if any |output| > range_limit
+    float* gn_stats;                         // fused GroupNormalization statistics of the OUTPUT (include/dm3d.h): [batch][slots][cout][2] partial (sum, sum of squares)
     int epi_vec4;                            // h3v2: every epilogue operand is 16-byte aligned (cout, vec_ld % 4 == 0): 16-byte epilogue accesses
 };
 
@@ -44,9 +45,10 @@ enum { DM3D_CONV_K3S1 = 0, DM3D_CONV_K3S2 = 1, DM3D_CONV_K1 = 2, DM3D_CONV_UP = 
 int dm3d_conv_launch_f32(ConvArgs& a, int which, hipStream_t st);
 int dm3d_conv_launch_h3(ConvArgs& a, int which, hipStream_t st);
 int dm3d_conv_launch_h3v3(ConvArgs& a, int which, hipStream_t st);     // DM3D_WL_PAIR weights; which in {K3S1, UP}: the free-running form (dm3d_conv_h3v3.hip)
-struct H3v2Launch { ConvArgs k; bool reduce; size_t out_elems; };       // what pre_launch decided: the kernel's own arguments, a reduce launch behind it
+struct H3v2Launch { ConvArgs k; bool reduce; size_t out_elems; bool stats_after; };       // what pre_launch decided: the kernel's own arguments, a reduce launch behind it
 int dm3d_h3v2_pre_launch(ConvArgs& a, int td, H3v2Launch& L, hipStream_t st, int force_ksplit = 0);    // force_ksplit > 0: the caller's Cin split
 int dm3d_h3v2_post_launch(const ConvArgs& a, const H3v2Launch& L, hipStream_t st);
+int dm3d_h3v2_post_reduce(const ConvArgs& a, const H3v2Launch& L, hipStream_t st);
 int dm3d_conv_h3v2_ksplit(const ConvArgs& a, bool with_scratch);
 int dm3d_conv_h3v3_td(const ConvArgs& a);              // z-slices per brick (4 or 8) the free-running kernel takes for this launch
 int64_t dm3d_h3v2_skip_image_bytes(int cin, int cout);

@@ -92,6 +92,14 @@ int dm3d_h3v2_pre_launch(ConvArgs& a, int td, H3v2Launch& L, hipStream_t st, int
     const bool atomic2 = a.ksplit == 2 && linear && a.nchunks >= 8 && !(no_atomic && with_scratch);       // cheaper than a reduce launch when two parts suffice
     L.out_elems = out_elems;
     L.reduce = false;
+    // Fused GroupNormalization statistics: the kernel's 16-byte full-brick epilogue accumulates them (whole bricks, cout % 64 == 0, no Cin
+    // split, plain float32 output without PReLU); every other form leaves them to the stand-alone kernel behind the launch (post_launch).
+    L.stats_after = false;
+    if (a.gn_stats) {
+        const bool fused = a.od % td == 0 && a.oh % 8 == 0 && a.ow % 8 == 0 && a.cout % 64 == 0 && a.ksplit == 1 && a.epi_vec4 && !a.prelu
+                           && !a.out_h2 && !a.post_scale;
+        if (!fused) { k.gn_stats = nullptr; L.stats_after = true; }
+    }
     if (a.ksplit > 1 && (!with_scratch || atomic2)) {         // two halves, order-independent atomic add into the zeroed output
         k.split_atomic = 1;
         long zg = ((long)(out_elems / 4) + 255) / 256;
@@ -112,6 +120,12 @@ int dm3d_h3v2_pre_launch(ConvArgs& a, int td, H3v2Launch& L, hipStream_t st, int
 }
 
 int dm3d_h3v2_post_launch(const ConvArgs& a, const H3v2Launch& L, hipStream_t st) {
+    if (int rc = dm3d_h3v2_post_reduce(a, L, st)) return rc;
+    if (L.stats_after) return dm3d_groupnorm_partials(a.out, a.batch, (int64_t)a.fd * a.fh * a.fw, a.cout, a.gn_stats, st);
+    return DM3D_OK;
+}
+
+int dm3d_h3v2_post_reduce(const ConvArgs& a, const H3v2Launch& L, hipStream_t st) {
     if (!L.reduce) return DM3D_OK;
     const size_t out_elems = L.out_elems;
     const long n4 = (long)(out_elems / 4);                    // cout % 4 == 0 is not required of cout: fall back to scalar lanes

@@ -187,8 +187,12 @@ __device__ __forceinline__ void skip_phase(const ConvArgs& p, _Float16* smem, f3
 // NCT = 16-column tiles per wave the caller computed (4: a whole 64-column tile; 1 / 2: the narrow forms for Cout <= 16 / 32)
 // zs: the z-slice of the brick these tiles belong to (-1: the wave index — one slice per wave); tile pi sits at brick column
 // xa * (pi & 1) + xb (xb < 0: the direct kernels' patch geometry, 4 * (pi & 1) + dx_of_row; the Winograd form passes 1, 2 * x-pair)
+// gn: per-lane partial sums for the fused GroupNormalization statistics (ConvArgs.gn_stats; nullptr: none): [ni][j][sum, sum of squares] of
+// the values this lane stores for its four channels of column tile ni — only the 16-byte full-brick form accumulates (the launcher clears
+// gn_stats for every other form and runs the stand-alone statistics kernel behind the launch); gn_flush() adds them to the tensor's buffer.
 template <int TD, int NCT = 4>
-__device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT], const Brick& br, const int zs = -1, const int xa = 4, const int xb = -1) {
+__device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT], const Brick& br, const int zs = -1, const int xa = 4, const int xb = -1,
+                                         float* gn = nullptr) {
     constexpr int TH = 8, TW = 8, NT = 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = lane & 15, g4 = lane >> 4;
@@ -254,8 +258,8 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
         // The two rare options are compile-time forms of the loop: as run-time tests of uniform flags hipcc if-converted them, i.e. every
         // element paid the consumer's SiLU (v_exp_f32, v_rcp_f32) and the DM3D_FMT_H2 split and then selected them away — 164 instructions
         // per tile instead of ~60, 12 500 cycles per slice where no other wave hides them (in-kernel stamps of the Winograd form, round 3).
-        auto tiles = [&](auto POST_T, auto H2_T) {
-            constexpr bool POST = decltype(POST_T)::value, H2 = decltype(H2_T)::value;
+        auto tiles = [&](auto POST_T, auto H2_T, auto GN_T) {
+            constexpr bool POST = decltype(POST_T)::value, H2 = decltype(H2_T)::value, GN = decltype(GN_T)::value;
     #pragma unroll
             for (int ni = 0; ni < NCT; ++ni) {
                 const int n = n0 + ni * 16 + c4;             // first of this lane's four channels
@@ -284,6 +288,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
                         if constexpr (POST) v = dm3d_silu(fmaf(v, ps[j], pt[j]));         // the consumer's norm + SiLU, applied once here
                         DM3D_AMAX(amax, v);
                         v4[j] = v;
+                        if constexpr (GN) { gn[(ni * 4 + j) * 2] += v; gn[(ni * 4 + j) * 2 + 1] = fmaf(v, v, gn[(ni * 4 + j) * 2 + 1]); }
                     }
                     if constexpr (H2) {
                         const unsigned int w0 = split1_bits(v4[0]), w1 = split1_bits(v4[1]), w2 = split1_bits(v4[2]), w3 = split1_bits(v4[3]);
@@ -299,8 +304,10 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
         };
         const std::true_type yes_t;
         const std::false_type no_t;
-        if (p.post_scale) { if (p.out_h2) tiles(yes_t, yes_t); else tiles(yes_t, no_t); }
-        else { if (p.out_h2) tiles(no_t, yes_t); else tiles(no_t, no_t); }
+        if (p.post_scale) { if (p.out_h2) tiles(yes_t, yes_t, no_t); else tiles(yes_t, no_t, no_t); }
+        else if (p.out_h2) tiles(no_t, yes_t, no_t);
+        else if (gn) tiles(no_t, no_t, yes_t);          // (the launcher admits gn_stats with a plain float32 output only)
+        else tiles(no_t, no_t, no_t);
         if (p.range_flag && amax > rlim) *p.range_flag = 1;
         return;
     }
@@ -388,6 +395,46 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
         }
     }
     if (p.range_flag && amax > rlim) *p.range_flag = 1;
+}
+
+// Fused GroupNormalization statistics, second half: the per-lane partial sums of epilogue() — this lane's four channels of every column tile —
+// are summed over the 16 lanes that hold the same channels (lane bits 0-1: the voxel row inside a quad, bits 4-5: the voxel column group) and
+// STORED as this wave's partial (sum, sum of squares) per channel: gn_stats[b][slot][cout][2] float32, slot = the wave's z-slice of the
+// brick grid (parity forms: one set of slots per parity) — no atomics (a first form added float64 atomics to one [b][cout][2] buffer: a
+// million device-scope atomics per launch cost 13 % of the conv), and the sum dm3d_groupnorm_finalize2 takes over the slots has a fixed order.
+// `slices`: z-slices this wave covered (the Winograd form: 2 — the second slice's slot is written as zeros).  One call per wave and brick.
+template <int TD, int NCT>
+__device__ __forceinline__ void gn_flush(const ConvArgs& p, float (&gn)[NCT * 8], const Brick& br, const int zs, const int slices) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < NCT * 8; ++i) {
+        float v = gn[i];
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // lane ^ 1
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // lane ^ 2
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        gn[i] = v;
+    }
+    if ((lane & 0x33) == 0) {
+        const int c4 = lane & 12;
+        const int bh = p.oh / 8, bw = p.ow / 8, par = br.ooz * 4 + br.ooy * 2 + br.oox;
+        const long nslots = (long)p.od * bh * bw * (p.os == 2 ? 8 : 1);
+        const long slot = (((long)par * p.od + br.oz0 + zs) * bh + br.oy0 / 8) * bw + br.ox0 / 8;
+        float* dst = p.gn_stats + (((size_t)br.b * nslots + slot) * p.cout + br.ntile * 64 + c4) * 2;
+#pragma unroll
+        for (int ni = 0; ni < NCT; ++ni) {
+            *reinterpret_cast<f32x4*>(dst + ni * 32) = f32x4{gn[ni * 8], gn[ni * 8 + 1], gn[ni * 8 + 2], gn[ni * 8 + 3]};
+            *reinterpret_cast<f32x4*>(dst + ni * 32 + 4) = f32x4{gn[ni * 8 + 4], gn[ni * 8 + 5], gn[ni * 8 + 6], gn[ni * 8 + 7]};
+        }
+        for (int k = 1; k < slices; ++k) {                      // slots of further slices this wave covered in the same sums
+            float* dz = dst + (size_t)k * bh * bw * p.cout * 2;
+#pragma unroll
+            for (int ni = 0; ni < NCT; ++ni) {
+                *reinterpret_cast<f32x4*>(dz + ni * 32) = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(dz + ni * 32 + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
 }
 
 }  // namespace h3v2

@@ -418,7 +418,15 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v3(const ConvArgs p
         // (the launcher sizes the dynamic LDS for whichever of the two phases needs more: v3_lds_halfs)
         skip_phase<TD>(p, smem_v3, acc, br);
     }
-    epilogue<TD, NCT>(p, acc, br);
+    if (p.gn_stats) {                       // fused GroupNormalization statistics of the output (uniform; the launcher admits the 16-byte full-brick form only)
+        float gn[NCT * 8];
+#pragma unroll
+        for (int i = 0; i < NCT * 8; ++i) gn[i] = 0.0f;
+        epilogue<TD, NCT>(p, acc, br, -1, 4, -1, gn);
+        gn_flush<TD, NCT>(p, gn, br, threadIdx.x >> 6, 1);
+    } else {
+        epilogue<TD, NCT>(p, acc, br);
+    }
     STAMP(29);
 }
 

@@ -752,6 +752,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
         }
         // ---- the shared epilogue, one slice at a time straight from the accumulators (the LDS holds the next item's image and weights):
         // tile (2g + parity, ni) of slice s = rows 4g .. 4g+3, x = 2 * x-pair + parity; without a skip conv the output transform happens here.
+        float gn[32];                       // fused GroupNormalization statistics of the output (ConvArgs.gn_stats): partial sums over both slices
+#pragma unroll
+        for (int i = 0; i < 32; ++i) gn[i] = 0.0f;
         static_for<2>([&](auto S_) {
             constexpr int s = decltype(S_)::value;
             __builtin_amdgcn_sched_barrier(0);
@@ -779,8 +782,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
                         e[2 * g + 1][ni] = (m1 - m2) - m3;
                     }
             }
-            epilogue<TD, 4>(p, e, br, 2 * wave + s, 1, 2 * (lane >> 4));
+            epilogue<TD, 4>(p, e, br, 2 * wave + s, 1, 2 * (lane >> 4), p.gn_stats ? gn : nullptr);
         });
+        if (p.gn_stats) gn_flush<TD, 4>(p, gn, br, 2 * wave, 2);
         STAMP(29);
         if (!has_next) break;
         // the accumulators of the next item: zeroed only now, with every old value dead (zeroing a slice's tiles as soon as they were read

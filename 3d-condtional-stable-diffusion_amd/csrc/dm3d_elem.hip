@@ -349,6 +349,53 @@ __global__ __launch_bounds__(256) void groupnorm_finalize_kernel(double* __restr
     }
 }
 
+// GroupNormalization from per-TENSOR partial statistics (dm3d_conv_desc.gn_stats / dm3d_groupnorm_partials): part[b][slot][c][2] float32
+// (sum, sum of squares) over the voxels of slot, nslots = ceil(voxels / 64).  One block per (group, sample): float64 sums over the slots and
+// the group's channels — channel ch of concat(x1, x2) lives in part1 (ch < c1) or part2 — then scale / shift of those channels.
+__global__ __launch_bounds__(256) void groupnorm_finalize2_kernel(const float* __restrict__ part1, int c1, const float* __restrict__ part2, int c2,
+                                                                  long voxels, long nslots, int groups, float eps, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift) {
+    const int g = blockIdx.x, b = blockIdx.y, c_total = c1 + c2, gc = c_total / groups;
+    __shared__ double red[2][256];
+    double s = 0, q = 0;
+    for (long i = threadIdx.x; i < nslots * gc; i += 256) {
+        const long slot = i / gc;
+        const int ch = g * gc + (int)(i % gc);
+        const float* src = ch < c1 ? part1 + (((size_t)b * nslots + slot) * c1 + ch) * 2 : part2 + (((size_t)b * nslots + slot) * c2 + (ch - c1)) * 2;
+        s += (double)src[0];
+        q += (double)src[1];
+    }
+    red[0][threadIdx.x] = s; red[1][threadIdx.x] = q;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) { red[0][threadIdx.x] += red[0][threadIdx.x + w]; red[1][threadIdx.x] += red[1][threadIdx.x + w]; }
+        __syncthreads();
+    }
+    const double n = (double)voxels * gc, m = red[0][0] / n;
+    double var = red[1][0] / n - m * m;
+    var = var > 0 ? var : 0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    for (int i = threadIdx.x; i < gc; i += 256) {
+        const int ch = g * gc + i;
+        const double sc = (double)gamma[ch] * rstd;
+        scale[(size_t)b * c_total + ch] = (float)sc;
+        shift[(size_t)b * c_total + ch] = (float)((double)beta[ch] - m * sc);
+    }
+}
+
+// the stand-alone producer of such partials: block (slot, sample) sums its 64 voxels for every channel
+__global__ __launch_bounds__(256) void groupnorm_partials_kernel(const float* __restrict__ x, long voxels, int c, float* __restrict__ part, long nslots) {
+    const long slot = blockIdx.x;
+    const int b = blockIdx.y;
+    const long v0 = slot * 64, v1 = v0 + 64 < voxels ? v0 + 64 : voxels;
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        float s = 0.f, q = 0.f;
+        for (long v = v0; v < v1; ++v) { const float t = x[((size_t)b * voxels + v) * c + ch]; s += t; q = fmaf(t, t, q); }
+        float* dst = part + (((size_t)b * nslots + slot) * c + ch) * 2;
+        dst[0] = s; dst[1] = q;
+    }
+}
+
 __global__ __launch_bounds__(256) void affine_act_batched_kernel(const float* __restrict__ x, float* __restrict__ y, long per_sample4,
                                                                  int c4, const float* scale, const float* shift, int act) {
     const int b = blockIdx.y;
@@ -727,6 +774,29 @@ extern "C" int dm3d_groupnorm_finalize(double* acc, int32_t batch, int64_t voxel
     hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3((unsigned)batch), dim3(256), 0, static_cast<hipStream_t>(stream), acc,
                        (long)voxels, c_total, groups, eps, gamma, beta, scale, shift);
     return dm3d_launch_check("groupnorm_finalize_kernel");
+}
+
+extern "C" int64_t dm3d_groupnorm_partials_bytes(int32_t batch, int64_t voxels, int32_t c) {
+    return (batch > 0 && voxels > 0 && c > 0) ? (int64_t)batch * ((voxels + 63) / 64) * c * 2 * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int dm3d_groupnorm_partials(const float* x, int32_t batch, int64_t voxels, int32_t c, float* part, void* stream) {
+    DM3D_REQUIRE(x && part && batch > 0 && batch <= 65535 && voxels > 0 && c > 0, "groupnorm_partials: bad arguments");
+    const long nslots = (long)((voxels + 63) / 64);
+    DM3D_REQUIRE(nslots < (1l << 31), "groupnorm_partials: too many slots");
+    hipLaunchKernelGGL(groupnorm_partials_kernel, dim3((unsigned)nslots, (unsigned)batch), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       (long)voxels, c, part, nslots);
+    return dm3d_launch_check("groupnorm_partials_kernel");
+}
+
+extern "C" int dm3d_groupnorm_finalize2(const float* part1, int32_t c1, const float* part2, int32_t c2, int32_t batch, int64_t voxels, int32_t groups,
+                                        float eps, const float* gamma, const float* beta, float* scale, float* shift, void* stream) {
+    DM3D_REQUIRE(part1 && c1 > 0 && gamma && beta && scale && shift && batch > 0 && batch <= 65535 && voxels > 0, "groupnorm_finalize2: bad arguments");
+    DM3D_REQUIRE((part2 != nullptr) == (c2 > 0) && c2 >= 0, "groupnorm_finalize2: part2 / c2 go together");
+    DM3D_REQUIRE(groups > 0 && groups <= 64 && (c1 + c2) % groups == 0, "groupnorm_finalize2: groups=%d must divide c=%d (<= 64)", groups, c1 + c2);
+    hipLaunchKernelGGL(groupnorm_finalize2_kernel, dim3((unsigned)groups, (unsigned)batch), dim3(256), 0, static_cast<hipStream_t>(stream), part1, c1,
+                       part2, c2, (long)voxels, (long)((voxels + 63) / 64), groups, eps, gamma, beta, scale, shift);
+    return dm3d_launch_check("groupnorm_finalize2_kernel");
 }
 
 extern "C" int dm3d_affine_act_batched(const float* x, float* y, int32_t batch, int64_t rows_per_sample, int32_t c,

@@ -141,7 +141,7 @@ def pack_weights_convt(kernel: torch.Tensor, h3: bool = False):
 
 def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False, pro_scale=None, pro_shift=None,
            vec=None, vec_idx=None, relu=False, res=None, precision=_lib.PREC_F32, w_exp=0, prelu_alpha=None,
-           relu_out=False, transpose=False, skip=None, x1_h2_channels=None, out_h2=False, post=None, wpk_wino=None) -> torch.Tensor:
+           relu_out=False, transpose=False, skip=None, x1_h2_channels=None, out_h2=False, post=None, wpk_wino=None, gn_stats=None) -> torch.Tensor:
     """Conv3D(padding="same") on NDHWC with the fused prologue / concat / upsample / epilogue of dm3d_conv3d_ndhwc.
     ``skip=(sx1, sx2_or_None, skip_wpk[, skip_wpk_frag])``: also accumulate Conv3D(cout, 1) of the raw concat(sx1, sx2) (H3, k3, stride 1).
     ``post=(scale, shift)``: out = silu(out*scale[c] + shift[c]) at the very end; ``out_h2``: store DM3D_FMT_H2;
@@ -184,6 +184,8 @@ def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False
         d.post_scale, d.post_shift = post[0].data_ptr(), post[1].data_ptr()
     if wpk_wino is not None:
         d.wpk_wino = wpk_wino.data_ptr()
+    if gn_stats is not None:               # float32 [B, ceil(voxels / 64), cout, 2]: partial (sum, sum of squares) of the output per (sample, channel)
+        d.gn_stats = gn_stats.data_ptr()
     if skip is not None:
         sx1, sx2, swpk = skip[:3]
         if len(skip) > 3 and skip[3] is not None:

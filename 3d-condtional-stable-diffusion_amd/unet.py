@@ -492,7 +492,7 @@ class Plan:
         self.t_idx = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.vec = torch.empty(vec_rows, net.temb_ld, dtype=torch.float32, device=dev)
         self.ctx_bufs: Dict[str, tuple] = {}
-        self._gn_acc = None
+        self._gn_stats = {}
         # H3 range guard (include/dm3d.h): every H3 launch of the plan reports into one flag; see UNet.check_range
         self.range_flag = torch.zeros(1, dtype=torch.int32, device=dev) if net.precision == "h3" else None
         self.uses_wino = False                  # some conv of this plan takes the Winograd-x form (dm3d_conv_tile_form() == 10)
@@ -520,30 +520,45 @@ class Plan:
         self._keep.append(t)
         return t
 
+    # -- GroupNormalization statistics (cfg.norm == "group") -----------------------------------------------------------------
+    # Every tensor that gets normalised owns a float32 buffer [B][slots][C][2] of partial (sum, sum of squares) per (sample, channel),
+    # one slot per 64 voxels.  A conv producer fills it while it stores the tensor (dm3d_conv_desc.gn_stats: fused in the full-brick
+    # epilogue — a wave stores its sums as the slot of its z-slice, no atomics — else by the library behind the launch); a tensor from
+    # another producer (the attention blocks' GEMMs) gets one stand-alone pass.  A norm layer then needs one small launch
+    # (dm3d_groupnorm_finalize2 over the buffers of its one or two inputs), and a tensor with several consumers (the skip connections)
+    # is summed once.  Every slot is rewritten every step: nothing to clear.
+    def _stats_alloc(self, t: torch.Tensor, c: int, vox: int) -> int:
+        buf = torch.empty(lib().dm3d_groupnorm_partials_bytes(self.B, vox, c) // 4, dtype=torch.float32, device=self.net.device)
+        self._keep.append(buf)
+        self._gn_stats[t.data_ptr()] = buf.data_ptr()
+        return buf.data_ptr()
+
+    def _stats_for(self, t: torch.Tensor, c: int, vox: int) -> int:
+        ptr = self._gn_stats.get(t.data_ptr())
+        if ptr is None:                    # no conv produced it with gn_stats: one stand-alone pass over the tensor
+            ptr = self._stats_alloc(t, c, vox)
+            self.ops.append((lib().dm3d_groupnorm_partials, (t.data_ptr(), self.B, vox, c, ptr), "groupnorm", {}))
+        return ptr
+
     def _norm(self, name, x1, c1, edge, x2=None, c2=0):
-        """Prologue vectors of a normalisation layer: (pro, batch_stride).  BatchNorm: the folded constants.  GroupNorm:
-        two launches (per-channel moments, group finalize) write per-sample scale/shift for this step."""
+        """Prologue vectors of a normalisation layer: (pro, batch_stride).  BatchNorm: the folded constants.  GroupNorm: one small
+        launch turns the statistics of the input tensor(s) into per-sample scale/shift for this step."""
         P = self.net.P
         if self.net.cfg.norm != "group":
             return P[name], 0
         gamma, beta = P[name]
         ct, B, vox = c1 + c2, self.B, edge ** 3
-        if self._gn_acc is None or self._gn_acc.numel() < B * ct * 2:
-            self._gn_acc = torch.zeros(B * max(ct, 1024) * 2, dtype=torch.float64, device=self.net.device)
-            self._keep.append(self._gn_acc)
         scale, shift = self._buf(B, ct), self._buf(B, ct)
         self._keep += [gamma, beta]
-        st = lib().dm3d_groupnorm_stats
-        self.ops.append((st, (x1.data_ptr(), B, vox, c1, self._gn_acc.data_ptr(), ct, 0), "groupnorm", {}))
-        if x2 is not None:
-            self.ops.append((st, (x2.data_ptr(), B, vox, c2, self._gn_acc.data_ptr(), ct, c1), "groupnorm", {}))
-        self.ops.append((lib().dm3d_groupnorm_finalize, (self._gn_acc.data_ptr(), B, vox, ct, self.net.cfg.norm_groups, BN_EPS,
-                                                         gamma.data_ptr(), beta.data_ptr(), scale.data_ptr(), shift.data_ptr()),
-                         "groupnorm", {}))
+        a1 = self._stats_for(x1, c1, vox)
+        a2 = self._stats_for(x2, c2, vox) if x2 is not None else None
+        self.ops.append((lib().dm3d_groupnorm_finalize2, (a1, c1, a2, c2, B, vox, self.net.cfg.norm_groups, BN_EPS, gamma.data_ptr(),
+                                                          beta.data_ptr(), scale.data_ptr(), shift.data_ptr()), "groupnorm", {}))
         return (scale, shift), ct
 
     def _conv(self, w: _Conv, x1, out, edge_in, x2=None, c1=None, c2=0, upsample=0, stride=1, pro=None, vec_off=None,
-              relu=0, res=None, pro_bstride=0, skip=None, post=None, out_h2=False, x1_h2=False):
+              relu=0, res=None, pro_bstride=0, skip=None, post=None, out_h2=False, x1_h2=False, normed=True):
+        """``normed``: the output feeds a normalisation layer (GroupNormalization variant: the launch also sums its statistics)."""
         d = ConvDesc()
         d.x1, d.x2 = _ptr(x1), _ptr(x2)
         d.c1, d.c2 = (c1 if c1 is not None else w.cin), c2
@@ -571,6 +586,8 @@ class Plan:
             d.wpk_wino = w.wpk_wino.data_ptr()
         if self.range_flag is not None and w.precision == _lib.PREC_H3:
             d.range_flag, d.range_limit = self.range_flag.data_ptr(), self.range_limit
+        if self.net.cfg.norm == "group" and normed and not out_h2 and w.cout % 4 == 0:
+            d.gn_stats = self._stats_alloc(out, w.cout, out.numel() // (self.B * w.cout))
         skip_flops = 0.0
         if skip is not None:
             sx1, sx2, sc1, sc2, simg, sfrag = skip
@@ -677,10 +694,10 @@ class Plan:
                 self._conv(P[blk.name], cur, out, edge, upsample=1)
                 cur, edge = out, blk.edge
         if final_handoff:
-            self._conv(P["out.conv"], cur, self.eps, edge, x1_h2=True)
+            self._conv(P["out.conv"], cur, self.eps, edge, x1_h2=True, normed=False)
             return
         pro, bs = self._norm("out.norm", cur, cur_c, edge)
-        self._conv(P["out.conv"], cur, self.eps, edge, pro=pro, pro_bstride=bs)
+        self._conv(P["out.conv"], cur, self.eps, edge, pro=pro, pro_bstride=bs, normed=False)
 
     def _res_block(self, blk, x1, c1, x2, c2, edge, final_post=None):
         """ResidualBlock (conditional_dm3d.py:238-271): three launches (two when the widths match).  ``final_post``: the folded norm of
@@ -691,7 +708,7 @@ class Plan:
             res, skip = None, (x1, x2, c1, c2, P[f"{n}.skip_fused"], P.get(f"{n}.skip_frag"))
         elif f"{n}.skip" in P:
             res = self._buf(B, edge, edge, edge, w)
-            self._conv(P[f"{n}.skip"], x1, res, edge, x2=x2, c1=c1, c2=c2)
+            self._conv(P[f"{n}.skip"], x1, res, edge, x2=x2, c1=c1, c2=c2, normed=False)
         else:
             res = x1
         hmid = self._buf(B, edge, edge, edge, w)

@@ -24,7 +24,7 @@ extern "C" {
 #define DM3D_VERSION 109          /* major*100 + minor; the descriptor structs grew in 101 (w_layout), 102 (scratch), 103 (skip_*),
                                      104 (dm3d_attention), 105 (x1_fmt / out_fmt / post_*), 106 (ddpm seed_dev; conv/gemm range_flag; the
                                      training entries), 107 (conv wpk_f8: a float8 cross-term form, removed again in 109), 108 (conv wpk_wino: the Winograd-x form), 109 (wpk_f8 and
-                                     dm3d_pack_weights_h3f8 are gone; the Winograd-x image pairs its taps differently; dm3d_mlp_fused; conv skip_wpk_frag): a host built against an older header must be rebuilt */
+                                     dm3d_pack_weights_h3f8 are gone; the Winograd-x image pairs its taps differently; dm3d_mlp_fused; conv skip_wpk_frag, gn_stats; dm3d_groupnorm_finalize2): a host built against an older header must be rebuilt */
 
 #define DM3D_OK            0
 #define DM3D_EINVAL       -1      /* bad argument (shape, alignment, null pointer) */
@@ -201,6 +201,13 @@ typedef struct dm3d_conv_desc {
        Winograd-x form also serves launches that carry a skip conv — as a register-direct tail between an item's chunk loop and its
        epilogue (no LDS: such launches are persistent like the others); without it they stay on the direct kernel.  NULL: never. */
     const void* skip_wpk_frag;
+    /* Optional: fused GroupNormalization statistics of the OUTPUT tensor: gn_stats[batch][slots][cout][2] float32 = partial (sum, sum of
+       squares) per (sample, channel) over the voxels of a slot, slots = ceil(voxels / 64), dm3d_groupnorm_partials_bytes() bytes — the
+       input dm3d_groupnorm_finalize2 needs to turn this tensor into a consumer's per-sample scale / shift, without a pass of its own over the
+       tensor.  The 16x16x32 kernels' full-brick epilogue stores a wave's sums as the slot of its z-slice while it stores the output (no
+       atomics; every slot is written); behind any other kernel or form the library runs dm3d_groupnorm_partials on the finished output
+       itself.  Float32 output only (cout % 4 == 0, 16-byte aligned buffer).  NULL: none. */
+    float* gn_stats;
 } dm3d_conv_desc;
 
 int     dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream);
@@ -287,6 +294,14 @@ int dm3d_groupnorm_stats(const float* x, int32_t batch, int64_t voxels, int32_t 
                          int32_t chan_off, void* stream);
 int dm3d_groupnorm_finalize(double* acc, int32_t batch, int64_t voxels, int32_t c_total, int32_t groups, float eps,
                             const float* gamma, const float* beta, float* scale, float* shift, void* stream);
+/* the same from per-TENSOR partial statistics of up to two concatenated inputs: part [batch][slots][c][2] float32, slots = ceil(voxels / 64),
+ * each slot the (sum, sum of squares) of its voxels per channel — what dm3d_conv_desc.gn_stats or dm3d_groupnorm_partials left there.
+ * Float64 sums over the slots in a fixed order (no atomics anywhere on this path); nothing is cleared: a tensor with several consumers is
+ * summed once. */
+int64_t dm3d_groupnorm_partials_bytes(int32_t batch, int64_t voxels, int32_t c);
+int dm3d_groupnorm_partials(const float* x, int32_t batch, int64_t voxels, int32_t c, float* part, void* stream);
+int dm3d_groupnorm_finalize2(const float* part1, int32_t c1, const float* part2, int32_t c2, int32_t batch, int64_t voxels, int32_t groups,
+                             float eps, const float* gamma, const float* beta, float* scale, float* shift, void* stream);
 /* y[b][r][c] = act(x[b][r][c]*scale[b][c] + shift[b][c]) : dm3d_affine_act with per-sample vectors. c % 4 == 0. */
 int dm3d_affine_act_batched(const float* x, float* y, int32_t batch, int64_t rows_per_sample, int32_t c, const float* scale,
                             const float* shift, int32_t act, void* stream);

@@ -337,3 +337,59 @@ def test_mlp_fused_against_float64(dev, m, out_h2):
     out = ops.mlp_fused(ops.split_h2(c(x)), w0t, c(b0), w1t, c(b1), u)
     ref0 = ref - r1.double() - r2.double()
     assert float((out.cpu().double() - ref0).abs().max() / ref0.abs().max()) < 2e-5
+
+
+GN_CASES = [("direct kernel, whole bricks (fused)", 2, (8, 8, 8), 32, 64, 0, 0), ("Winograd form, item lists (fused)", 2, (16, 16, 16), 32, 64, 1, 0),
+            ("ragged extent and Cout (the library sums behind the launch)", 1, (6, 8, 10), 16, 40, 0, 0), ("UpSample parity form", 1, (8, 8, 8), 32, 64, 0, 1),
+            ("Cin split on a small grid (sums behind the launch)", 1, (8, 8, 8), 256, 64, 0, 0)]
+
+
+@pytest.mark.parametrize("case", GN_CASES, ids=[c[0] for c in GN_CASES])
+def test_conv_sums_groupnorm_statistics_of_its_output(dev, monkeypatch, case):
+    """dm3d_conv_desc.gn_stats: per-(sample, channel) partial sums and sums of squares of the OUTPUT, stored by the producing launch (the
+    GroupNormalization variant the reference keeps commented out, conditional_dm3d.py:77, 254, 261, 409 — fused into the producer as
+    north_star words it), against torch on the stored output; and dm3d_groupnorm_finalize2 over two such buffers against the oracle's
+    group_norm of the concatenated tensors."""
+    from dm3d_amd import ops, _lib
+    from dm3d_amd._lib import lib, check
+    name, B, dims, cin, cout, wino, up = case
+    if wino:
+        monkeypatch.setenv("DM3D_CONV_WIDE_WGS", "1")
+        monkeypatch.setenv("DM3D_CONV_WINO_GRID", "4")
+    torch.manual_seed(3)
+    x = torch.randn(B, *dims, cin, device=dev)
+    k = torch.randn(3, 3, 3, cin, cout, device=dev) * 0.1
+    if up:
+        wpk, w_exp = ops.pack_weights_up(k, h3=True)
+    else:
+        wpk, w_exp = ops.pack_weights_h3(k)
+    eo = [d * (2 if up else 1) for d in dims]
+    vox_out = eo[0] * eo[1] * eo[2]
+    st = torch.full((B, (vox_out + 63) // 64, cout, 2), float("nan"), device=dev)          # every slot must be written
+    kw = dict(bias=torch.randn(cout, device=dev), precision=_lib.PREC_H3, w_exp=w_exp, gn_stats=st, upsample=bool(up))
+    if wino:
+        kw["wpk_wino"] = ops.pack_weights_h3w(k, w_exp)
+    y = ops.conv3d(x, wpk, cout, 3, **kw)
+    torch.cuda.synchronize()
+    yd = y.double().reshape(B, -1, cout)
+    want = torch.stack([yd.sum(1), (yd * yd).sum(1)], -1)
+    assert torch.isfinite(st).all()
+    err = float((st.double().sum(1) - want).abs().max() / want.abs().max())
+    print(f"{name}: statistics rel err {err:.2e}")
+    assert err < 2e-6
+    # two tensors -> per-sample scale / shift of GroupNormalization(8)(concat) (here: the tensor with itself)
+    g = torch.rand(2 * cout, device=dev) + 0.5
+    b_ = torch.randn(2 * cout, device=dev)
+    scale, shift = torch.empty(B, 2 * cout, device=dev), torch.empty(B, 2 * cout, device=dev)
+    vox = yd.shape[1]
+    check(lib().dm3d_groupnorm_finalize2(st.data_ptr(), cout, st.data_ptr(), cout, B, vox, 8, 1e-3, g.data_ptr(), b_.data_ptr(), scale.data_ptr(),
+                                         shift.data_ptr(), torch.cuda.current_stream().cuda_stream), "groupnorm_finalize2")
+    cat = torch.cat([yd, yd], -1)                                         # [B, vox, 2 cout]
+    grp = cat.reshape(B, vox, 8, -1)
+    mean, var = grp.mean((1, 3)), grp.var((1, 3), unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-3)
+    sc = g.double().reshape(8, -1) * rstd[:, :, None]
+    sh = b_.double().reshape(8, -1) - mean[:, :, None] * sc
+    torch.cuda.synchronize()
+    assert float((scale.double() - sc.reshape(B, -1)).abs().max() / sc.abs().max()) < 1e-5
+    assert float((shift.double() - sh.reshape(B, -1)).abs().max() / sh.abs().max().clamp_min(1.0)) < 1e-5
