@@ -52,11 +52,15 @@
 using namespace h3v2;
 
 // Diagnostic build only (-DDM3D_CLOCK_STAMPS, tools/mk_stamp_variants.py -> variants/cck.so; the product library carries none of it): thread 0 of
-// every workgroup writes s_memtime / s_memrealtime at kernel entry (0), around the chunk loop (1, 28) and at the end (29) into a buffer of its own.
+// a workgroup writes s_memtime / s_memrealtime at kernel entry (0: its first item only — a stamp at the item advance costs the step loop a
+// spilled register), around every item's chunk loop (1, 28), inside its epilogue (20, 21) and at its end (29) into a buffer of its own.
 #ifdef DM3D_CLOCK_STAMPS
 __device__ unsigned long long* g_dbg_stamps_w = nullptr;
 extern "C" int dm3d_debug_set_stamps_wino(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_stamps_w), &p, sizeof(p)); }
-#define STAMP(i) do { if (g_dbg_stamps_w && threadIdx.x == 0 && cur.ntile == 0 && cur.khalf == 0 && item / ny < 4096u) { \
+#ifndef STAMP_MASK
+#define STAMP_MASK 0xffffffffu
+#endif
+#define STAMP(i) do { if (((STAMP_MASK >> (i)) & 1u) && g_dbg_stamps_w && wave == 0 && __builtin_amdgcn_mbcnt_lo(~0u, 0u) == 0u && cur.ntile == 0 && cur.khalf == 0 && item / ny < 4096u) { \
     g_dbg_stamps_w[(item / ny) * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
     if ((i) == 1) g_dbg_stamps_w[(item / ny) * 32 + 30] = __builtin_amdgcn_s_memrealtime(); \
     if ((i) == 28) g_dbg_stamps_w[(item / ny) * 32 + 31] = __builtin_amdgcn_s_memrealtime(); } } while (0)
@@ -803,7 +807,6 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
         cur = decode(item);
         c_lo = cur.khalf * cpp; c_hi = c_lo + cpp;
         has_next = item + item_step < item_end;
-        STAMP(0);
     }
     }       // items
 }

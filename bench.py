@@ -12,10 +12,11 @@ Contract (one JSON line from rank 0):  python bench.py --gpus N --steps K --warm
     `python bench.py --gpus N` it launches the N ranks itself as fresh child processes — before this process has touched the
     GPU — relays rank 0's JSON line and exits non-zero if any rank fails.
   * roofline: the dominant kernel is the k3/stride-1 Conv3d with the norm+SiLU prologue in its Winograd F(2,3)-along-x form,
-    conv3d_igemm_h3w<1, false> (19 launches/step at B = 32: the Cin >= 32 convs of the 32^3 / 16^3 levels without a fused skip conv and the
-    Cin >= 256 convs of the 8^3 level with their two-way Cin split, ~45 % of the step; persistent workgroups, one per CU); its MODE-2 twin
-    behind a DM3D_FMT_H2 hand-off, the direct kernel conv3d_igemm_h3v3 (launches with a long fused skip conv, small grids, conv_in /
-    conv_out, the UpSample parity convs) and the stride-2 convs are listed under per_kernel_kind;
+    conv3d_igemm_h3w<1> (23 launches/step at B = 32: every Cin >= 32 conv of the 32^3 / 16^3 levels that reads a float32 tensor, and the
+    Cin >= 256 convs of the 8^3 level with their two-way Cin split, with or without a fused 1x1 skip tail; ~52 % of the step; persistent
+    workgroups, one per CU); its MODE-2 twin behind a DM3D_FMT_H2 hand-off (10 launches, ~28 %), the direct kernel conv3d_igemm_h3v3
+    (conv_in / conv_out, the UpSample parity convs, the first 8^3 conv, every k3 conv of small batches) and the stride-2 convs are listed
+    under per_kernel_kind;
     achieved = algorithmic FLOPs (2*27*Cin*Cout*B*Dout^3 per launch, plus those of a fused 1x1 skip conv) /
     HIP-event time of those launches, measured live on the launch stream; peak = the dense MFMA peak of the datatype the
     kernel multiplies in (MI355X_MICROARCH.md): float16 2500 TFLOP/s in the default h3 mode (three v_mfma_f32_16x16x32_f16
@@ -317,11 +318,12 @@ def main():
         n, ms, fl, by, ex, us = acc[dom]
         achieved = fl / (ms * 1e-3) / 1e12
         if dom == "conv_wino":
-            kname = ("conv3d_igemm_h3w<1, false> (k3 stride-1 Conv3d with the fused norm+SiLU prologue as Winograd F(2,3) along x: 8x8x8 bricks, one wave "
+            kname = ("conv3d_igemm_h3w<1> (k3 stride-1 Conv3d with the fused norm+SiLU prologue as Winograd F(2,3) along x: 8x8x8 bricks, one wave "
                      "per SIMD with 256 accumulator registers, persistent workgroups (one per CU walks a list of bricks; the next brick's first image "
                      "and weight steps are staged during the last chunk of the current one), 40 k-steps per output pair instead of 54; float16 hi+lo "
-                     "split, 3 x v_mfma_f32_16x16x32_f16 per transformed product, fp32 accumulate; launches with Cin < 32, a long fused skip conv or small "
-                     "grids stay on the direct kernel conv3d_igemm_h3v3, listed as conv_k3s1_h2in / conv_k3s1_td4 / conv_k3s1_n32)")
+                     "split, 3 x v_mfma_f32_16x16x32_f16 per transformed product, fp32 accumulate; a fused 1x1 skip conv runs as a register-direct tail on the "
+                     "transformed tiles; launches with Cin < 32, partial bricks or grids too small even with the two-way Cin split stay on the direct "
+                     "kernel conv3d_igemm_h3v3, listed as conv_k3s1_td4 / conv_k3s1_n32 / conv_up)")
             peak, passes = PEAK_F16_MFMA_TFLOPS, round(3 * 40 / 54, 3)
         elif args.precision == "h3":
             kname = ("conv3d_igemm_h3v3<3, 1, 8, 4> (k3 stride-1 Conv3d with the fused norm+SiLU prologue, 8-slice bricks, free-running "
@@ -356,7 +358,7 @@ def main():
     if roofline is not None:
         import csv
         import glob
-        want = ("conv3d_igemm_h3w<1, false>" if roofline["kernel"].startswith("conv3d_igemm_h3w") else
+        want = ("conv3d_igemm_h3w<1>" if roofline["kernel"].startswith("conv3d_igemm_h3w") else
              "conv3d_igemm_h3v3<3, 1, 8, 4>" if "conv_k3s1" in per_kind else "conv3d_igemm_h3v3<3, 1, 4, 4>") if args.precision != "fp32" \
             else "conv3d_igemm_f32<4, 8, 8, 1, 3, 4, 1>"
         sig = f"batch={B} size={S} channels={Cc} norm={args.norm} precision={args.precision} csrc={csrc_digest()}"

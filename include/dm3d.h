@@ -215,7 +215,7 @@ int64_t dm3d_conv_scratch_bytes(const dm3d_conv_desc* d);
 /* Which tile form of the 16x16x32 conv kernels serves this descriptor: 8 (8 z-slices per brick, 512 threads, one workgroup per CU — launches
  * with enough bricks to give every CU two such workgroups in turn), 4 (4 slices, 256 threads, two workgroups per CU: small grids, the parity
  * form, launches with a fused skip conv, Cout <= 32), 10 (the Winograd-x form: wpk_wino given and eligible; conv3d_igemm_h3w<MODE>), 0 (another kernel).  Profiling
- * harnesses use it to name the instantiation a launch runs (rocprofv3 lists conv3d_igemm_h3v3<KS, MODE, TD, NCT> and conv3d_igemm_h3w<MODE, SKIP>). */
+ * harnesses use it to name the instantiation a launch runs (rocprofv3 lists conv3d_igemm_h3v3<KS, MODE, TD, NCT> and conv3d_igemm_h3w<MODE>). */
 int32_t dm3d_conv_tile_form(const dm3d_conv_desc* d);
 
 /* ---- Dense / einsum contractions: out[b][m][n] = act(alpha * sum_k A[b][m][k]*B[b][n][k] + bias) + res -------

@@ -60,7 +60,7 @@ PERSIST = [
 
 @pytest.mark.parametrize("case", PERSIST, ids=[c[0] for c in PERSIST])
 def test_persistent_winograd_item_lists(dev, monkeypatch, case):
-    """conv3d_igemm_h3w<MODE, false> with fewer workgroups than work items: every workgroup multiplies one item while it stages the next
+    """conv3d_igemm_h3w<MODE> with fewer workgroups than work items: every workgroup multiplies one item while it stages the next
     one's first image and weight steps, the epilogue of an item runs between two items' chunk loops (conditional_dm3d.py:254-268)."""
     from dm3d_amd import ops, _lib
     name, B, dims, c1, c2, cout, pro, res, grid = case

@@ -1,8 +1,8 @@
 #!/bin/bash
 # The end-of-round evidence run (one gpurun call): GPU tests, tools/profile_round.sh, then the bench lines that attach the fresh summaries.
-#   gpurun --timeout 1200 -- 'bash tools/final_round.sh r03'
+#   gpurun --timeout 1200 -- 'bash tools/final_round.sh r04'
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 export TMPDIR=/tmp
 out=$PWD/gpurun_out; mkdir -p $out
 timeout -k 10 1100 python3 -m pytest tests -x -q -m gpu > $out/${tag}_gpu_tests.log 2>&1 || { tail -40 $out/${tag}_gpu_tests.log; exit 1; }

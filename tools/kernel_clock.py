@@ -53,14 +53,15 @@ if what == "conv":
         s = s[s[:, 1] > 0]                            # the workgroups that stamped (blockIdx.y == 0, the first 4096)
         dt, dr = s[:, 28] - s[:, 1], s[:, 31] - s[:, 30]
         ok = dr > 0
+        f0 = (s[:, 0] > 0) & (s[:, 29] > 0)      # (stamp 0 = kernel entry: the first item of each persistent workgroup only)
         ghz = (dt[ok] / dr[ok] * 0.1)
         nch = cin // 16
         mfma_cycles = nch * 20 * 48 * 16 if wino else 2 * nch * 14 * 48 * 16          # (direct form: two waves per SIMD)
         fl = 2.0 * 27 * cin * cout * B * e ** 3
         print(f"{name}: {ms:.3f} ms {fl / ms / 1e9:.0f} TF/s algorithmic | in-kernel clock median {ghz.median():.3f} GHz (p10 {ghz.quantile(0.1):.3f}, p90 {ghz.quantile(0.9):.3f}) "
               f"| chunk loop {dt.median():.0f} ticks = {dr.median() / 100:.1f} us, MFMA duty in the loop {mfma_cycles / dt.median():.3f} "
-              f"| {s.shape[0]} workgroups stamped; whole workgroup {((s[:, 29] - s[:, 0])[s[:, 29] > 0]).median() if (s[:, 29] > 0).any() else 0:.0f} ticks "
-              f"(prologue {(s[:, 1] - s[:, 0]).median():.0f}, epilogue {((s[:, 29] - s[:, 28])[s[:, 29] > 0]).median() if (s[:, 29] > 0).any() else 0:.0f})", flush=True)
+              f"| {s.shape[0]} items stamped; first item of a workgroup {((s[:, 29] - s[:, 0])[f0]).median() if f0.any() else 0:.0f} ticks "
+              f"(prologue {((s[:, 1] - s[:, 0])[f0]).median() if f0.any() else 0:.0f}), epilogue {((s[:, 29] - s[:, 28])[s[:, 29] > 0]).median() if (s[:, 29] > 0).any() else 0:.0f}", flush=True)
         if wino: print(f"    epilogue stamps: accumulators -> LDS {(s[:, 20] - s[:, 28]).median():.0f}, slice 0 {(s[:, 21] - s[:, 20]).median():.0f}, slice 1 {((s[:, 29] - s[:, 21])[s[:, 29] > 0]).median():.0f} ticks", flush=True)
         rows_out.append((name, ms, fl / ms / 1e9, float(ghz.median()), float(ghz.quantile(0.1)), float(ghz.quantile(0.9)), mfma_cycles / float(dt.median())))
     (raw.dm3d_debug_set_stamps_wino if wino else raw.dm3d_debug_set_stamps_conv)(C.c_void_p(0))

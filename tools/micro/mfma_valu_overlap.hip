@@ -2,6 +2,8 @@
 // bounds 1), a loop of 16 independent v_mfma_f32_16x16x32_f16 with K independent instructions behind each (K = 0 .. 4; VALU v_fma_f32 on
 // private registers, or ds_read_b128), timed with s_memtime: cycles per MFMA.  If the shadow of an MFMA (16 cycles of matrix pipe, 4 of
 // issue) can hold the wave's other instructions, K <= 3 costs nothing; if the wave issues strictly serially, every instruction adds 4.
+// Round 4 (KIND 2): K ds_read_b128 per TWELVE MFMAs, spread evenly — the fragment-read ratios of the conv forms: 4 (the Winograd-x kernel and
+// the direct kernel: 16 reads per 48 MFMAs), 8 and 10 (what F(2,3) x F(2,3) tilings would need: 2 x 2 or 4 x 1 tiles per term and wave).
 // Build: hipcc --offload-arch=gfx950 -O3 -o mfma_valu_overlap mfma_valu_overlap.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -24,13 +26,18 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k(float* out, unsigned long lon
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
             asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[m]) : "v"(a), "v"(b));
+            if (KIND == 2) {                    // K reads per 12 MFMAs (16 MFMAs per iteration: the pattern runs over 48 = three iterations' worth of phase)
+                const int ph = m % 12;
+                if ((ph + 1) * K / 12 != ph * K / 12) asm volatile("ds_read_b128 %0, %1" : "=v"(r[m & 3]) : "v"(la));
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(x[j]));
                 else asm volatile("ds_read_b128 %0, %1" : "=v"(r[j]) : "v"(la));
             }
         }
-        if (KIND == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (KIND >= 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0.f;
@@ -49,6 +56,13 @@ static void run(float* out, unsigned long long* clk) {
     (void)hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost);
     unsigned long long s = 0;
     for (int i = 0; i < 256; ++i) s += h[i];
+    if (KIND == 2) {
+        int reads = 0;
+        for (int m = 0; m < 16; ++m) { const int ph = m % 12; reads += (ph + 1) * K / 12 != ph * K / 12; }
+        printf("waves per SIMD %d, ds_read_b128 x %d per 12 MFMAs (%d reads per 16-MFMA iteration = %.2f per MFMA): %.2f cycles per MFMA per wave\n", WAVES / 4, K,
+               reads, reads / 16.0, (double)s / 256.0 / (iters * 16.0));
+        return;
+    }
     printf("waves per SIMD %d, %s x %d per MFMA: %.0f shader cycles (s_memtime) ... %.2f cycles per MFMA per wave\n", WAVES / 4, KIND ? "ds_read_b128" : "v_fma_f32", K,
            (double)s / 256.0, (double)s / 256.0 / (iters * 16.0));
 }
@@ -59,5 +73,6 @@ int main() {
     run<0, 0, 4>(out, clk); run<1, 0, 4>(out, clk); run<2, 0, 4>(out, clk); run<3, 0, 4>(out, clk); run<4, 0, 4>(out, clk);
     run<1, 1, 4>(out, clk); run<2, 1, 4>(out, clk);
     run<0, 0, 8>(out, clk); run<2, 0, 8>(out, clk); run<4, 0, 8>(out, clk); run<2, 1, 8>(out, clk);
+    run<4, 2, 4>(out, clk); run<6, 2, 4>(out, clk); run<8, 2, 4>(out, clk); run<10, 2, 4>(out, clk); run<12, 2, 4>(out, clk);
     return 0;
 }
