@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DM3D_LIB") or os.path.join(_HERE, "csrc", "libdm3d_hip.so")     # DM3D_LIB: A/B builds (tools)
 
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
-ABI_VERSION = 109                   # DM3D_VERSION of include/dm3d.h these ctypes mirrors were written against
+ABI_VERSION = 110                   # DM3D_VERSION of include/dm3d.h these ctypes mirrors were written against
 PREC_F32, PREC_H3 = 0, 1
 WL_TAP, WL_PAIR = 0, 1
 FMT_F32, FMT_H2 = 0, 1
@@ -59,6 +59,25 @@ class MlpDesc(C.Structure):
         ("w1", C.c_void_p), ("b1", _f32p),
         ("res", _f32p), ("res2", _f32p), ("ldr", C.c_int64),
         ("out", C.c_void_p), ("ldo", C.c_int64), ("out_fmt", C.c_int32),
+        ("m", C.c_int32), ("units", C.c_int32),
+        ("range_flag", C.c_void_p), ("range_limit", C.c_float),
+        ("w2", C.c_void_p), ("b2", _f32p), ("res3", _f32p), ("ldr3", C.c_int64),
+    ]
+
+
+class AttnFrontDesc(C.Structure):
+    _fields_ = [
+        ("x", _f32p), ("ldx", C.c_int64),
+        ("w_in", C.c_void_p), ("b_in", _f32p),
+        ("w_qk", C.c_void_p), ("b_qk", _f32p),
+        ("w_v", C.c_void_p), ("b_v", _f32p),
+        ("g1", _f32p), ("be1", _f32p), ("g2", _f32p), ("be2", _f32p), ("g3", _f32p), ("be3", _f32p),
+        ("eps", C.c_float),
+        ("y", _f32p), ("ldy", C.c_int64),
+        ("qk", C.c_void_p), ("ldqk", C.c_int64),
+        ("vt", C.c_void_p), ("ldvt", C.c_int64),
+        ("q2", C.c_void_p), ("ldq2", C.c_int64),
+        ("n3", C.c_void_p), ("ldn3", C.c_int64),
         ("m", C.c_int32), ("units", C.c_int32),
         ("range_flag", C.c_void_p), ("range_limit", C.c_float),
     ]
@@ -126,6 +145,8 @@ SIGNATURES = {
     "dm3d_gemm_tn_group": (C.c_int, [C.POINTER(GemmDesc), C.c_int32, C.c_void_p]),
     "dm3d_mlp_fused": (C.c_int, [C.POINTER(MlpDesc), C.c_void_p]),
     "dm3d_pack_mlp_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "dm3d_attn_front": (C.c_int, [C.POINTER(AttnFrontDesc), C.c_void_p]),
+    "dm3d_pack_front_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "dm3d_split_h2": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "dm3d_layernorm3_h2": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_float] + [_f32p] * 9 + [C.c_void_p]),
     "dm3d_softmax_rows_h2": (C.c_int, [_f32p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]),

@@ -46,6 +46,8 @@ struct MlpArgs {
     void* out; long ldo; int out_h2;
     int m;
     int* range_flag; float range_limit;
+    const void* w2; const float* b2;            // optional tail: out = relu(W2 . a3 + b2) + res3 with a3 = the MLP's result (never stored)
+    const float* res3; long ldr3;
 };
 
 template <int N, int I = 0, class F>
@@ -61,7 +63,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3(const MlpArgs p) {
     constexpr int HID = 4 * U, TM = 64, HS = 128, NSLAB = HID / HS;
     constexpr int KR = U / 16;                                  // records per x / W0 row (16)
     constexpr int HR = HS / 16;                                 // records of a slab's hidden columns (8)
+    constexpr int T_RS = TM * 64 + 32;                          // record stride of the tail's a3 image (16 records: 66 048 bytes)
     static_assert(U == 256, "built for the U-Net's attention width");
+    static_assert(16 * T_RS <= 64 * 1040, "the tail's a3 image overlays the x staging area");
 
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_m[];
     _Float16* lds_h = smem_m;                                   // [8 records][64 rows][REC]   32 KB (the x staging area of the prologue overlays it: 65 KB)
@@ -115,7 +119,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3(const MlpArgs p) {
     // MFMA in it — DM3D_MFMA_DRAIN stands in front of every vector read of an accumulator.
 #define DM3D_MFMA_VX(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
 #define DM3D_MFMA_VV(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
-#define DM3D_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
+// (alone between two scheduling barriers: hipcc otherwise places VALU instructions — address arithmetic of the loads that follow — between the
+// last MFMA and the drain, and one of them may write a register that MFMA still reads as an operand: on gfx950 the K = 16 MFMA reads its
+// operands over several passes, and behind an asm MFMA hipcc's hazard pass inserts nothing; found in dm3d_attn_front_h3.hip)
+#define DM3D_MFMA_DRAIN() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
     f32x16 acc_out[2][2];                                       // [row tile mr][column tile nr]: lane = row 32 mr + l32, register r = column 32 nr + (r & 3) + 8 (r >> 2) + 4 half of the wave's 64
 #pragma unroll
@@ -255,8 +262,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3(const MlpArgs p) {
         });
     }
     MSTAMP(14);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the redundant tail loads
     DM3D_MFMA_DRAIN();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the redundant tail loads
+    if (p.w2) lds_barrier();                                    // the tail's a3 image overlays the H slab: every wave must be past its last phase-2 read
 
     // ---- epilogue: + b1 + res + res2 -> float32 or DM3D_FMT_H2.  Lane (l32, half) holds row 32 mr + l32 and, per group gq of four
     // registers, columns n0 .. n0 + 3, n0 = 64 w + 32 nr + 8 gq + 4 half: 16-byte residual loads and stores (H2: 8 + 8 bytes).  Every load is
@@ -288,7 +296,17 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3(const MlpArgs p) {
                     o[j] = ((acc_out[mr][nr][4 * gq + j] + bv[nr][gq][j]) + (has_r ? rv[nr][gq][j] : 0.0f)) + (has_r2 ? rv2[nr][gq][j] : 0.0f);
                     DM3D_AMAX(amax, o[j]);
                 }
-                if (row < p.m) {
+                if (p.w2) {
+                    // the tail's B operand: this row's four columns as H2 into the LDS image [record][row][64 B] (record stride 4 KB + 32 B,
+                    // slots XOR-swizzled by the row: dm3d_attn_front_h3.hip's layout).  Rows past m hold the last row's values: never stored.
+                    unsigned int h0, l0, h1, l1;
+                    split2(__builtin_amdgcn_fmed3f(o[0], -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(o[1], -65504.0f, 65504.0f), h0, l0);
+                    split2(__builtin_amdgcn_fmed3f(o[2], -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(o[3], -65504.0f, 65504.0f), h1, l1);
+                    const int r = mr * 32 + l32, sw = (r >> 2) & 3, slot = (n0 >> 3) & 1;
+                    char* rp = reinterpret_cast<char*>(smem_m) + (n0 >> 4) * T_RS + r * 64 + (n0 & 7) * 2;
+                    *reinterpret_cast<u32x2*>(rp + ((slot ^ sw) << 4)) = u32x2{h0, h1};
+                    *reinterpret_cast<u32x2*>(rp + (((2 + slot) ^ sw) << 4)) = u32x2{l0, l1};
+                } else if (row < p.m) {
                     if (p.out_h2) {
                         unsigned int h0, l0, h1, l1;
                         split2(__builtin_amdgcn_fmed3f(o[0], -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(o[1], -65504.0f, 65504.0f), h0, l0);
@@ -302,6 +320,75 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3(const MlpArgs p) {
                     }
                 }
             }
+    }
+    // ---- optional tail (the block's proj_out, conditional_dm3d.py:195: Conv3D(units, 1, relu) on a3, + the block input): one more K = 256
+    // product in the phase-2 form — weights as pre-tiled fragments (dm3d_pack_front_weights) by plain loads, a3 from the LDS image above
+    if (p.w2) {
+        lds_barrier();                                          // (every wave is past its last H read; the a3 image is complete)
+        const char* w2_lane = static_cast<const char*>(p.w2) + (size_t)wave * (KR * 4 * 1024) + lane * 16;
+        auto load_t = [&](const int set, const int g) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) wa[set][t] = *reinterpret_cast<const h8*>(w2_lane + (size_t)(g < KR / 2 ? g : KR / 2 - 1) * 8192 + t * 1024);
+        };
+        load_t(0, 0);
+#pragma unroll
+        for (int mr = 0; mr < 2; ++mr)
+#pragma unroll
+            for (int nr = 0; nr < 2; ++nr)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_out[mr][nr][r] = 0.0f;
+        static_for<KR / 2>([&](auto G_) {
+            constexpr int g = decltype(G_)::value, set = g & 1;
+            load_t(set ^ 1, g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int kk = 2 * g + i;
+                h8 ah[2], al[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    ah[t] = *reinterpret_cast<const h8*>(lds_hc + kk * T_RS + a2_off[t]);
+                    al[t] = *reinterpret_cast<const h8*>(lds_hc + kk * T_RS + (a2_off[t] ^ 32u));
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) DM3D_MFMA_VV(acc_out[t >> 1][t & 1], wa[set][4 * i + 2 * (t & 1)], al[t >> 1]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) DM3D_MFMA_VV(acc_out[t >> 1][t & 1], wa[set][4 * i + 2 * (t & 1) + 1], ah[t >> 1]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) DM3D_MFMA_VV(acc_out[t >> 1][t & 1], wa[set][4 * i + 2 * (t & 1)], ah[t >> 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        DM3D_MFMA_DRAIN();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool has_r3 = p.res3 != nullptr;
+#pragma unroll
+        for (int mr = 0; mr < 2; ++mr) {
+            const int row = m0 + mr * 32 + l32;
+            const size_t rrow = (size_t)(row < p.m ? row : p.m - 1);
+            f32x4 rv[2][4], bv[2][4];
+#pragma unroll
+            for (int nr = 0; nr < 2; ++nr)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int n0 = wave * 64 + nr * 32 + 8 * gq + 4 * half;
+                    bv[nr][gq] = *reinterpret_cast<const f32x4*>(p.b2 + n0);
+                    rv[nr][gq] = *reinterpret_cast<const f32x4*>(has_r3 ? p.res3 + rrow * p.ldr3 + n0 : p.b2 + n0);
+                }
+#pragma unroll
+            for (int nr = 0; nr < 2; ++nr)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int n0 = wave * 64 + nr * 32 + 8 * gq + 4 * half;
+                    f32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = fmaxf(acc_out[mr][nr][4 * gq + j] + bv[nr][gq][j], 0.0f) + (has_r3 ? rv[nr][gq][j] : 0.0f);
+                        DM3D_AMAX(amax, o[j]);
+                    }
+                    if (row < p.m) *reinterpret_cast<f32x4*>(static_cast<char*>(p.out) + ((size_t)row * p.ldo + n0) * 4) = o;
+                }
+        }
     }
     if (p.range_flag && amax > p.range_limit) *p.range_flag = 1;
     MSTAMP(15);
@@ -357,6 +444,12 @@ extern "C" int dm3d_mlp_fused(const dm3d_mlp_desc* d, void* stream) {
     a.x = d->x; a.ldx = d->ldx; a.w0 = d->w0; a.b0 = d->b0; a.w1 = d->w1; a.b1 = d->b1;
     a.res = d->res; a.res2 = d->res2; a.ldr = d->ldr; a.out = d->out; a.ldo = d->ldo; a.out_h2 = d->out_fmt == DM3D_FMT_H2;
     a.m = d->m; a.range_flag = d->range_flag; a.range_limit = d->range_limit > 0.0f ? d->range_limit : 65504.0f;
+    if (d->w2) {
+        DM3D_REQUIRE(d->b2 && dm3d_aligned16(d->w2) && dm3d_aligned16(d->b2), "mlp_fused: the tail needs w2 and b2, 16-byte aligned");
+        DM3D_REQUIRE(d->out_fmt == DM3D_FMT_F32, "mlp_fused: with a tail (w2) the output is float32");
+        DM3D_REQUIRE(!d->res3 || (d->ldr3 >= d->units && d->ldr3 % 4 == 0 && dm3d_aligned16(d->res3)), "mlp_fused: res3 needs ldr3 >= units, ldr3 %% 4 == 0, 16-byte alignment");
+        a.w2 = d->w2; a.b2 = d->b2; a.res3 = d->res3; a.ldr3 = d->ldr3;
+    }
     constexpr size_t lds = 64 * 1040;                       // the x staging area of the prologue; the H slab (32 KB) overlays it afterwards
     static bool attr_set[64] = {false};
     int dev = 0;

@@ -349,10 +349,43 @@ def pack_mlp_weights(w_h2: torch.Tensor, units: int, which: int) -> torch.Tensor
     return out
 
 
+def pack_front_weights(w_h2: torch.Tensor, n: int, units: int = 256) -> torch.Tensor:
+    """DM3D_FMT_H2 weight rows W[n][units] (split_h2 of the [n, units] float32 weight) -> the operand-fragment image dm3d_attn_front reads."""
+    out = torch.empty_like(w_h2)
+    check(lib().dm3d_pack_front_weights(w_h2.data_ptr(), n, units, out.data_ptr(), _st()), "pack_front_weights")
+    return out
+
+
+def attn_front(x: torch.Tensor, w_in_t: torch.Tensor, b_in: torch.Tensor, w_qk_t: torch.Tensor, b_qk: torch.Tensor, w_v_t: torch.Tensor,
+               b_v: torch.Tensor, norms, eps: float = 1e-3):
+    """The front half of a CrossAttentionBlock in one launch (dm3d_attn_front; conditional_dm3d.py:186-193, 163-170): x [m, 256] float32,
+    weights from pack_front_weights, norms = ((g1, b1), (g2, b2), (g3, b3)).  Returns y [m, 256] float32 and the DM3D_FMT_H2 buffers
+    qk [m, 512], v_t [256, m], q2 [m, 256], n3 [m, 256] (decode with h2_to_f32)."""
+    from ._lib import AttnFrontDesc
+    _f32c(x, "x")
+    m, u = x.shape
+    dev = x.device
+    y = torch.empty(m, u, dtype=torch.float32, device=dev)
+    qk, v_t = torch.empty(m, 2 * u, dtype=torch.float32, device=dev), torch.empty(u, m, dtype=torch.float32, device=dev)
+    q2, n3 = torch.empty(m, u, dtype=torch.float32, device=dev), torch.empty(m, u, dtype=torch.float32, device=dev)
+    d = AttnFrontDesc()
+    d.x, d.ldx = x.data_ptr(), u
+    d.w_in, d.b_in, d.w_qk, d.b_qk, d.w_v, d.b_v = w_in_t.data_ptr(), b_in.data_ptr(), w_qk_t.data_ptr(), b_qk.data_ptr(), w_v_t.data_ptr(), b_v.data_ptr()
+    (g1, b1), (g2, b2), (g3, b3) = norms
+    d.g1, d.be1, d.g2, d.be2, d.g3, d.be3 = g1.data_ptr(), b1.data_ptr(), g2.data_ptr(), b2.data_ptr(), g3.data_ptr(), b3.data_ptr()
+    d.eps = eps
+    d.y, d.ldy, d.qk, d.ldqk, d.vt, d.ldvt, d.q2, d.ldq2, d.n3, d.ldn3 = y.data_ptr(), u, qk.data_ptr(), 2 * u, v_t.data_ptr(), m, q2.data_ptr(), u, n3.data_ptr(), u
+    d.m, d.units = m, u
+    check(lib().dm3d_attn_front(C.byref(d), _st()), "attn_front")
+    return y, qk, v_t, q2, n3
+
+
 def mlp_fused(x_h2: torch.Tensor, w0_t: torch.Tensor, b0: torch.Tensor, w1_t: torch.Tensor, b1: torch.Tensor, units: int,
-              res: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None, out_h2: bool = False) -> torch.Tensor:
+              res: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None, out_h2: bool = False,
+              tail=None) -> torch.Tensor:
     """Dense(units)(relu(Dense(4 units)(x))) + res + res2 in one launch (dm3d_mlp_fused): x [m, units] as a DM3D_FMT_H2 buffer (split_h2),
-    w0_t / w1_t from pack_mlp_weights, biases / residuals float32.  Returns [m, units] float32, or a DM3D_FMT_H2 buffer with ``out_h2``."""
+    w0_t / w1_t from pack_mlp_weights, biases / residuals float32.  Returns [m, units] float32, or a DM3D_FMT_H2 buffer with ``out_h2``.
+    ``tail = (w2_t, b2, res3)`` (w2_t from pack_front_weights; res3 may be None): returns relu(Dense_2(that)) + res3 instead (float32)."""
     from ._lib import MlpDesc
     m = x_h2.numel() // units
     out = torch.empty(m, units, dtype=torch.float32, device=x_h2.device)
@@ -360,5 +393,8 @@ def mlp_fused(x_h2: torch.Tensor, w0_t: torch.Tensor, b0: torch.Tensor, w1_t: to
     d.x, d.ldx, d.w0, d.b0, d.w1, d.b1 = x_h2.data_ptr(), units, w0_t.data_ptr(), b0.data_ptr(), w1_t.data_ptr(), b1.data_ptr()
     d.res, d.res2, d.ldr = _p(res), _p(res2), units
     d.out, d.ldo, d.out_fmt, d.m, d.units = out.data_ptr(), units, (_lib.FMT_H2 if out_h2 else _lib.FMT_F32), m, units
+    if tail is not None:
+        w2_t, b2, res3 = tail
+        d.w2, d.b2, d.res3, d.ldr3 = w2_t.data_ptr(), b2.data_ptr(), _p(res3), units
     check(lib().dm3d_mlp_fused(C.byref(d), _st()), "mlp_fused")
     return out

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, ConvDesc, GemmDesc, MlpDesc, check, lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, AttnFrontDesc, ConvDesc, GemmDesc, MlpDesc, check, lib
 from .betas import time_embedding_table
 from .weights import UNetConfig, keras_init_weights, upsample_parity_kernels, walk
 
@@ -307,6 +307,8 @@ class UNet:
                     w.tiled = torch.empty_like(w.h2)
                     check(lib().dm3d_pack_mlp_weights(w.h2.data_ptr(), u, i, w.tiled.data_ptr(), _stream()), "pack_mlp_weights")
             P[f"{n}.key"] = self._pack(s[f"{n}.key.kernel"], s[f"{n}.key.bias"])
+            P[f"{n}.proj_in"].ftiled = self._front_tiles(P[f"{n}.proj_in"], u, u)
+            P[f"{n}.proj_out"].ftiled = self._front_tiles(P[f"{n}.proj_out"], u, u)
         else:
             P[f"{n}.norm"] = self._fold_bn(f"{n}.norm")
             P[f"{n}.proj"] = self._with_h2(self._pack(s[f"{n}.proj.kernel"], s[f"{n}.proj.bias"]))
@@ -314,6 +316,16 @@ class UNet:
         P[f"{n}.qk"] = self._with_h2(self._pack(np.concatenate([s[f"{n}.query.kernel"], s[f"{n}.key.kernel"]], axis=1),
                                                 np.concatenate([s[f"{n}.query.bias"], s[f"{n}.key.bias"]])))
         P[f"{n}.value"] = self._with_h2(self._pack(s[f"{n}.value.kernel"], s[f"{n}.value.bias"]))
+        if self.cfg.conditional:                                               # operand-fragment images for dm3d_attn_front (u = 256 only)
+            P[f"{n}.qk"].ftiled = self._front_tiles(P[f"{n}.qk"], 2 * u, u)
+            P[f"{n}.value"].ftiled = self._front_tiles(P[f"{n}.value"], u, u)
+
+    def _front_tiles(self, w, n_rows: int, u: int):
+        if getattr(w, "h2", None) is None or u != 256 or w.cin_pad != u or w.h2.numel() < n_rows * u:
+            return None
+        t = torch.empty(n_rows * u, dtype=torch.float32, device=self.device)
+        check(lib().dm3d_pack_front_weights(w.h2.data_ptr(), n_rows, u, t.data_ptr(), _stream()), "pack_front_weights")
+        return t
 
     def _gemm_now(self, **kw):
         d = _gemm_desc(**kw)
@@ -504,7 +516,7 @@ class Plan:
             self.range_limit = net._h3_range_limit(winograd=True)
             for d in self._keep:
                 for one in (d if isinstance(d, C.Array) else (d,)):
-                    if isinstance(one, (ConvDesc, GemmDesc, MlpDesc)) and one.range_flag:
+                    if isinstance(one, (ConvDesc, GemmDesc, MlpDesc, AttnFrontDesc)) and one.range_flag:
                         one.range_limit = self.range_limit
         # one workspace for every conv that can split its Cin range (dm3d_conv_scratch_bytes): launches are stream-ordered
         need = max([lib().dm3d_conv_scratch_bytes(C.byref(d)) for d in self._keep if isinstance(d, ConvDesc)] + [0])
@@ -823,27 +835,53 @@ class Plan:
         hh = dict(h3=True, a_h2=True, b_h2=True)
         y = self._buf(M, u)                                                   # relu(proj_in(norm(x))), float32
         xin = self._group_normed(n, x, u, edge) if self.net.cfg.norm == "group" else x      # BatchNorm is folded into proj_in
-        self._gemm(a=xin, lda=u, b=pin.h2, ldb=pin.cin_pad, out=y, ldo=u, m=M, n=u, k=u, bias=pin.bias, act=ACT_RELU,
-                   h3=True, b_h2=True)
-        n1, n2, n3 = self._buf(M, u), self._buf(M, u), self._buf(M, u)
         (g1, b1), (g2, b2), (g3, b3) = P[f"{n}.ln1"], P[f"{n}.ln2"], P[f"{n}.ln3"]
         self._keep += [g1, b1, g2, b2, g3, b3]
-        self.ops.append((lib().dm3d_layernorm3_h2, (y.data_ptr(), M, u, LN_EPS, g1.data_ptr(), b1.data_ptr(), n1.data_ptr(),
-                                                    g2.data_ptr(), b2.data_ptr(), n2.data_ptr(), g3.data_ptr(), b3.data_ptr(),
-                                                    n3.data_ptr()), "layernorm", {}))
+        # proj_in + the three LayerNormalizations + the q|k, v^T, q2 projections as ONE launch (dm3d_attn_front, round 4): y, n1, n2 stay on the
+        # CU.  Same shape rule as the fused MLP (u = 256, enough 64-row tiles to fill the chip); otherwise the three launches below.
+        front = (u == 256 and M % 64 == 0 and M >= 64 * 128 and all(getattr(w, "ftiled", None) is not None for w in (pin, qk, val))
+                 and os.environ.get("DM3D_ATTN_FRONT", "1") != "0")
+        n3 = self._buf(M, u)
+        if front:
+            qkb, v_t, q2 = self._buf(M, 2 * u), self._buf(u, M), self._buf(M, u)
+            fd = AttnFrontDesc()
+            fd.x, fd.ldx = _ptr(xin), u
+            fd.w_in, fd.b_in, fd.w_qk, fd.b_qk, fd.w_v, fd.b_v = (pin.ftiled.data_ptr(), _ptr(pin.bias), qk.ftiled.data_ptr(), _ptr(qk.bias),
+                                                                  val.ftiled.data_ptr(), _ptr(val.bias))
+            fd.g1, fd.be1, fd.g2, fd.be2, fd.g3, fd.be3 = g1.data_ptr(), b1.data_ptr(), g2.data_ptr(), b2.data_ptr(), g3.data_ptr(), b3.data_ptr()
+            fd.eps = LN_EPS
+            fd.y, fd.ldy, fd.qk, fd.ldqk, fd.vt, fd.ldvt, fd.q2, fd.ldq2, fd.n3, fd.ldn3 = _ptr(y), u, _ptr(qkb), 2 * u, _ptr(v_t), M, _ptr(q2), u, _ptr(n3), u
+            fd.m, fd.units = M, u
+            if self.range_flag is not None:
+                fd.range_flag, fd.range_limit = self.range_flag.data_ptr(), self.range_limit
+            self._keep.append(fd)
+            self.ops.append((lib().dm3d_attn_front, (C.byref(fd),), "attn_front",
+                             {"desc": f"attn_front m={M} u={u} (proj_in + 3 LayerNorm + q|k, v^T, q2)", "flops": 2.0 * M * u * 5 * u,
+                              "bufs": {"x": xin, "y": y, "qk": qkb, "v_t": v_t, "q2": q2, "n3": n3}}))
+        else:
+            self._gemm(a=xin, lda=u, b=pin.h2, ldb=pin.cin_pad, out=y, ldo=u, m=M, n=u, k=u, bias=pin.bias, act=ACT_RELU,
+                       h3=True, b_h2=True)
+            n1, n2 = self._buf(M, u), self._buf(M, u)
+            self.ops.append((lib().dm3d_layernorm3_h2, (y.data_ptr(), M, u, LN_EPS, g1.data_ptr(), b1.data_ptr(), n1.data_ptr(),
+                                                        g2.data_ptr(), b2.data_ptr(), n2.data_ptr(), g3.data_ptr(), b3.data_ptr(),
+                                                        n3.data_ptr()), "layernorm", {}))
         # the MLP (Dense(4u, relu) -> Dense(u), :132-133) as ONE launch with the hidden activation in LDS (dm3d_mlp_fused, round 4) where the
         # kernel's shape fits (u = 256 and enough row tiles to fill the chip); otherwise its first Dense joins the grouped launch below
         mlp_fused = u == 256 and M >= 64 * 128 and getattr(m0, "tiled", None) is not None and os.environ.get("DM3D_MLP_FUSED", "1") != "0"
-        qkb, v_t, q2 = self._buf(M, 2 * u), self._buf(u, M), self._buf(M, u)
         hid = None if mlp_fused else self._buf(M, 4 * u)
-        self._gemm_group([
-            dict(a=n1, lda=u, b=qk.h2, ldb=qk.cin_pad, out=qkb, ldo=2 * u, m=M, n=2 * u, k=u, bias=qk.bias, out_h2=True, **hh),
-            dict(a=val.h2, lda=val.cin_pad, b=n1, ldb=u, out=v_t, ldo=M, m=u, n=M, k=u, bias=val.bias, bias_along_m=1,
-                 out_h2=True, **hh),
-            dict(a=n2, lda=u, b=qk.h2, ldb=qk.cin_pad, out=q2, ldo=u, m=M, n=u, k=u, bias=qk.bias, out_h2=True, **hh),
-        ] + ([] if mlp_fused else [
-            dict(a=n3, lda=u, b=m0.h2, ldb=m0.cin_pad, out=hid, ldo=4 * u, m=M, n=4 * u, k=u, bias=m0.bias, act=ACT_RELU,
-                 out_h2=True, **hh)]))
+        group = []
+        if not front:
+            qkb, v_t, q2 = self._buf(M, 2 * u), self._buf(u, M), self._buf(M, u)
+            group += [
+                dict(a=n1, lda=u, b=qk.h2, ldb=qk.cin_pad, out=qkb, ldo=2 * u, m=M, n=2 * u, k=u, bias=qk.bias, out_h2=True, **hh),
+                dict(a=val.h2, lda=val.cin_pad, b=n1, ldb=u, out=v_t, ldo=M, m=u, n=M, k=u, bias=val.bias, bias_along_m=1,
+                     out_h2=True, **hh),
+                dict(a=n2, lda=u, b=qk.h2, ldb=qk.cin_pad, out=q2, ldo=u, m=M, n=u, k=u, bias=qk.bias, out_h2=True, **hh)]
+        if not mlp_fused:
+            group.append(dict(a=n3, lda=u, b=m0.h2, ldb=m0.cin_pad, out=hid, ldo=4 * u, m=M, n=4 * u, k=u, bias=m0.bias, act=ACT_RELU,
+                              out_h2=True, **hh))
+        if group:
+            self._gemm_group(group)
         rows = B if self.per_sample_context else 1
         kctx, vctx_t = self._buf(rows, L * u), self._buf(rows, u * L)
         self.ctx_bufs[n] = (kctx, vctx_t)
@@ -866,7 +904,8 @@ class Plan:
                 d.batch, d.lq, d.lk, d.c, d.scale, d.precision, d.fmt = B, L, L, u, scale, _lib.PREC_H3, _lib.FMT_H2
             self._keep.append(descs)
             self.ops.append((lib().dm3d_attention_group, (descs, 2, None), "attn_fused",
-                             {"desc": f"attn_fused 2 passes B={B} L={L} c={u}", "flops": 2 * 2 * 2.0 * B * L * L * u}))
+                             {"desc": f"attn_fused 2 passes B={B} L={L} c={u}", "flops": 2 * 2 * 2.0 * B * L * L * u,
+                              "bufs": {"a1": a1, "a2": a2}}))
         else:
             scores = self._buf(2, B, L, L)
             s2 = B * L * L                                                        # element offset of the cross-attention scores
@@ -883,22 +922,32 @@ class Plan:
                 dict(a=scores, a_off=s2, lda=L, stride_a=L * L, b=vctx_t, ldb=L, stride_b=vs, out=a2, ldo=u, stride_o=L * u,
                      m=L, n=u, k=L, batch=B, **hh),
             ])
-        a3 = self._buf(M, u)
+        # ... and the block's proj_out (Conv3D(units, 1, relu) + the block input, :195) as a tail of the same launch: a3 never leaves the CU
+        tail = mlp_fused and getattr(pout, "ftiled", None) is not None and os.environ.get("DM3D_MLP_TAIL", "1") != "0"
+        out = self._buf(B, edge, edge, edge, u)
+        a3 = None if tail else self._buf(M, u)
         if mlp_fused:
             d = MlpDesc()
             d.x, d.ldx, d.w0, d.b0, d.w1, d.b1 = _ptr(n3), u, m0.tiled.data_ptr(), _ptr(m0.bias), m1.tiled.data_ptr(), _ptr(m1.bias)
-            d.res, d.res2, d.ldr, d.out, d.ldo, d.out_fmt, d.m, d.units = _ptr(a1), _ptr(a2), u, _ptr(a3), u, _lib.FMT_H2, M, u
+            d.res, d.res2, d.ldr, d.m, d.units = _ptr(a1), _ptr(a2), u, M, u
+            if tail:
+                d.out, d.ldo, d.out_fmt = _ptr(out), u, _lib.FMT_F32
+                d.w2, d.b2, d.res3, d.ldr3 = pout.ftiled.data_ptr(), _ptr(pout.bias), _ptr(x), u
+            else:
+                d.out, d.ldo, d.out_fmt = _ptr(a3), u, _lib.FMT_H2
             if self.range_flag is not None:
                 d.range_flag, d.range_limit = self.range_flag.data_ptr(), self.range_limit
             self._keep.append(d)
             self.ops.append((lib().dm3d_mlp_fused, (C.byref(d),), "mlp_fused",
-                             {"desc": f"mlp_fused m={M} u={u} hidden={4 * u}", "flops": 2 * 2.0 * M * u * 4 * u}))
+                             {"desc": f"mlp_fused m={M} u={u} hidden={4 * u}" + (" + proj_out" if tail else ""),
+                              "flops": 2 * 2.0 * M * u * 4 * u + (2.0 * M * u * u if tail else 0.0),
+                              "bufs": {"out": out if tail else a3}}))
         else:
             self._gemm(a=hid, lda=4 * u, b=m1.h2, ldb=m1.cin_pad, out=a3, ldo=u, m=M, n=u, k=4 * u, bias=m1.bias, res=a1, res2=a2,
                        ldr=u, out_h2=True, **hh)
-        out = self._buf(B, edge, edge, edge, u)
-        self._gemm(a=a3, lda=u, b=pout.h2, ldb=pout.cin_pad, out=out, ldo=u, m=M, n=u, k=u, bias=pout.bias, act=ACT_RELU,
-                   res=x, ldr=u, **hh)
+        if not tail:
+            self._gemm(a=a3, lda=u, b=pout.h2, ldb=pout.cin_pad, out=out, ldo=u, m=M, n=u, k=u, bias=pout.bias, act=ACT_RELU,
+                       res=x, ldr=u, **hh)
         return out
 
     def _self_block(self, blk, x, edge):
@@ -945,7 +994,7 @@ class Plan:
                                              buf.shape[1], st), "gather_rows")
 
     _RANGE_OF = {"conv_wino": "conv", "conv_wino_h2in": "conv", "conv_k3s1_td4": "conv", "conv_k1": "conv", "conv_k3s2": "conv", "conv_up": "conv", "conv_k3s1_n32": "conv", "conv_k3s1_h2in": "conv", "conv_k3s1": "conv",
-                 "gemm": "attn", "gemm_h3": "attn", "mlp_fused": "attn", "attn_fused": "attn", "softmax": "attn", "layernorm": "attn", "groupnorm": "norm", "affine": "norm",
+                 "gemm": "attn", "gemm_h3": "attn", "mlp_fused": "attn", "attn_front": "attn", "attn_fused": "attn", "softmax": "attn", "layernorm": "attn", "groupnorm": "norm", "affine": "norm",
                  "range": "guard"}
 
     def run(self, stream: Optional[int] = None):

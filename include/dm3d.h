@@ -21,10 +21,10 @@
 extern "C" {
 #endif
 
-#define DM3D_VERSION 109          /* major*100 + minor; the descriptor structs grew in 101 (w_layout), 102 (scratch), 103 (skip_*),
+#define DM3D_VERSION 110          /* major*100 + minor; the descriptor structs grew in 101 (w_layout), 102 (scratch), 103 (skip_*),
                                      104 (dm3d_attention), 105 (x1_fmt / out_fmt / post_*), 106 (ddpm seed_dev; conv/gemm range_flag; the
                                      training entries), 107 (conv wpk_f8: a float8 cross-term form, removed again in 109), 108 (conv wpk_wino: the Winograd-x form), 109 (wpk_f8 and
-                                     dm3d_pack_weights_h3f8 are gone; the Winograd-x image pairs its taps differently; dm3d_mlp_fused; conv skip_wpk_frag, gn_stats; dm3d_groupnorm_finalize2): a host built against an older header must be rebuilt */
+                                     dm3d_pack_weights_h3f8 are gone; the Winograd-x image pairs its taps differently; dm3d_mlp_fused; conv skip_wpk_frag, gn_stats; dm3d_groupnorm_finalize2), 110 (dm3d_attn_front): a host built against an older header must be rebuilt */
 
 #define DM3D_OK            0
 #define DM3D_EINVAL       -1      /* bad argument (shape, alignment, null pointer) */
@@ -261,8 +261,40 @@ typedef struct dm3d_mlp_desc {
     void* out; int64_t ldo; int32_t out_fmt;
     int32_t m, units;
     int32_t* range_flag; float range_limit;                /* as in dm3d_gemm_desc */
+    /* optional tail (ABI 110): out = relu(W2 . a3 + b2) + res3 with a3 = the result above, which is then NOT stored (out is float32
+     * [m][units]) — the block's proj_out and its residual add (conditional_dm3d.py:195).  w2: dm3d_pack_front_weights image of W2[units][units] */
+    const void* w2; const float* b2;
+    const float* res3; int64_t ldr3;
 } dm3d_mlp_desc;
 int dm3d_mlp_fused(const dm3d_mlp_desc* d, void* stream);
+
+/* ---- front half of a CrossAttentionBlock in one launch (csrc/dm3d_attn_front_h3.hip; reference networks/conditional_dm3d.py:186-193,
+ * 163-170):  y = relu(x . W_in^T + b_in)  (float32 out: the residual of the self-attention pass; an inference BatchNormalization in front
+ * is folded into W_in / b_in by the caller),  n_i = LayerNormalization_i(y) for the block's three norms,  q|k = n1 . W_qk^T + b_qk,
+ * v^T = (n1 . W_v^T + b_v)^T,  q2 = n2 . W_qk[0:units]^T + b_qk[0:units],  n3 as is — all but y in DM3D_FMT_H2; n1 and n2 never leave
+ * the CU.  Replaces dm3d_gemm_tn (proj_in) + dm3d_layernorm3_h2 + a dm3d_gemm_tn_group of three.  units == 256, m % 64 == 0,
+ * DM3D_PREC_H3 arithmetic.  Weights are operand-fragment images made once by dm3d_pack_front_weights from the DM3D_FMT_H2 rows
+ * W[n][units] (dm3d_split_h2 of the [n][units] float32 weight; n = 256 for w_in / w_v, 512 for w_qk: query rows, then key rows);
+ * same byte count as the source. */
+typedef struct dm3d_attn_front_desc {
+    const float* x; int64_t ldx;                           /* [m][units] float32 */
+    const void* w_in; const float* b_in;
+    const void* w_qk; const float* b_qk;                   /* b_qk: [2 units] */
+    const void* w_v; const float* b_v;
+    const float* g1; const float* be1;                     /* LayerNormalization (gamma, beta) of norm1 / norm2 / norm3, [units] each */
+    const float* g2; const float* be2;
+    const float* g3; const float* be3;
+    float eps;
+    float* y; int64_t ldy;                                 /* [m][units] float32 */
+    void* qk; int64_t ldqk;                                /* DM3D_FMT_H2 [m][2 units] */
+    void* vt; int64_t ldvt;                                /* DM3D_FMT_H2 [units][m] */
+    void* q2; int64_t ldq2;                                /* DM3D_FMT_H2 [m][units] */
+    void* n3; int64_t ldn3;                                /* DM3D_FMT_H2 [m][units] */
+    int32_t m, units;
+    int32_t* range_flag; float range_limit;                /* as in dm3d_gemm_desc */
+} dm3d_attn_front_desc;
+int dm3d_pack_front_weights(const void* w_h2, int32_t n, int32_t units, void* tiled, void* stream);
+int dm3d_attn_front(const dm3d_attn_front_desc* d, void* stream);
 
 /* dst(H2) = split(src * 2^exp2): one-time conversion of static operands (weights, context keys/values). k % 16 == 0 is
  * not required of src: columns k..round_up(k,16) of dst are zero filled; ld_dst % 16 == 0, ld_dst >= round_up(k,16). */

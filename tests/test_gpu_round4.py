@@ -337,6 +337,46 @@ def test_mlp_fused_against_float64(dev, m, out_h2):
     out = ops.mlp_fused(ops.split_h2(c(x)), w0t, c(b0), w1t, c(b1), u)
     ref0 = ref - r1.double() - r2.double()
     assert float((out.cpu().double() - ref0).abs().max() / ref0.abs().max()) < 2e-5
+    # with the proj_out tail: relu(Dense(u)(that)) + res3, the MLP's own result not stored (conditional_dm3d.py:195)
+    if not out_h2:
+        w2, b2, r3 = torch.randn(u, u, generator=g) / 16.0, torch.randn(u, generator=g) * 0.1, torch.randn(m, u, generator=g)
+        ref2 = torch.relu(ref @ w2.double().T + b2.double()) + r3.double()
+        w2t = ops.pack_front_weights(ops.split_h2(c(w2)), u)
+        out = ops.mlp_fused(ops.split_h2(c(x)), w0t, c(b0), w1t, c(b1), u, res=c(r1), res2=c(r2), tail=(w2t, c(b2), c(r3)))
+        torch.cuda.synchronize()
+        err2 = float((out.cpu().double() - ref2).abs().max() / ref2.abs().max())
+        print(f"mlp_fused + tail m={m}: {err2:.2e}")
+        assert err2 < 2e-5
+        out = ops.mlp_fused(ops.split_h2(c(x)), w0t, c(b0), w1t, c(b1), u, res=c(r1), res2=c(r2), tail=(w2t, c(b2), None))
+        assert float((out.cpu().double() - (ref2 - r3.double())).abs().max() / ref2.abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("m", [64, 1024], ids=["one tile", "16 tiles"])
+def test_attn_front_against_float64(dev, m):
+    """dm3d_attn_front: relu(proj_in) -> three LayerNormalizations -> q|k, v^T, q2 projections in one launch (conditional_dm3d.py:186-193,
+    163-170) against float64, and against the three launches it replaces; u = 256."""
+    from dm3d_amd import ops
+    u = 256
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(m, u, generator=g) * 2.0
+    w_in, b_in = torch.randn(u, u, generator=g) / 16.0, torch.randn(u, generator=g) * 0.1
+    w_qk, b_qk = torch.randn(2 * u, u, generator=g) / 16.0, torch.randn(2 * u, generator=g) * 0.1
+    w_v, b_v = torch.randn(u, u, generator=g) / 16.0, torch.randn(u, generator=g) * 0.1
+    norms = [(torch.rand(u, generator=g) + 0.5, torch.randn(u, generator=g) * 0.2) for _ in range(3)]
+    D = lambda t: t.double()
+    y_ref = torch.relu(D(x) @ D(w_in).T + D(b_in))
+    ln = lambda gb: torch.nn.functional.layer_norm(y_ref, (u,), D(gb[0]), D(gb[1]), 1e-3)
+    n1, n2, n3 = ln(norms[0]), ln(norms[1]), ln(norms[2])
+    qk_ref, v_ref, q2_ref = n1 @ D(w_qk).T + D(b_qk), n1 @ D(w_v).T + D(b_v), n2 @ D(w_qk[:u]).T + D(b_qk[:u])
+    c = lambda t: t.to(dev).contiguous()
+    tile = lambda w: ops.pack_front_weights(ops.split_h2(c(w)), w.shape[0])
+    y, qk, v_t, q2, n3o = ops.attn_front(c(x), tile(w_in), c(b_in), tile(w_qk), c(b_qk), tile(w_v), c(b_v), [(c(a), c(b)) for a, b in norms])
+    torch.cuda.synchronize()
+    rel = lambda got, ref: float((got.cpu().double() - ref).abs().max() / ref.abs().max())
+    errs = {"y": rel(y, y_ref), "qk": rel(ops.h2_to_f32(qk, 2 * u), qk_ref), "v_t": rel(ops.h2_to_f32(v_t, m), v_ref.T.contiguous()),
+            "q2": rel(ops.h2_to_f32(q2, u), q2_ref), "n3": rel(ops.h2_to_f32(n3o, u), n3)}
+    print(f"attn_front m={m}: " + " ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    assert max(errs.values()) < 2e-5, errs
 
 
 GN_CASES = [("direct kernel, whole bricks (fused)", 2, (8, 8, 8), 32, 64, 0, 0), ("Winograd form, item lists (fused)", 2, (16, 16, 16), 32, 64, 1, 0),

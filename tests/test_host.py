@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol(built_library):
         assert hasattr(handle, name), f"{name} declared in include/dm3d.h but not exported"
     from dm3d_amd import _lib
     assert set(_lib.SIGNATURES) == declared
-    assert _lib.lib().dm3d_version() == _lib.ABI_VERSION == 109
+    assert _lib.lib().dm3d_version() == _lib.ABI_VERSION == 110
     assert _lib.lib().dm3d_packed_weight_elems(27, 96, 64) == 27 * 64 * 96
     assert _lib.lib().dm3d_packed_weight_elems(1, 8, 8) == 64 * 16
 
@@ -29,14 +29,14 @@ def test_library_exports_every_declared_symbol(built_library):
 def test_struct_layouts_match_the_header(built_library, tmp_path):
     """sizeof() of the descriptor structs as the C compiler sees them == the ctypes mirrors."""
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "dm3d.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(dm3d_conv_desc),'
-                   ' sizeof(dm3d_gemm_desc), sizeof(dm3d_ddpm_desc), sizeof(dm3d_attention_desc), sizeof(dm3d_mlp_desc));return 0;}\n')
+    src.write_text('#include <stdio.h>\n#include "dm3d.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(dm3d_conv_desc),'
+                   ' sizeof(dm3d_gemm_desc), sizeof(dm3d_ddpm_desc), sizeof(dm3d_attention_desc), sizeof(dm3d_mlp_desc), sizeof(dm3d_attn_front_desc));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     sizes = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     from dm3d_amd import _lib
     assert sizes == [ctypes.sizeof(_lib.ConvDesc), ctypes.sizeof(_lib.GemmDesc), ctypes.sizeof(_lib.DdpmDesc),
-                     ctypes.sizeof(_lib.AttentionDesc), ctypes.sizeof(_lib.MlpDesc)]
+                     ctypes.sizeof(_lib.AttentionDesc), ctypes.sizeof(_lib.MlpDesc), ctypes.sizeof(_lib.AttnFrontDesc)]
 
 
 def test_plain_c_program_links_against_the_abi(built_library, tmp_path):

@@ -9,7 +9,7 @@ os.chdir(CSRC)
 subprocess.check_call(["make"])
 os.makedirs("variants", exist_ok=True)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I../../include", "-Wno-unused-function", "-ffp-contract=off"]
-OBJS = ["dm3d_api.o", "dm3d_conv.o", "dm3d_conv_h3.o", "dm3d_conv_h3_host.o", "dm3d_conv_h3v3.o", "dm3d_conv_h3w.o", "dm3d_gemm.o", "dm3d_gemm_h3.o", "dm3d_mlp_h3.o", "dm3d_elem.o", "dm3d_train.o", "dm3d_attn_h3.o"]
+OBJS = ["dm3d_api.o", "dm3d_conv.o", "dm3d_conv_h3.o", "dm3d_conv_h3_host.o", "dm3d_conv_h3v3.o", "dm3d_conv_h3w.o", "dm3d_gemm.o", "dm3d_gemm_h3.o", "dm3d_mlp_h3.o", "dm3d_attn_front_h3.o", "dm3d_elem.o", "dm3d_train.o", "dm3d_attn_h3.o"]
 
 
 # ---- conv3d_igemm_h3v3
