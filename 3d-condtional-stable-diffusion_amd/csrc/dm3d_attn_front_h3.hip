@@ -81,18 +81,22 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
     };
 
     // ---- weight stream: five passes of 8 groups; the loads of a group are issued in front of the MFMAs of the group before it (two register
-    // sets), those of a pass's first group during the previous pass's last group
+    // sets), those of a pass's first groups during the previous pass's last groups
     const size_t w_lane = (size_t)wave * (KR * 4 * 1024) + lane * 16;
     const char* const w_in = static_cast<const char*>(p.w_in) + w_lane;
     const char* const w_q = static_cast<const char*>(p.w_qk) + w_lane;
     const char* const w_k = w_q + PASS;
     const char* const w_v = static_cast<const char*>(p.w_v) + w_lane;
-    h8 wa[2][8];                                                // [set][record i of the group][column tile nr][hi | lo]
+    // (WSETS - 1 groups ahead: a group is 24 MFMAs = 0.35 us, a load from the L2 comes back after ~1 us under this kernel's own traffic — with
+    // one group of lead the launch took the same 56 us with and without its MFMAs)
+    constexpr int WSETS = 4;
+    h8 wa[WSETS][8];                                            // [set][record i of the group][column tile nr][hi | lo]
     auto load_w = [&](const int set, const char* wp, const int g) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) wa[set][t] = *reinterpret_cast<const h8*>(wp + (size_t)g * 8192 + t * 1024);
     };
-    load_w(0, w_in, 0);
+#pragma unroll
+    for (int g = 0; g < WSETS - 1; ++g) load_w(g, w_in, g);
 
     // ---- stage x: 64 rows x 256 float32 -> H2 records in region A.  A wave's load instruction reads one whole row (1 KB); lane l converts
     // columns 4l .. 4l+3: record l >> 2, slot (l >> 1) & 1 (lo: + 2), bytes 8 (l & 1) .. + 7 of the slot.
@@ -139,19 +143,28 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
             for (int nr = 0; nr < 2; ++nr)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.0f;
+        // the B fragments of a record are requested one record ahead of the MFMAs that use them (two register sets)
+        h8 bh[2][2], bl[2][2];
+        auto read_b = [&](const int set, const int kk) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bh[set][t] = *reinterpret_cast<const h8*>(reg + kk * RS + b_off[t]);
+                bl[set][t] = *reinterpret_cast<const h8*>(reg + kk * RS + (b_off[t] ^ 32u));
+            }
+        };
+        read_b(0, 0);
         static_for<NG>([&](auto G_) __attribute__((always_inline)) {
-            constexpr int g = decltype(G_)::value, set = g & 1;          // (NG is even: every pass starts in set 0)
-            if (g + 1 < NG) load_w(set ^ 1, wp, g + 1); else load_w(set ^ 1, wnext, 0);
+            constexpr int g = decltype(G_)::value, set = g & (WSETS - 1);          // (NG % WSETS == 0: every pass starts in set 0)
+            constexpr int ga = g + WSETS - 1;                                       // the group requested now: WSETS - 1 groups ahead
+            if (ga < NG) load_w(ga & (WSETS - 1), wp, ga); else load_w(ga & (WSETS - 1), wnext, ga - NG);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int kk = 2 * g + i;
-                h8 ah[2], al[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    ah[t] = *reinterpret_cast<const h8*>(reg + kk * RS + b_off[t]);
-                    al[t] = *reinterpret_cast<const h8*>(reg + kk * RS + (b_off[t] ^ 32u));
-                }
+                const int kk = 2 * g + i, bs = i;                       // (two records per group: the record's parity is i)
+                if (kk + 1 < KR) read_b(bs ^ 1, kk + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const h8 (&ah)[2] = bh[bs];
+                const h8 (&al)[2] = bl[bs];
                 // pass-major over the four tiles (a 32x32x16 that depends on the one issued just before it waits out its latency)
                 if constexpr (!SWAP) {
 #pragma unroll
@@ -168,8 +181,8 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) DM3D_MFMA_VV(acc[t >> 1][t & 1], ah[t >> 1], wa[set][4 * i + 2 * (t & 1)]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         });
         DM3D_MFMA_DRAIN();
     };
@@ -179,25 +192,29 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
     float amax = 0.0f;
     // lane (l32, half): row 32 mr + l32; register 4 gq + j of tile (mr, nr): column n0 + j, n0 = 64 w + 32 nr + 8 gq + 4 half
     auto col0 = [&](int nr, int gq) { return wave * 64 + nr * 32 + 8 * gq + 4 * half; };
-    // four consecutive columns of one row as DM3D_FMT_H2: the hi halves are 8 contiguous bytes of the row's record, the lo halves 32 further
-    auto store_h2 = [&](void* base, long ld, int row, int n, const float (&v)[4]) __attribute__((always_inline)) {
+    // Four consecutive columns of one row -> 16 bytes of DM3D_FMT_H2.  This lane (half h) holds columns 8 q + 4 h .. + 3 of an 8-column group,
+    // its partner lane (half h ^ 1, same row) the other four: v_permlane32_swap exchanges the halves' words so that the half-0 lane ends up
+    // with the group's eight hi halves (one whole 16-byte slot of the record) and the half-1 lane with its eight lo halves (the slot 32
+    // bytes further): one 16-byte store per lane instead of two 8-byte ones.
+    auto pack16 = [&](const float (&v)[4]) __attribute__((always_inline)) {
         unsigned int h0, l0, h1, l1;
         split2(clamp(v[0]), clamp(v[1]), h0, l0);
         split2(clamp(v[2]), clamp(v[3]), h1, l1);
-        char* dst = static_cast<char*>(base) + (size_t)row * ld * 4 + (n >> 4) * 64 + ((n >> 3) & 1) * 16 + (n & 7) * 2;
-        *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
-        *reinterpret_cast<u32x2*>(dst + 32) = u32x2{l0, l1};
+        const auto s0 = __builtin_amdgcn_permlane32_swap(h0, l0, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(h1, l1, false, false);
+        return u32x4{s0[0], s1[0], s0[1], s1[1]};
     };
-    // the same four values into an LDS image (the B operand of a later pass)
-    auto store_lds = [&](char* reg, int r, int n, const float (&v)[4]) __attribute__((always_inline)) {
-        unsigned int h0, l0, h1, l1;
-        split2(clamp(v[0]), clamp(v[1]), h0, l0);
-        split2(clamp(v[2]), clamp(v[3]), h1, l1);
-        const int sw = (r >> 2) & 3, slot = (n >> 3) & 1;
-        char* rp = reg + (n >> 4) * RS + r * 64 + (n & 7) * 2;
-        *reinterpret_cast<u32x2*>(rp + ((slot ^ sw) << 4)) = u32x2{h0, h1};
-        *reinterpret_cast<u32x2*>(rp + (((2 + slot) ^ sw) << 4)) = u32x2{l0, l1};
+    // n8: first column of the 8-column group (a multiple of 8)
+    auto store_h2 = [&](void* base, long ld, int row, int n8, const float (&v)[4]) __attribute__((always_inline)) {
+        char* dst = static_cast<char*>(base) + (size_t)row * ld * 4 + (n8 >> 4) * 64 + ((n8 >> 3) & 1) * 16 + 32 * half;
+        *reinterpret_cast<u32x4*>(dst) = pack16(v);
     };
+    // the same into an LDS image (the B operand of a later pass)
+    auto store_lds = [&](char* reg, int r, int n8, const float (&v)[4]) __attribute__((always_inline)) {
+        const int sw = (r >> 2) & 3, slot = ((n8 >> 3) & 1) + 2 * half;
+        *reinterpret_cast<u32x4*>(reg + (n8 >> 4) * RS + r * 64 + ((slot ^ sw) << 4)) = pack16(v);
+    };
+    auto col8 = [&](int nr, int gq) { return wave * 64 + nr * 32 + 8 * gq; };
 
     // ---- pass 0: y = relu(W_in . x + b_in), kept in registers
     f32x16 yv[2][2];
@@ -291,8 +308,8 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
                     float v[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { v[j] = yv[mr][nr][4 * gq + j] * gv[nr][gq][j] + tv[nr][gq][j]; DM3D_AMAX(amax, v[j]); }
-                    if constexpr (which == 0) store_h2(p.n3, p.ldn3, m0 + mr * 32 + l32, col0(nr, gq), v);
-                    else store_lds(which == 1 ? reg_b : reg_a, mr * 32 + l32, col0(nr, gq), v);
+                    if constexpr (which == 0) store_h2(p.n3, p.ldn3, m0 + mr * 32 + l32, col8(nr, gq), v);
+                    else store_lds(which == 1 ? reg_b : reg_a, mr * 32 + l32, col8(nr, gq), v);
                 }
     });
     lds_barrier();                                              // n1 and n2 are visible
@@ -316,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
                     float v[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { v[j] = acc[mr][nr][4 * gq + j] + bv[nr][gq][j]; DM3D_AMAX(amax, v[j]); }
-                    store_h2(p.qk, p.ldqk, m0 + mr * 32 + l32, pi * U + col0(nr, gq), v);
+                    store_h2(p.qk, p.ldqk, m0 + mr * 32 + l32, pi * U + col8(nr, gq), v);
                 }
     });
     // ---- pass 3: v^T = W_v . n1^T + b_v with the operands exchanged: lane = channel 64 w + 32 nr + l32, register 4 gq + j of tile (mr, nr) =
@@ -334,7 +351,7 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
                     float v[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { v[j] = acc[mr][nr][4 * gq + j] + bias; DM3D_AMAX(amax, v[j]); }
-                    store_h2(p.vt, p.ldvt, ch, m0 + mr * 32 + 8 * gq + 4 * half, v);
+                    store_h2(p.vt, p.ldvt, ch, m0 + mr * 32 + 8 * gq, v);
                 }
         }
     }
@@ -356,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
                     float v[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { v[j] = acc[mr][nr][4 * gq + j] + bv[nr][gq][j]; DM3D_AMAX(amax, v[j]); }
-                    store_h2(p.q2, p.ldq2, m0 + mr * 32 + l32, col0(nr, gq), v);
+                    store_h2(p.q2, p.ldq2, m0 + mr * 32 + l32, col8(nr, gq), v);
                 }
     }
     if (p.range_flag && amax > p.range_limit) *p.range_flag = 1;
