@@ -87,9 +87,10 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
     const char* const w_q = static_cast<const char*>(p.w_qk) + w_lane;
     const char* const w_k = w_q + PASS;
     const char* const w_v = static_cast<const char*>(p.w_v) + w_lane;
-    // (WSETS - 1 groups ahead: a group is 24 MFMAs = 0.35 us, a load from the L2 comes back after ~1 us under this kernel's own traffic — with
-    // one group of lead the launch took the same 56 us with and without its MFMAs)
-    constexpr int WSETS = 4;
+    // (WSETS - 1 groups ahead.  Measured: one group and three groups of lead take the same 57 us at B = 32, and so does a timing-only build without
+    // any MFMA — a lone workgroup per CU runs its phases serially (36 us for a workgroup alone on the chip: x load and staging, five passes each
+    // followed by its stores, two statistics exchanges), and 100 MB of output per launch add the rest; the MFMAs (14 us) hide inside the waits)
+    constexpr int WSETS = 2;
     h8 wa[WSETS][8];                                            // [set][record i of the group][column tile nr][hi | lo]
     auto load_w = [&](const int set, const char* wp, const int g) __attribute__((always_inline)) {
 #pragma unroll
