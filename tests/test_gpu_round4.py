@@ -295,6 +295,38 @@ def test_nan_born_inside_the_unet_raises(dev, where):
             smp.step()
 
 
+@pytest.mark.parametrize("norm", ["batch", "group"])
+def test_fused_attention_block_equals_its_separate_launches(dev, monkeypatch, norm):
+    """The CrossAttentionBlock as three launches (dm3d_attn_front, fused attention, dm3d_mlp_fused with the proj_out tail) against the launches they
+    replace (proj_in GEMM, layernorm3, grouped q|k / v^T / q2 GEMM, MLP as two GEMMs, proj_out GEMM: the form small batches keep and the oracle
+    tests cover at small sizes) on one model and one input, B = 16 at 32^3 x 8ch, both normalisation variants (GroupNormalization feeds the front
+    kernel a materialised tensor): eps within 2e-5."""
+    import dm3d_amd
+    from dm3d_amd.unet import UNet
+    B, C = 16, 8
+    cfg = dm3d_amd.UNetConfig(img_size=32, img_channels=C, norm=norm)
+    W = dm3d_amd.synthetic_weights(cfg, seed=4)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 32, 32, 32, C, generator=g).to(dev)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    ctx = torch.randint(0, 2, (B, 1, 1), generator=g)
+    out, kinds = {}, {}
+    for fused in ("1", "0"):
+        for var in ("DM3D_ATTN_FRONT", "DM3D_MLP_TAIL", "DM3D_MLP_FUSED"):
+            monkeypatch.setenv(var, fused)
+        net = UNet(cfg, weights=W, precision="h3")
+        out[fused] = net([x, t, ctx]).clone()
+        kinds[fused] = net.plan(B, B, per_sample_context=True).count()
+        del net
+        torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    assert kinds["1"].get("attn_front", 0) == 6 and kinds["1"].get("mlp_fused", 0) == 6 and "gemm_h3" not in kinds["1"], kinds["1"]
+    assert "attn_front" not in kinds["0"] and "mlp_fused" not in kinds["0"] and kinds["0"].get("gemm_h3", 0) >= 24, kinds["0"]
+    err = _rel(out["1"], out["0"])
+    print(f"norm={norm}: fused block vs separate launches, eps rel diff {err:.2e}")
+    assert torch.isfinite(out["1"]).all() and err < 2e-5
+
+
 def test_bench_four_rank_rehearsal(dev):
     """`python bench.py --gpus 4` in rehearsal mode: four rank processes on GPU 0 over gloo (the boxes allow six GPU processes, so this is the
     widest rehearsal that touches the card; the eight-rank width of the driver's run is rehearsed without a GPU in tests/test_host.py)."""

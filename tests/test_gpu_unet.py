@@ -483,6 +483,8 @@ def test_unet_eps_b32_h3_full_size(dev):
     plan = net.plan(B, B, per_sample_context=True)
     kinds = plan.count()
     assert kinds.get("conv_wino", 0) >= 15 and kinds.get("conv_wino_h2in", 0) >= 5, kinds
+    # ... and the attention blocks as three launches each (dm3d_attn_front, fused attention, dm3d_mlp_fused with the proj_out tail)
+    assert kinds.get("attn_front", 0) == 6 and kinds.get("attn_fused", 0) == 6 and kinds.get("mlp_fused", 0) == 6 and "gemm_h3" not in kinds, kinds
     assert plan.uses_wino and plan.range_limit <= 32752.0
     err = _rel(eps, ref)
     per_sample = [_rel(eps[i], ref[i]) for i in range(B)]
