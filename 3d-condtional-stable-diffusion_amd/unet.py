@@ -824,9 +824,11 @@ class Plan:
         return out
 
     def _cross_block_h2(self, blk, x, edge):
-        """CrossAttentionBlock on the H3 GEMM with DM3D_FMT_H2 intermediates, 8 launches: the GEMMs that depend only on the
-        LayerNorm outputs (q|k, v^T, q2, MLP hidden) go out as one grouped launch, likewise the two score products and the
-        two P.V products; a3 = MLP + (attn_self + y) + attn_cross is formed in the MLP GEMM's epilogue (two residuals)."""
+        """CrossAttentionBlock with DM3D_FMT_H2 intermediates (conditional_dm3d.py:163-195).  Large batches (u = 256, >= 128 row tiles): THREE
+        launches — dm3d_attn_front (proj_in + the three LayerNormalizations + q|k, v^T, q2), dm3d_attention_group (both passes, online softmax),
+        dm3d_mlp_fused with the proj_out tail; a3 = MLP + (attn_self + y) + attn_cross is formed inside the last.  Otherwise the GEMM form: the
+        GEMMs that depend only on the LayerNorm outputs (q|k, v^T, q2, MLP hidden) as one grouped launch, likewise the two score products and
+        the two P.V products."""
         P, B, n, u = self.net.P, self.B, blk.name, blk.cout
         L = edge ** 3
         M = B * L
