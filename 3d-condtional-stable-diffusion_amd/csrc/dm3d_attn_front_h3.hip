@@ -247,7 +247,6 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
     // ---- LayerNormalization statistics of the 64 rows (two-pass): this lane's 32 columns of its two rows, its partner half's, the four waves'
     float mean[2], rstd[2];
     {
-        float s[2];
 #pragma unroll
         for (int mr = 0; mr < 2; ++mr) {
             float a = 0.0f;
@@ -256,7 +255,6 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a += yv[mr][nr][r];
             a += __shfl_xor(a, 32);
-            s[mr] = a;
             if (half == 0) stat[wave * 64 + mr * 32 + l32] = a;
         }
         lds_barrier();                                          // (also: every wave has finished reading x — region A is free)
@@ -279,7 +277,6 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
             const float var = ((stat[256 + r] + stat[320 + r]) + (stat[384 + r] + stat[448 + r])) * (1.0f / U);
             rstd[mr] = rsqrtf(var + p.eps);
         }
-        (void)s;
     }
     // normalised rows in place, then the three affine copies: n3 -> HBM (the MLP's input), n1 -> region B, n2 -> region A
 #pragma unroll

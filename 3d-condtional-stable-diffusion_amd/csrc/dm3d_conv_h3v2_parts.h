@@ -1,6 +1,7 @@
 // dm3d_conv_h3v2_parts.h — pieces shared by the two 16x16x32 split-float16 Conv3d kernels (dm3d_conv_h3v3.hip: the free-running
-// software-pipelined three-pass kernel, the default; dm3d_conv_h3v2.hip: the opt-in float8 cross-term form): operand geometry helpers, the
-// fused 1x1 skip-conv tail phase and the epilogue.  Both kernels own a [4 patches][column tiles] accumulator per wave, one 8 x 8 z-slice each.
+// software-pipelined direct kernel; dm3d_conv_h3w.hip: the persistent Winograd-x kernel, which calls the epilogue once per z-slice):
+// operand geometry helpers, the direct kernel's LDS-staged 1x1 skip-conv tail phase, the epilogue and the GroupNormalization partial sums.
+// The epilogue works on a [4 patches][column tiles] accumulator of one 8 x 8 z-slice.
 #pragma once
 #include "dm3d_conv_args.h"
 #include "dm3d_h3.h"

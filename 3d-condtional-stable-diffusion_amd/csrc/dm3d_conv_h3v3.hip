@@ -4,7 +4,7 @@
 // (networks/conditional_dm3d.py:254-268), UpSampling3D + Conv3D (:288-296), Concatenate + ResidualBlock on the up path (:394-404).
 //
 // Same arithmetic, operand geometry, LDS images, packed weight image (DM3D_WL_PAIR), skip-conv tail phase and epilogue as the round-1/2
-// kernels (now only the float8 form is left of them, dm3d_conv_h3v2.hip; shared pieces in dm3d_conv_h3v2_parts.h).  What changed is the
+// kernels (git history; the pieces this kernel shares with the Winograd-x form, dm3d_conv_h3w.hip, are in dm3d_conv_h3v2_parts.h).  What changed is the
 // skeleton.  Round 3 measured the round-2 kernel with one stamp pair around its chunk loop (tools/kernel_clock.py, profiles/
 // r03_v2_clocks.log): the chip held 1.93-2.02 GHz under it and the matrix pipe was busy 72-75 % of the loop — against 87 % at 1.87 GHz
 // for a bare LDS-fed MFMA loop (tools/micro/mfma_shapes) — and 67 % of the launch (SQ_VALU_MFMA_BUSY_CYCLES, profiles/

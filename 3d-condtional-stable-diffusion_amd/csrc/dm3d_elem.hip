@@ -499,8 +499,8 @@ __global__ __launch_bounds__(256) void ddpm_kernel(const DdpmArgs p) {
 typedef unsigned int u32x4r __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void range_check_kernel(const float* __restrict__ x, long n4, float limit, int* __restrict__ flag) {
     // |x| compared as integers: for non-negative floats the bit patterns order like the values and every NaN pattern lies above +inf,
-    // so a NaN raises the flag too (fmaxf drops NaNs and `amax > limit` is false for one: a NaN produced upstream — the float8
-    // conversions of the h3f8 mode return NaN beyond 448 — would otherwise pass unseen)
+    // so a NaN raises the flag too (fmaxf drops NaNs and `amax > limit` is false for one: a NaN produced upstream — NaN or Inf weights of a
+    // diverged checkpoint — would otherwise pass unseen)
     unsigned int amax = 0u;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const u32x4r v = reinterpret_cast<const u32x4r*>(x)[i];

@@ -20,6 +20,8 @@
 // LDS-DMA — 2 048 one-KB DMA instructions per workgroup at 100+ cycles of issue each, as long as the MFMAs themselves, plus a barrier per
 // granule: 78 us per block against 98 for the two GEMMs; in-kernel stamps put a granule at 1 900 cycles for 768 of MFMA.)
 // The only workgroup-wide synchronisation left is the hand-over of the H slab: two barriers per slab.
+// Optional tail (MlpArgs.w2): the block's proj_out — relu(W2 . a3 + b2) + the block input — as one more K = 256 product in the phase-2 form, with
+// the MLP's result a3 handed over through LDS instead of HBM (conditional_dm3d.py:195).
 #include "dm3d_h3.h"
 #include <cstdlib>
 #include <type_traits>
@@ -36,7 +38,6 @@ extern "C" int dm3d_debug_set_stamps_mlp(void* p) { return (int)hipMemcpyToSymbo
 
 namespace {
 
-constexpr int REC = DM3D_REC;
 
 struct MlpArgs {
     const void* x; long ldx;                    // [m][u] DM3D_FMT_H2 (ld in elements of 4 bytes)
