@@ -82,20 +82,24 @@ __global__ __launch_bounds__(256, 1) void attn_fused_h3(const AttnArgs p) {
     //   K tile  [16 channel records s][32 keys][REC]: instruction (s, key half) — wave w moves s = 4w .. 4w+3 for both halves;
     //   V^T tile [2 key records j][256 channels][REC]: instruction (j, 16-channel block) — wave w moves blocks 4w .. 4w+3 for j = 0, 1.
     // Two LDS buffers: tile t+1 streams in while tile t is multiplied (a tile is ~1.7 us of MFMAs; a 16 KB fill lands in ~1.1 us).
+    // Buffer form of the LDS-DMA (round 4, as in dm3d_conv_h3w.hip): one resource descriptor per operand in scalar registers, a per-lane
+    // 32-bit offset that never changes, the tile as a scalar offset — the first form added a 64-bit per-lane address for every instruction.
     const char* kbase = ps.k + (size_t)b * ps.sk * 4;
     const char* vbase = ps.vt + (size_t)b * ps.sv * 4;
+    const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kbase), (short)0, (int)((long)lk * ps.ldk * 4), 0x00020000);
+    const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vbase), (short)0, (int)((long)AC * ps.ldv * 4), 0x00020000);
     const int r16 = lane >> 2, pslot = lane & 3;
-    const char* k_lane[2];                       // + key0 * ldk * 4 + s * 64
-    const char* v_lane[4];                       // + key0 * 4 + j * 64
+    int k_lane[2];                               // + key0 * ldk * 4 + s * 64
+    int v_lane[4];                               // + key0 * 4 + j * 64
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
         const int row = kh * 16 + r16;
-        k_lane[kh] = kbase + (size_t)row * ps.ldk * 4 + ((pslot ^ swz(row)) << 4);
+        k_lane[kh] = (int)(row * ps.ldk * 4) + ((pslot ^ swz(row)) << 4);
     }
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
         const int row = (wave * 4 + cb) * 16 + r16;
-        v_lane[cb] = vbase + (size_t)row * ps.ldv * 4 + ((pslot ^ swz(row)) << 4);
+        v_lane[cb] = (int)(row * ps.ldv * 4) + ((pslot ^ swz(row)) << 4);
     }
     // part p of a tile: this wave issues K record plane (4w + p) for both key halves and V^T
     // block (4w + p) for both key records: 4 instructions.  A tile is issued in four parts between the score MFMAs of the previous tile.
@@ -105,16 +109,16 @@ __global__ __launch_bounds__(256, 1) void attn_fused_h3(const AttnArgs p) {
     auto fetch_part = [&](int key0, int buf, int part) {
         char* dk = reinterpret_cast<char*>(smem_at) + buf * ((K_TILE + V_TILE) * 2);
         char* dv = dk + K_TILE * 2;
-        const size_t koff = (size_t)key0 * ps.ldk * 4, voff = (size_t)key0 * 4;
-        const int sidx = wave * 4 + part;
+        const int sidx = __builtin_amdgcn_readfirstlane(wave * 4 + part);
+        const int koff = __builtin_amdgcn_readfirstlane(key0 * (int)ps.ldk * 4 + sidx * 64), voff = __builtin_amdgcn_readfirstlane(key0 * 4);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(k_lane[kh] + koff + sidx * 64),
-                                             (__attribute__((address_space(3))) void*)(dk + (sidx * KT + kh * 16) * (REC * 2)), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(dk + (sidx * KT + kh * 16) * (REC * 2)), 16,
+                                                     k_lane[kh], koff, 0, 0);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(v_lane[part] + voff + j * 64),
-                                             (__attribute__((address_space(3))) void*)(dv + (j * AC + sidx * 16) * (REC * 2)), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(dv + (j * AC + sidx * 16) * (REC * 2)), 16,
+                                                     v_lane[part], voff + j * 64, 0, 0);
     };
     auto fetch = [&](int key0, int buf) {
 #pragma unroll
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void attn_fused_h3(const AttnArgs p) {
 // true when the fused kernel serves this description
 static bool attn_fusable(const dm3d_attention_desc* d) {
     return d->precision == DM3D_PREC_H3 && d->fmt == DM3D_FMT_H2 && d->c == AC && d->lq % QT == 0 && d->lk % KT == 0 &&
-           (int64_t)AC * d->ldv * 4 < (1ll << 31) && (int64_t)KT * d->ldk * 4 < (1ll << 31) &&
+           (int64_t)AC * d->ldv * 4 < (1ll << 31) && (int64_t)d->lk * d->ldk * 4 < (1ll << 31) &&
            d->ldq % 16 == 0 && d->ldk % 16 == 0 && d->ldv % 16 == 0 && d->stride_k % 16 == 0 && d->stride_vt % 16 == 0 && d->ldo % 4 == 0 &&
            dm3d_aligned16(d->q) && dm3d_aligned16(d->k) && dm3d_aligned16(d->vt) && dm3d_aligned16(d->out) && dm3d_aligned16(d->res);
 }
