@@ -19,6 +19,7 @@
 // LayerNormalization: the row statistics need all 256 columns of a row, i.e. all four waves: two exchanges of 64 x 4 partial sums through
 // LDS (mean, then the centred sum of squares — the two-pass form of dm3d_layernorm3).
 #include "dm3d_h3.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -49,8 +50,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
-    constexpr int U = 256, TM = 64, KR = U / 16;
+// MR: 32-row tiles per workgroup.  2: 64 rows, one workgroup per CU (134 KB of LDS); 1: 32 rows, 68 KB and half the registers, up to two workgroups
+// per CU, at twice the weight traffic per row (the launcher picks by the number of rows).
+template <int MR>
+__global__ __launch_bounds__(256, MR == 1 ? 2 : 1) void attn_front_h3(const FrontArgs p) {
+    constexpr int U = 256, TM = 32 * MR, KR = U / 16, RW = TM / 4;      // RW: rows a wave stages
     constexpr int RS = TM * 64 + 32;                            // bytes between records of the LDS image
     constexpr int REGION = KR * RS;                             // 66 048 bytes
     constexpr int NG = KR / 2;                                  // weight groups per pass: two records = 8 fragments each
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_f[];
     char* reg_a = smem_f;                                       // x, later n2
     char* reg_b = smem_f + REGION;                              // n1
-    float* stat = reinterpret_cast<float*>(smem_f + 2 * REGION);        // [2][4 waves][64 rows]
+    float* stat = reinterpret_cast<float*>(smem_f + 2 * REGION);        // [2][4 waves][TM rows]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l32 = lane & 31;
@@ -102,16 +106,16 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
     // ---- stage x: 64 rows x 256 float32 -> H2 records in region A.  A wave's load instruction reads one whole row (1 KB); lane l converts
     // columns 4l .. 4l+3: record l >> 2, slot (l >> 1) & 1 (lo: + 2), bytes 8 (l & 1) .. + 7 of the slot.
     {
-        f32x4 xv[16];
+        f32x4 xv[RW];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int row = m0 + wave * 16 + j;
+        for (int j = 0; j < RW; ++j) {
+            const int row = m0 + wave * RW + j;
             xv[j] = *reinterpret_cast<const f32x4*>(p.x + (size_t)row * p.ldx + 4 * lane);
         }
         const int rec = lane >> 2, slot = (lane >> 1) & 1, sub = (lane & 1) * 8;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int r = wave * 16 + j, sw = (r >> 2) & 3;
+        for (int j = 0; j < RW; ++j) {
+            const int r = wave * RW + j, sw = (r >> 2) & 3;
             unsigned int h0, l0, h1, l1;
             split2(clamp(xv[j][0]), clamp(xv[j][1]), h0, l0);
             split2(clamp(xv[j][2]), clamp(xv[j][3]), h1, l1);
@@ -123,9 +127,9 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
     lds_barrier();
 
     // B-operand fragment offsets (bytes): logical slot `half` (hi; lo: ^ 32) of this lane's row, swizzled by the row
-    unsigned b_off[2];
+    unsigned b_off[MR];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < MR; ++t) {
         const int ra = t * 32 + l32;
         b_off[t] = (unsigned)(ra * 64 + ((half ^ ((ra >> 2) & 3)) << 4));
     }
@@ -136,19 +140,19 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
 #define DM3D_MFMA_VV(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0)
 #define DM3D_MFMA_DRAIN() do { } while (0)
     // One pass: acc[mr][nr] (+)= W[64w + 32nr ..][:] . in[32mr ..][:]^T over K = 256.  SWAP: the operands exchanged (acc^T: lane = column).
-    auto pass = [&](auto SWAP_T, f32x16 (&acc)[2][2], const char* reg, const char* wp, const char* wnext) __attribute__((always_inline)) {
+    auto pass = [&](auto SWAP_T, f32x16 (&acc)[MR][2], const char* reg, const char* wp, const char* wnext) __attribute__((always_inline)) {
         constexpr bool SWAP = decltype(SWAP_T)::value;
 #pragma unroll
-        for (int mr = 0; mr < 2; ++mr)
+        for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
             for (int nr = 0; nr < 2; ++nr)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.0f;
         // the B fragments of a record are requested one record ahead of the MFMAs that use them (two register sets)
-        h8 bh[2][2], bl[2][2];
+        h8 bh[2][MR], bl[2][MR];
         auto read_b = [&](const int set, const int kk) __attribute__((always_inline)) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < MR; ++t) {
                 bh[set][t] = *reinterpret_cast<const h8*>(reg + kk * RS + b_off[t]);
                 bl[set][t] = *reinterpret_cast<const h8*>(reg + kk * RS + (b_off[t] ^ 32u));
             }
@@ -164,23 +168,23 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
                 const int kk = 2 * g + i, bs = i;                       // (two records per group: the record's parity is i)
                 if (kk + 1 < KR) read_b(bs ^ 1, kk + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                const h8 (&ah)[2] = bh[bs];
-                const h8 (&al)[2] = bl[bs];
+                const h8 (&ah)[MR] = bh[bs];
+                const h8 (&al)[MR] = bl[bs];
                 // pass-major over the four tiles (a 32x32x16 that depends on the one issued just before it waits out its latency)
                 if constexpr (!SWAP) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) DM3D_MFMA_VV(acc[t >> 1][t & 1], wa[set][4 * i + 2 * (t & 1)], al[t >> 1]);
+                    for (int t = 0; t < 2 * MR; ++t) DM3D_MFMA_VV(acc[t >> 1][t & 1], wa[set][4 * i + 2 * (t & 1)], al[t >> 1]);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) DM3D_MFMA_VV(acc[t >> 1][t & 1], wa[set][4 * i + 2 * (t & 1) + 1], ah[t >> 1]);
+                    for (int t = 0; t < 2 * MR; ++t) DM3D_MFMA_VV(acc[t >> 1][t & 1], wa[set][4 * i + 2 * (t & 1) + 1], ah[t >> 1]);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) DM3D_MFMA_VV(acc[t >> 1][t & 1], wa[set][4 * i + 2 * (t & 1)], ah[t >> 1]);
+                    for (int t = 0; t < 2 * MR; ++t) DM3D_MFMA_VV(acc[t >> 1][t & 1], wa[set][4 * i + 2 * (t & 1)], ah[t >> 1]);
                 } else {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) DM3D_MFMA_VV(acc[t >> 1][t & 1], al[t >> 1], wa[set][4 * i + 2 * (t & 1)]);
+                    for (int t = 0; t < 2 * MR; ++t) DM3D_MFMA_VV(acc[t >> 1][t & 1], al[t >> 1], wa[set][4 * i + 2 * (t & 1)]);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) DM3D_MFMA_VV(acc[t >> 1][t & 1], ah[t >> 1], wa[set][4 * i + 2 * (t & 1) + 1]);
+                    for (int t = 0; t < 2 * MR; ++t) DM3D_MFMA_VV(acc[t >> 1][t & 1], ah[t >> 1], wa[set][4 * i + 2 * (t & 1) + 1]);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) DM3D_MFMA_VV(acc[t >> 1][t & 1], ah[t >> 1], wa[set][4 * i + 2 * (t & 1)]);
+                    for (int t = 0; t < 2 * MR; ++t) DM3D_MFMA_VV(acc[t >> 1][t & 1], ah[t >> 1], wa[set][4 * i + 2 * (t & 1)]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
     auto col8 = [&](int nr, int gq) { return wave * 64 + nr * 32 + 8 * gq; };
 
     // ---- pass 0: y = relu(W_in . x + b_in), kept in registers
-    f32x16 yv[2][2];
+    f32x16 yv[MR][2];
     pass(plain_t, yv, reg_a, w_in, w_q);
     {
         f32x4 bv[2][4];
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) bv[nr][gq] = *reinterpret_cast<const f32x4*>(p.b_in + col0(nr, gq));
 #pragma unroll
-        for (int mr = 0; mr < 2; ++mr) {
+        for (int mr = 0; mr < MR; ++mr) {
             const int row = m0 + mr * 32 + l32;
 #pragma unroll
             for (int nr = 0; nr < 2; ++nr)
@@ -245,42 +249,42 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
         }
     }
     // ---- LayerNormalization statistics of the 64 rows (two-pass): this lane's 32 columns of its two rows, its partner half's, the four waves'
-    float mean[2], rstd[2];
+    float mean[MR], rstd[MR];
     {
 #pragma unroll
-        for (int mr = 0; mr < 2; ++mr) {
+        for (int mr = 0; mr < MR; ++mr) {
             float a = 0.0f;
 #pragma unroll
             for (int nr = 0; nr < 2; ++nr)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a += yv[mr][nr][r];
             a += __shfl_xor(a, 32);
-            if (half == 0) stat[wave * 64 + mr * 32 + l32] = a;
+            if (half == 0) stat[wave * TM + mr * 32 + l32] = a;
         }
         lds_barrier();                                          // (also: every wave has finished reading x — region A is free)
 #pragma unroll
-        for (int mr = 0; mr < 2; ++mr) {
+        for (int mr = 0; mr < MR; ++mr) {
             const int r = mr * 32 + l32;
-            mean[mr] = ((stat[r] + stat[64 + r]) + (stat[128 + r] + stat[192 + r])) * (1.0f / U);
+            mean[mr] = ((stat[r] + stat[TM + r]) + (stat[2 * TM + r] + stat[3 * TM + r])) * (1.0f / U);
             float q = 0.0f;
 #pragma unroll
             for (int nr = 0; nr < 2; ++nr)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { const float d = yv[mr][nr][i] - mean[mr]; q = fmaf(d, d, q); }
             q += __shfl_xor(q, 32);
-            if (half == 0) stat[256 + wave * 64 + r] = q;
+            if (half == 0) stat[4 * TM + wave * TM + r] = q;
         }
         lds_barrier();
 #pragma unroll
-        for (int mr = 0; mr < 2; ++mr) {
+        for (int mr = 0; mr < MR; ++mr) {
             const int r = mr * 32 + l32;
-            const float var = ((stat[256 + r] + stat[320 + r]) + (stat[384 + r] + stat[448 + r])) * (1.0f / U);
+            const float var = ((stat[4 * TM + r] + stat[5 * TM + r]) + (stat[6 * TM + r] + stat[7 * TM + r])) * (1.0f / U);
             rstd[mr] = rsqrtf(var + p.eps);
         }
     }
     // normalised rows in place, then the three affine copies: n3 -> HBM (the MLP's input), n1 -> region B, n2 -> region A
 #pragma unroll
-    for (int mr = 0; mr < 2; ++mr)
+    for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
         for (int nr = 0; nr < 2; ++nr)
 #pragma unroll
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
                 tv[nr][gq] = *reinterpret_cast<const f32x4*>(bet + col0(nr, gq));
             }
 #pragma unroll
-        for (int mr = 0; mr < 2; ++mr)
+        for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
             for (int nr = 0; nr < 2; ++nr)
 #pragma unroll
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
     lds_barrier();                                              // n1 and n2 are visible
 
     // ---- passes 1, 2: q | k = W_qk . n1 + b_qk  -> qk[:, 0..255 | 256..511]
-    f32x16 acc[2][2];
+    f32x16 acc[MR][2];
     static_for<2>([&](auto P_) __attribute__((always_inline)) {
         constexpr int pi = decltype(P_)::value;
         pass(plain_t, acc, reg_b, pi == 0 ? w_q : w_k, pi == 0 ? w_k : w_v);
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) bv[nr][gq] = *reinterpret_cast<const f32x4*>(p.b_qk + pi * U + col0(nr, gq));
 #pragma unroll
-        for (int mr = 0; mr < 2; ++mr)
+        for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
             for (int nr = 0; nr < 2; ++nr)
 #pragma unroll
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
             const int ch = wave * 64 + nr * 32 + l32;
             const float bias = p.b_v[ch];
 #pragma unroll
-            for (int mr = 0; mr < 2; ++mr)
+            for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     float v[4];
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(256, 1) void attn_front_h3(const FrontArgs p) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) bv[nr][gq] = *reinterpret_cast<const f32x4*>(p.b_qk + col0(nr, gq));
 #pragma unroll
-        for (int mr = 0; mr < 2; ++mr)
+        for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
             for (int nr = 0; nr < 2; ++nr)
 #pragma unroll
@@ -409,6 +413,11 @@ extern "C" int dm3d_attn_front(const dm3d_attn_front_desc* d, void* stream) {
     DM3D_REQUIRE(d != nullptr, "attn_front: null descriptor");
     DM3D_REQUIRE(d->units == 256, "attn_front: units=%d (this kernel is built for 256: the U-Net's attention width; use dm3d_gemm_tn + dm3d_layernorm3_h2 otherwise)", d->units);
     DM3D_REQUIRE(d->m > 0 && d->m % 64 == 0, "attn_front: m=%d must be a positive multiple of 64", d->m);
+    // Tile form.  Measured (tools/front_time.py; us per launch at m = 512 / 2 048 / 8 192 / 16 384): 32-row tiles 24 / 26 / 31 / 60, 64-row
+    // tiles 36 / 37 / 41 / 54 — a workgroup's latency is what small launches pay (32-row tiles: two thirds of it, and twice the workgroups), the
+    // weight traffic per row what a launch that fills the chip twice over pays.  DM3D_FRONT_MR=1|2 forces a form (read per call: an A/B switch).
+    const char* mr_env = getenv("DM3D_FRONT_MR");
+    const int mr = (mr_env && (mr_env[0] == '1' || mr_env[0] == '2')) ? mr_env[0] - '0' : (d->m <= 8192 ? 1 : 2);
     DM3D_REQUIRE(d->x && d->w_in && d->b_in && d->w_qk && d->b_qk && d->w_v && d->b_v, "attn_front: x / weights / biases must be non-null");
     DM3D_REQUIRE(d->g1 && d->be1 && d->g2 && d->be2 && d->g3 && d->be3, "attn_front: the three LayerNormalization (gamma, beta) pairs must be non-null");
     DM3D_REQUIRE(d->y && d->qk && d->vt && d->q2 && d->n3, "attn_front: y / qk / vt / q2 / n3 must be non-null");
@@ -425,16 +434,17 @@ extern "C" int dm3d_attn_front(const dm3d_attn_front_desc* d, void* stream) {
     a.g1 = d->g1; a.be1 = d->be1; a.g2 = d->g2; a.be2 = d->be2; a.g3 = d->g3; a.be3 = d->be3; a.eps = d->eps;
     a.y = d->y; a.ldy = d->ldy; a.qk = d->qk; a.ldqk = d->ldqk; a.vt = d->vt; a.ldvt = d->ldvt; a.q2 = d->q2; a.ldq2 = d->ldq2; a.n3 = d->n3; a.ldn3 = d->ldn3;
     a.m = d->m; a.range_flag = d->range_flag; a.range_limit = d->range_limit > 0.0f ? d->range_limit : 65504.0f;
-    constexpr size_t lds = 2 * 16 * (64 * 64 + 32) + 2 * 4 * 64 * sizeof(float);       // two operand images + the statistics exchange
-    static_assert(lds <= 160 * 1024, "one workgroup per CU");
-    static bool attr_set[64] = {false};
+    const size_t lds = (size_t)2 * 16 * (32 * mr * 64 + 32) + (size_t)2 * 4 * 32 * mr * sizeof(float);       // two operand images + the statistics exchange
+    static bool attr_set[64][2] = {};
     int dev = 0;
     DM3D_HIP(hipGetDevice(&dev));
     DM3D_REQUIRE(dev >= 0 && dev < 64, "attn_front: device ordinal %d", dev);
-    if (!attr_set[dev]) {
-        DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_front_h3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[dev] = true;
+    if (!attr_set[dev][mr - 1]) {
+        if (mr == 2) DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_front_h3<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_front_h3<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dev][mr - 1] = true;
     }
-    hipLaunchKernelGGL(attn_front_h3, dim3((unsigned)(d->m / 64)), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    if (mr == 2) hipLaunchKernelGGL(attn_front_h3<2>, dim3((unsigned)(d->m / 64)), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(attn_front_h3<1>, dim3((unsigned)(d->m / 32)), dim3(256), lds, static_cast<hipStream_t>(stream), a);
     return dm3d_launch_check("attn_front_h3");
 }

@@ -383,11 +383,13 @@ def test_mlp_fused_against_float64(dev, m, out_h2):
         assert float((out.cpu().double() - (ref2 - r3.double())).abs().max() / ref2.abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("mr", ["1", "2"], ids=["32-row tiles", "64-row tiles"])
 @pytest.mark.parametrize("m", [64, 1024], ids=["one tile", "16 tiles"])
-def test_attn_front_against_float64(dev, m):
+def test_attn_front_against_float64(dev, monkeypatch, m, mr):
     """dm3d_attn_front: relu(proj_in) -> three LayerNormalizations -> q|k, v^T, q2 projections in one launch (conditional_dm3d.py:186-193,
     163-170) against float64, and against the three launches it replaces; u = 256."""
     from dm3d_amd import ops
+    monkeypatch.setenv("DM3D_FRONT_MR", mr)
     u = 256
     g = torch.Generator().manual_seed(7)
     x = torch.randn(m, u, generator=g) * 2.0
