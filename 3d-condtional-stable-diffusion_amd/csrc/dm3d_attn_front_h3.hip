@@ -435,7 +435,7 @@ extern "C" int dm3d_attn_front(const dm3d_attn_front_desc* d, void* stream) {
     a.y = d->y; a.ldy = d->ldy; a.qk = d->qk; a.ldqk = d->ldqk; a.vt = d->vt; a.ldvt = d->ldvt; a.q2 = d->q2; a.ldq2 = d->ldq2; a.n3 = d->n3; a.ldn3 = d->ldn3;
     a.m = d->m; a.range_flag = d->range_flag; a.range_limit = d->range_limit > 0.0f ? d->range_limit : 65504.0f;
     const size_t lds = (size_t)2 * 16 * (32 * mr * 64 + 32) + (size_t)2 * 4 * 32 * mr * sizeof(float);       // two operand images + the statistics exchange
-    static bool attr_set[64][2] = {};
+    static std::atomic<bool> attr_set[64][2] = {};     // (atomic: two host threads may meet in a first launch; the attribute call itself is idempotent)
     int dev = 0;
     DM3D_HIP(hipGetDevice(&dev));
     DM3D_REQUIRE(dev >= 0 && dev < 64, "attn_front: device ordinal %d", dev);

@@ -292,7 +292,7 @@ int dm3d_attention_fused_launch(const dm3d_attention_desc* descs, int count, hip
     constexpr size_t lds_stage = (size_t)2 * (K_TILE + V_TILE) * sizeof(_Float16), lds_out = (size_t)4 * 32 * O_LD * sizeof(float);
     constexpr size_t lds = lds_stage > lds_out ? lds_stage : lds_out;
     static_assert(lds <= 160 * 1024, "LDS");
-    static bool attr_set[64] = {false};            // per device: the attribute belongs to the device the launch goes to
+    static std::atomic<bool> attr_set[64] = {};            // per device: the attribute belongs to the device the launch goes to
     int dev_ = 0;
     DM3D_HIP(hipGetDevice(&dev_));
     DM3D_REQUIRE(dev_ >= 0 && dev_ < 64, "attention: device ordinal %d", dev_);

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 #include "dm3d.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -370,7 +370,7 @@ int launch_h3(ConvArgs& a, hipStream_t st) {
     a.bd = (a.od + TD - 1) / TD;
     a.bh = (a.oh + TH - 1) / TH;
     a.bw = (a.ow + TW - 1) / TW;
-    static bool attr_set[64] = {false};            // per device: the attribute belongs to the device the launch goes to
+    static std::atomic<bool> attr_set[64] = {};            // per device: the attribute belongs to the device the launch goes to
     int dev_ = 0;
     DM3D_HIP(hipGetDevice(&dev_));
     DM3D_REQUIRE(dev_ >= 0 && dev_ < 64, "conv: device ordinal %d", dev_);

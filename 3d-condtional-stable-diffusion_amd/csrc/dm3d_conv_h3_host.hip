@@ -96,8 +96,12 @@ int dm3d_h3v2_pre_launch(ConvArgs& a, int td, H3v2Launch& L, hipStream_t st, int
     // split, plain float32 output without PReLU); every other form leaves them to the stand-alone kernel behind the launch (post_launch).
     L.stats_after = false;
     if (a.gn_stats) {
+#ifdef DM3D_EPILOGUE_SCALAR
+        const bool fused = false;            // (that A/B build compiles the 16-byte epilogue — the only form that accumulates — out)
+#else
         const bool fused = a.od % td == 0 && a.oh % 8 == 0 && a.ow % 8 == 0 && a.cout % 64 == 0 && a.ksplit == 1 && a.epi_vec4 && !a.prelu
                            && !a.out_h2 && !a.post_scale;
+#endif
         if (!fused) { k.gn_stats = nullptr; L.stats_after = true; }
     }
     if (a.ksplit > 1 && (!with_scratch || atomic2)) {         // two halves, order-independent atomic add into the zeroed output

@@ -436,7 +436,7 @@ int launch_v3(ConvArgs& a, hipStream_t st) {
     constexpr int main_halfs = HREC * REC + 4 * 2 * 64 * REC, skip_halfs = (KS == 3 && NCT == 4) ? skip_lds_halfs<TD>() : 0;
     constexpr size_t lds = (size_t)(main_halfs > skip_halfs ? main_halfs : skip_halfs) * sizeof(_Float16);
     static_assert((TD == 4 ? 2 : 1) * lds <= 160 * 1024, "workgroups per CU x LDS");
-    static bool attr_set[64] = {false};            // per device: the attribute belongs to the device the launch goes to
+    static std::atomic<bool> attr_set[64] = {};            // per device: the attribute belongs to the device the launch goes to
     int dev = 0;
     DM3D_HIP(hipGetDevice(&dev));
     DM3D_REQUIRE(dev >= 0 && dev < 64, "conv: device ordinal %d", dev);

@@ -728,6 +728,12 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
                 h8 ahi[8], alo[8];
 #pragma unroll
                 for (int t = 0; t < 8; ++t) split8(ar0[S][t], ar1[S][t], lim0[S], lim1[S], ahi[t], alo[t]);
+                // A VALU write of an MFMA operand needs two wait states before an asm MFMA reads it (hipcc pads one at the statement boundary,
+                // and the MFMA then reads the STALE register in > 99 % of the cases: tools/micro/mfma_hazards.hip, profiles/r05_mfma_hazards.log):
+                // the split's last v_cvt_pk sat one state in front of the first MFMA.  tools/isa_hazard.py checks this file's ISA at build time.
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 1" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
                 // pass-major: an accumulator tile is touched once per 32 MFMAs; tile t = 4 s + 2 g + parity -> acc[parity][2 s + g][ni]
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
@@ -816,16 +822,17 @@ int launch_w(ConvArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)(4 * 2 * 64 * REC + 10 * 10 * 17 * REC) * sizeof(_Float16);      // 32 KB of weights + 106 KB of image
     static_assert(lds <= 160 * 1024, "one workgroup per CU");
     // (per device: the attribute and the CU count belong to the device the launch goes to)
-    static int cus[64] = {0};
+    static std::atomic<int> cus[64] = {};
     int dev = 0;
     DM3D_HIP(hipGetDevice(&dev));
     DM3D_REQUIRE(dev >= 0 && dev < 64, "conv: device ordinal %d", dev);
-    if (cus[dev] == 0) {
+    if (cus[dev].load(std::memory_order_acquire) == 0) {       // (two host threads may meet here: both set the same attribute and store the same count)
         DM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_igemm_h3w<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int n = 0;
         DM3D_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-        cus[dev] = n > 0 ? n : 256;
+        cus[dev].store(n > 0 ? n : 256, std::memory_order_release);
     }
+    const int ncu = cus[dev].load(std::memory_order_relaxed);
     H3v2Launch L;
     if (int rc = dm3d_h3v2_pre_launch(a, 8, L, st, dm3d_conv_h3w_ksplit(a))) return rc;
     L.k.wpk = a.wpk_wino;
@@ -834,7 +841,9 @@ int launch_w(ConvArgs& a, hipStream_t st) {
     const long items = (long)a.batch * a.bd * a.bh * a.bw * (a.coutpad / 64) * a.ksplit;
     static const bool persist = [] { const char* e = getenv("DM3D_CONV_WINO_PERSIST"); return !(e && e[0] == '0'); }();
     long g = items;
-    if (persist && items > cus[dev]) g = (items % 8 == 0) ? (cus[dev] / 8 * 8) : cus[dev];
+    // (a partition that reports fewer than 8 CUs has no whole XCD round: one workgroup per CU, never an empty grid)
+    if (persist && items > ncu) g = (items % 8 == 0 && ncu >= 8) ? (ncu / 8 * 8) : ncu;
+    if (g < 1) g = 1;
     if (persist) {                           // test knob (read per call): at most this many workgroups, so that small shapes walk item lists too
         const char* cap = getenv("DM3D_CONV_WINO_GRID");
         if (cap && atol(cap) > 0 && atol(cap) < g) g = atol(cap);

@@ -438,7 +438,7 @@ template <int MR>
 static int launch_group_mr(GemmGroup& g, bool af, bool bf, hipStream_t st) {
     constexpr int TM = 64 * MR, NT = 64 * MR;
     constexpr size_t lds = (size_t)(2 * 2 * TM * REC + 2 * 2 * NT * REC) * sizeof(_Float16);     // 65536 (MR 2) / 32768 (MR 1)
-    static bool attr_set[64] = {false};            // per device: the attribute belongs to the device the launch goes to
+    static std::atomic<bool> attr_set[64] = {};            // per device: the attribute belongs to the device the launch goes to
     int dev = 0;
     DM3D_HIP(hipGetDevice(&dev));
     DM3D_REQUIRE(dev >= 0 && dev < 64, "gemm(h3): device ordinal %d", dev);

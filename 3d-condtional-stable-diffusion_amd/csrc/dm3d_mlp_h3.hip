@@ -117,12 +117,16 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3(const MlpArgs p) {
     __builtin_amdgcn_s_barrier();                              // everyone has its copy: the staging area becomes the H slab and the ring
     asm volatile("" ::: "memory");
     // x from the accumulation file; accumulators and the other fragments architectural.  Inline asm: hipcc's hazard pass does not see an
-    // MFMA in it — DM3D_MFMA_DRAIN stands in front of every vector read of an accumulator.
-#define DM3D_MFMA_VX(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
-#define DM3D_MFMA_VV(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
-// (alone between two scheduling barriers: hipcc otherwise places VALU instructions — address arithmetic of the loads that follow — between the
-// last MFMA and the drain, and one of them may write a register that MFMA still reads as an operand: on gfx950 the K = 16 MFMA reads its
-// operands over several passes, and behind an asm MFMA hipcc's hazard pass inserts nothing; found in dm3d_attn_front_h3.hip)
+    // MFMA in it, so the two pads it would insert are written here (rules and their measurement: tools/isa_hazard.py, tools/micro/mfma_hazards.hip,
+    // profiles/r05_mfma_hazards.log; the build runs the checker over this file's ISA, tests/test_host.py):
+    //  * `s_nop 1` INSIDE every MFMA statement, in front of the MFMA: a VALU write of A, B or C needs two wait states before the MFMA reads
+    //    it, and hipcc materialises the copies of a "+v" accumulator (v_mov_b64 of the zeroed tile) directly in front of the statement —
+    //    a stand-alone fence would sit in front of those copies.  Free when the matrix pipe is the pace (8 + 8 of a 32-cycle 32x32x16).
+    //  * DM3D_MFMA_DRAIN (P + 4 = 12 wait states, here 32) in front of every vector read of an accumulator.
+    // (Round 4 read the failure this guards against as a write-after-read on A / B behind the MFMA; the probe shows that one does not exist
+    // on gfx950 — operands are read at issue — and that the read-after-write in FRONT of it does.)
+#define DM3D_MFMA_VX(acc, a, b) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
+#define DM3D_MFMA_VV(acc, a, b) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 #define DM3D_MFMA_DRAIN() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
     f32x16 acc_out[2][2];                                       // [row tile mr][column tile nr]: lane = row 32 mr + l32, register r = column 32 nr + (r & 3) + 8 (r >> 2) + 4 half of the wave's 64
@@ -452,7 +456,7 @@ extern "C" int dm3d_mlp_fused(const dm3d_mlp_desc* d, void* stream) {
         a.w2 = d->w2; a.b2 = d->b2; a.res3 = d->res3; a.ldr3 = d->ldr3;
     }
     constexpr size_t lds = 64 * 1040;                       // the x staging area of the prologue; the H slab (32 KB) overlays it afterwards
-    static bool attr_set[64] = {false};
+    static std::atomic<bool> attr_set[64] = {};
     int dev = 0;
     DM3D_HIP(hipGetDevice(&dev));
     DM3D_REQUIRE(dev >= 0 && dev < 64, "mlp_fused: device ordinal %d", dev);

@@ -118,20 +118,20 @@ class DiffusionModel:
     def load_state_dict(self, sd, strict=True):
         """Weights by name; ``optimizer/...`` entries (save_weights of a trained model) restore the Adam slots and step count, so a
         resumed run continues the bias correction where it stopped; without them the optimizer starts afresh."""
-        self._sync_from_trainer()                                  # a non-strict load fills missing names from the CURRENT (trained) weights
+        # validated BEFORE anything is touched: a checkpoint with partial slots fails here with the model as it was (new weights with the
+        # old Adam state gone would be a half-loaded model)
         opt = {k: v for k, v in sd.items() if k.startswith("optimizer/")}
-        self.network.load_state_dict({k: v for k, v in sd.items() if not k.startswith("optimizer/")}, strict)
-        self._drop_graphs()
-        self._trainer, self._trainer_dirty = None, False          # Adam moments belong to the weights they were built for
-        # the slots wait until a Trainer exists (an inference-only load builds none: theta, gradients and moments are four copies of the
-        # weights); validated now, so that a checkpoint with partial slots fails at load time with a message
-        self._pending_optimizer = None
         if opt:
             missing = [k for k in ["optimizer/iter"] + [f"optimizer/{slot}/{n}" for n in self._trainable_names() for slot in ("m", "v")] if k not in opt]
             if missing:
                 raise ValueError(f"checkpoint carries optimizer state but {len(missing)} entries are missing (first: {missing[:3]}); "
                                  "drop every optimizer/ entry to load the weights alone")
-            self._pending_optimizer = opt
+        self._sync_from_trainer()                                  # a non-strict load fills missing names from the CURRENT (trained) weights
+        self.network.load_state_dict({k: v for k, v in sd.items() if not k.startswith("optimizer/")}, strict)
+        self._drop_graphs()
+        self._trainer, self._trainer_dirty = None, False          # Adam moments belong to the weights they were built for
+        # the slots wait until a Trainer exists (an inference-only load builds none: theta, gradients and moments are four copies of the weights)
+        self._pending_optimizer = opt or None
 
     def _trainable_names(self):
         """Names of the parameters Adam updates (everything but the BatchNormalization moving statistics)."""

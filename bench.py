@@ -221,13 +221,27 @@ def main():
     W = dm3d_amd.synthetic_weights(cfg, seed=0)
     W = parallel.broadcast_state(W if rank == 0 else None, spec, src=0, device=comm_dev)   # RCCL broadcast over xGMI (no-op at N=1)
     # every rank's identity: device, Philox seed, digest of the weights it holds after the broadcast (must all agree)
+    # (PCI bus id / UUID of the device this rank computes on and the world size its process group reports: an N-rank line must show N
+    # distinct devices)
+    ident = {"pci_bus_id": None, "uuid": None}
+    if not dry:
+        pr = torch.cuda.get_device_properties(dev_index)
+        if getattr(pr, "pci_bus_id", None) is not None:
+            ident["pci_bus_id"] = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{getattr(pr, 'pci_device_id', 0):02x}"
+        ident["uuid"] = str(getattr(pr, "uuid", "")) or None
     me = json.dumps({"rank": rank, "device": "none (cpu rehearsal)" if dry else torch.cuda.get_device_name(dev_index), "device_index": dev_index,
+                     "pci_bus_id": ident["pci_bus_id"], "uuid": ident["uuid"], "pid": os.getpid(),
+                     "world_size_seen": dist.get_world_size() if world > 1 else 1,
                      "seed": parallel.rank_seed(1234, rank), "weights_sha": parallel.state_digest(W)})
     ranks_info = {"world_size": dist.get_world_size() if world > 1 else 1,
                   "backend": dist.get_backend() if world > 1 else None,
                   "per_rank": [json.loads(x) for x in parallel.gather_strings(me)]}
     if len({r["weights_sha"] for r in ranks_info["per_rank"]}) != 1:
         raise SystemExit("ranks hold different weights after the broadcast")
+    ids = [r["uuid"] or r["pci_bus_id"] for r in ranks_info["per_rank"]]
+    ranks_info["distinct_devices"] = len(set(ids)) if all(ids) else None
+    if not rehearsal and world > 1 and ranks_info["distinct_devices"] not in (None, world):
+        raise SystemExit(f"{world} ranks but {ranks_info['distinct_devices']} distinct devices: {ids}")
     if dry:
         K = args.steps
         dist.barrier() if world > 1 else None
@@ -335,6 +349,25 @@ def main():
             peak, passes = PEAK_F16_MFMA_TFLOPS, 3
         else:
             kname, peak, passes = "conv3d_igemm_f32<4, 8, 8, 1, 3, 4, 1> (k3 stride-1 Conv3d, v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS, 1
+        # the WHOLE conv set of the step (every kind that is a Conv3D launch): sum of algorithmic FLOPs / sum of time / peak
+        conv_kinds = [k for k in acc if k.startswith("conv")]
+        conv_fl, conv_ms = sum(acc[k][2] for k in conv_kinds), sum(acc[k][1] for k in conv_kinds)
+        conv_ex, conv_us = sum(acc[k][4] for k in conv_kinds), sum(acc[k][5] for k in conv_kinds)
+        conv_all = {"kinds": sorted(conv_kinds), "ms_per_step": round(conv_ms / reps, 4),
+                    "algorithmic_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
+                    "algorithmic_frac_of_peak": round(conv_fl / (conv_ms * 1e-3) / 1e12 / peak, 4),
+                    "executed_mfma_frac_of_peak": round(conv_ex / (conv_ms * 1e-3) / 1e12 / peak, 4),
+                    "useful_mfma_frac_of_peak": round(conv_us / (conv_ms * 1e-3) / 1e12 / peak, 4)}
+        # the second kernel of the step (MODE-2 twin behind a DM3D_FMT_H2 hand-off, with its fused skip tails): its own algorithmic figures
+        secondary = None
+        if dom == "conv_wino" and "conv_wino_h2in" in acc:
+            n2, ms2, fl2, by2, ex2, us2 = acc["conv_wino_h2in"]
+            secondary = {"kernel": "conv3d_igemm_h3w<2> (the same kernel reading a pre-activated, pre-split DM3D_FMT_H2 tensor: ResidualBlock conv2 "
+                                   "behind the conv1 hand-off, incl. its fused 1x1 skip tails)",
+                         "achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(fl2 / (ms2 * 1e-3) / 1e12 / peak, 4), "avg_launch_ms": round(ms2 / n2, 4), "launches_per_step": n2 // reps,
+                         "algorithmic_gflop_per_launch": round(fl2 / n2 / 1e9, 2), "algorithmic_mb_per_launch": round(by2 / n2 / 1e6, 2),
+                         "useful_mfma_frac_of_peak": round(us2 / (ms2 * 1e-3) / 1e12 / peak, 4), "traffic": None}
         roofline = {"bound": "mfma", "kernel": kname,
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": None,
@@ -349,7 +382,8 @@ def main():
                     "achieved_vs_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                     "avg_launch_ms": round(ms / n, 4), "launches_per_step": n // reps,
                     "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
-                    "algorithmic_mb_per_launch": round(by / n / 1e6, 2)}
+                    "algorithmic_mb_per_launch": round(by / n / 1e6, 2),
+                    "all_convs": conv_all, "secondary": secondary}
 
     # HBM traffic of the dominant kernel: PMC counters need their own rocprofv3 passes (MI355X_MICROARCH.md), so the figure
     # comes from the committed summary of those passes over this same command (profiles/summarize_pmc.py), not from this run.
@@ -373,6 +407,13 @@ def main():
                 log(reason)
                 continue
             roofline["traffic"] = float(rows[0][4]) * 1e6
+            if roofline.get("secondary"):
+                rows2 = [r for r in csv.reader(l for l in lines if not l.startswith("#")) if r and r[0] == "conv3d_igemm_h3w<2>"]
+                if rows2:
+                    sec = roofline["secondary"]
+                    sec["traffic"] = float(rows2[0][4]) * 1e6
+                    sec["traffic_over_algorithmic"] = round(sec["traffic"] / (sec["algorithmic_mb_per_launch"] * 1e6), 3) if sec["algorithmic_mb_per_launch"] else None
+            roofline["traffic_over_algorithmic"] = round(roofline["traffic"] / (roofline["algorithmic_mb_per_launch"] * 1e6), 3) if roofline["algorithmic_mb_per_launch"] else None
             roofline["traffic_unit"] = "bytes/launch (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc, " + os.path.basename(path) + ")"
             roofline["hbm_GBps_of_kernel"] = round(roofline["traffic"] / (roofline["avg_launch_ms"] * 1e-3) / 1e9, 1)
             roofline["hbm_frac_of_8TBps"] = round(roofline["hbm_GBps_of_kernel"] / 8000.0, 4)
@@ -518,8 +559,18 @@ def main():
             "per_kernel_kind_note": "eager launches with a HIP-event pair around each (event overhead included; the timed step is "
                                     "a HIP-graph replay, so these rows sum to slightly more than ms_per_step)",
             "ranks": ranks_info,
-            "conv_mfma_util_pct": None if roofline is None else round(100 * roofline["executed_mfma_frac_of_peak"], 2),
-            "conv_mfma_useful_util_pct": None if roofline is None else round(100 * roofline["useful_mfma_frac_of_peak"], 2),
+            # MFMA utilisation of the Conv3d set, three accountings (all against the dense peak of the MFMA datatype used):
+            #   executed  = every MFMA issued (h3: three passes per product; the Winograd form's zero pad steps included)
+            #   useful    = executed minus the pad steps
+            #   algorithmic = SURVEY 8(d): 2*27*Cin*Cout FLOPs per output voxel / time — what BASELINE's "MFMA util %" is judged on
+            # "dominant" = the roofline kernel alone, "all" = every conv launch of the step
+            "conv_mfma_executed_pct": None if roofline is None else {"dominant": round(100 * roofline["executed_mfma_frac_of_peak"], 2),
+                                                                     "all": round(100 * roofline["all_convs"]["executed_mfma_frac_of_peak"], 2)},
+            "conv_mfma_useful_pct": None if roofline is None else {"dominant": round(100 * roofline["useful_mfma_frac_of_peak"], 2),
+                                                                   "all": round(100 * roofline["all_convs"]["useful_mfma_frac_of_peak"], 2)},
+            "conv_algorithmic_pct_of_peak": None if roofline is None else {"dominant": round(100 * roofline["frac"], 2),
+                                                                           "all": round(100 * roofline["all_convs"]["algorithmic_frac_of_peak"], 2)},
+            "conv_algorithmic_frac_of_peak": None if roofline is None else roofline["all_convs"]["algorithmic_frac_of_peak"],
             "precision": args.precision, "norm": args.norm,
         }
         print(json.dumps(line), flush=True)

@@ -248,6 +248,10 @@ def test_optimizer_state_survives_save_and_load(dev, tmp_path):
     del part[next(k for k in part if k.startswith("optimizer/v/"))]
     with pytest.raises(ValueError, match="optimizer state"):
         c.load_state_dict(part)
+    # ... and leaves the model as it was: same weights, the Trainer and its Adam state still there (validate before mutating)
+    assert c._trainer is not None and c.trainer.step_count == 1
+    sc2 = c.network.state_dict()
+    assert all(np.array_equal(sc[k], sc2[k]) for k in sc)
     with pytest.warns(UserWarning, match="Adam slots"):                 # the TF-format writer stores the network only and says so
         a.save_weights(str(tmp_path / "tfck"))
 
