@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DM3D_LIB") or os.path.join(_HERE, "csrc", "libdm3d_hip.so")     # DM3D_LIB: A/B builds (tools)
 
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
-ABI_VERSION = 110                   # DM3D_VERSION of include/dm3d.h these ctypes mirrors were written against
+ABI_VERSION = 111                   # DM3D_VERSION of include/dm3d.h these ctypes mirrors were written against
 PREC_F32, PREC_H3 = 0, 1
 WL_TAP, WL_PAIR = 0, 1
 FMT_F32, FMT_H2 = 0, 1
@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ("x1_fmt", C.c_int32), ("out_fmt", C.c_int32), ("post_scale", _f32p), ("post_shift", _f32p),
         ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64),
         ("range_flag", C.c_void_p), ("range_limit", C.c_float), ("wpk_wino", C.c_void_p), ("skip_wpk_frag", C.c_void_p), ("gn_stats", C.c_void_p),
+        ("split_counters", C.c_void_p), ("split_counter_words", C.c_int32),
     ]
 
 
@@ -129,6 +130,7 @@ SIGNATURES = {
     "dm3d_pack_weights_skip_h3p": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "dm3d_pack_weights_skip_h3f": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "dm3d_conv_scratch_bytes": (C.c_int64, [C.POINTER(ConvDesc)]),
+    "dm3d_conv_split_counter_words": (C.c_int32, [C.POINTER(ConvDesc)]),
     "dm3d_conv_tile_form": (C.c_int32, [C.POINTER(ConvDesc)]),
     "dm3d_conv_weight_layout": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "dm3d_attention_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),

@@ -280,6 +280,8 @@ extern "C" int dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream) {
     a.relu = d->relu; a.res = d->res; a.out = d->out; a.cout = d->cout;
     a.prelu = d->prelu_alpha; a.relu_out = d->relu_out;
     a.scratch = d->scratch; a.scratch_bytes = d->scratch_bytes;
+    DM3D_REQUIRE((d->split_counters == nullptr) == (d->split_counter_words == 0) && d->split_counter_words >= 0, "conv: split_counters and split_counter_words go together");
+    a.split_counters = d->split_counters; a.split_counter_words = d->split_counter_words;
     a.range_flag = d->range_flag; a.range_limit = d->range_limit > 0.0f ? d->range_limit : 65504.0f;
     if (d->wpk_wino) {
         DM3D_REQUIRE(d->precision == DM3D_PREC_H3 && dm3d_aligned16(d->wpk_wino), "conv: wpk_wino needs precision H3 and 16-byte alignment");
@@ -373,25 +375,49 @@ extern "C" int32_t dm3d_conv_tile_form(const dm3d_conv_desc* d) {
     a.swpk_f = d->skip_wpk ? d->skip_wpk_frag : nullptr; a.sc1 = d->skip_c1; a.sc2 = d->skip_c2;
     a.wpk_wino = d->wpk_wino; a.cout = d->cout; a.c1 = d->c1; a.c2 = d->c2; a.ind = d->in_d; a.inh = d->in_h; a.inw = d->in_w;
     a.nchunks = (int)(dm3d_round_up(d->c1 + d->c2, DM3D_CIN_PAD) / 16);
-    a.x1 = d->x1; a.x2 = d->x2; a.out = d->out; a.res = d->res; a.relu = d->relu; a.relu_out = d->relu_out; a.prelu = d->prelu_alpha;      // (the Cin split
-    a.out_h2 = d->out_fmt == DM3D_FMT_H2; a.post_scale = d->post_scale;                                                                      //  needs a linear epilogue)
+    a.x1 = d->x1; a.x2 = d->x2; a.out = d->out; a.res = d->res; a.relu = d->relu; a.relu_out = d->relu_out; a.prelu = d->prelu_alpha;
+    a.out_h2 = d->out_fmt == DM3D_FMT_H2; a.post_scale = d->post_scale;
+    a.split_counters = d->split_counters; a.split_counter_words = d->split_counter_words;      // (no Cin split without them)
     a.padz = a.pady = a.padx = (d->ksize == 3 && d->stride == 1 && !par_mode) ? 1 : 0;
     if (dm3d_conv_h3w_serves(a, (d->ksize == 3 && d->stride == 1 && !par_mode) ? DM3D_CONV_K3S1 : DM3D_CONV_UP)) return 10;
     return dm3d_conv_h3v3_td(a);
 }
 
-extern "C" int64_t dm3d_conv_scratch_bytes(const dm3d_conv_desc* d) {
-    if (!d || d->precision != DM3D_PREC_H3 || d->batch <= 0 || d->cout <= 0 || d->in_d <= 0 || d->in_h <= 0 || d->in_w <= 0) return 0;
-    if (dm3d_conv_weight_layout(d->ksize, d->stride, d->upsample, d->transpose, d->cout) != DM3D_WL_PAIR) return 0;
+// What a Cin-split launch of this descriptor needs (the hand-over form, dm3d_conv_h3v2_parts.h): tiles x parts x a tile's image.  Both
+// 16x16x32 kernels are asked (which one serves the launch depends on the weight images the caller passes at launch time): the larger need.
+static void split_needs(const dm3d_conv_desc* d, int64_t& bytes, int64_t& words) {
+    bytes = words = 0;
+    if (!d || d->precision != DM3D_PREC_H3 || d->batch <= 0 || d->cout <= 0 || d->in_d <= 0 || d->in_h <= 0 || d->in_w <= 0) return;
+    if (dm3d_conv_weight_layout(d->ksize, d->stride, d->upsample, d->transpose, d->cout) != DM3D_WL_PAIR) return;
     const bool par = d->upsample || d->transpose;
     ConvArgs a{};
+    int dummy = 0;
+    a.split_counters = &dummy;                               // "the host will provide them": what the split would be
     a.batch = d->batch; a.od = d->in_d; a.oh = d->in_h; a.ow = d->in_w; a.parity = par ? 1 : 0;
     a.coutpad = (int)dm3d_round_up(d->cout, DM3D_COUT_PAD);
     a.nchunks = (int)(dm3d_round_up(d->c1 + d->c2, DM3D_CIN_PAD) / 16);
-    const int ks = dm3d_conv_h3v2_ksplit(a, true);
-    if (ks <= 1) return 0;
-    const int os = par ? 2 : 1;
-    return (int64_t)ks * d->batch * d->in_d * os * d->in_h * os * d->in_w * os * d->cout * (int64_t)sizeof(float);
+    const int ks = dm3d_conv_h3v2_ksplit(a);
+    if (ks > 1) {
+        words = dm3d_conv_split_tiles(a, 4);
+        bytes = words * ks * (int64_t)(4 * 8 * 8 * 64) * (int64_t)sizeof(float);
+    }
+    if (d->ksize == 3 && d->stride == 1 && !par && d->cout > 32 && d->in_d % 8 == 0 && d->in_h % 8 == 0 && d->in_w % 8 == 0 && dm3d_conv_h3w_ksplit(a) > 1) {
+        const int64_t tw = dm3d_conv_split_tiles(a, 8), bw = tw * 2 * (int64_t)(8 * 8 * 8 * 64) * (int64_t)sizeof(float);
+        if (tw > words) words = tw;
+        if (bw > bytes) bytes = bw;
+    }
+}
+
+extern "C" int64_t dm3d_conv_scratch_bytes(const dm3d_conv_desc* d) {
+    int64_t bytes, words;
+    split_needs(d, bytes, words);
+    return bytes;
+}
+
+extern "C" int32_t dm3d_conv_split_counter_words(const dm3d_conv_desc* d) {
+    int64_t bytes, words;
+    split_needs(d, bytes, words);
+    return (int32_t)words;
 }
 
 extern "C" int32_t dm3d_conv_weight_layout(int32_t ksize, int32_t stride, int32_t upsample, int32_t transpose, int32_t cout) {

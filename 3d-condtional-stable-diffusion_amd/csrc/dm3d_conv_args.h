@@ -23,9 +23,12 @@ struct ConvArgs {
     int nchunks;
     int batch;
     float out_scale;          // H3: 2^-w_exp, applied to the accumulator
-    int ksplit;               // h3v2: workgroups per brick along Cin (each contracts nchunks / ksplit chunks)
-    int split_atomic;         // ksplit == 2 without scratch: both halves add into the zeroed output (order-independent for two)
-    long split_stride;        // ksplit > 1 with scratch: elements between the partial-sum images; out points at image 0
+    int ksplit;               // h3v2: workgroups per brick along Cin (each contracts nchunks / ksplit chunks); > 1: the hand-over form
+                              // (dm3d_conv_h3v2_parts.h, split_*): every part stores its raw accumulator tiles into scratch, the part that
+                              // draws the last ticket of its tile sums them in part order and runs the epilogue
+    int* split_counters;      // one ticket word per tile (brick x column tile x parity): zero before the launch, zero again behind it
+    int split_counter_words;
+    long split_tile_floats;   // floats of one part's image of one tile in scratch ([tile][part][piece][thread] x 4)
     void* scratch; long scratch_bytes;
     const float* post_scale; const float* post_shift;   // h3v2: out = silu(out*post_scale[c] + post_shift[c]) after everything else
     int out_h2;               // h3v2: store the output in DM3D_FMT_H2 (full bricks, cout % 64 == 0 only)
@@ -45,11 +48,11 @@ enum { DM3D_CONV_K3S1 = 0, DM3D_CONV_K3S2 = 1, DM3D_CONV_K1 = 2, DM3D_CONV_UP = 
 int dm3d_conv_launch_f32(ConvArgs& a, int which, hipStream_t st);
 int dm3d_conv_launch_h3(ConvArgs& a, int which, hipStream_t st);
 int dm3d_conv_launch_h3v3(ConvArgs& a, int which, hipStream_t st);     // DM3D_WL_PAIR weights; which in {K3S1, UP}: the free-running form (dm3d_conv_h3v3.hip)
-struct H3v2Launch { ConvArgs k; bool reduce; size_t out_elems; bool stats_after; };       // what pre_launch decided: the kernel's own arguments, a reduce launch behind it
+struct H3v2Launch { ConvArgs k; bool stats_after; };       // what pre_launch decided: the kernel's own arguments; the stand-alone statistics pass behind it
 int dm3d_h3v2_pre_launch(ConvArgs& a, int td, H3v2Launch& L, hipStream_t st, int force_ksplit = 0);    // force_ksplit > 0: the caller's Cin split
 int dm3d_h3v2_post_launch(const ConvArgs& a, const H3v2Launch& L, hipStream_t st);
-int dm3d_h3v2_post_reduce(const ConvArgs& a, const H3v2Launch& L, hipStream_t st);
-int dm3d_conv_h3v2_ksplit(const ConvArgs& a, bool with_scratch);
+int dm3d_conv_h3v2_ksplit(const ConvArgs& a);            // parts along Cin the direct kernel's 4-slice form would use (1: no split_counters, or the grid is large)
+long dm3d_conv_split_tiles(const ConvArgs& a, int td);   // tiles of a launch in td-slice bricks: bricks x column tiles x parities
 int dm3d_conv_h3v3_td(const ConvArgs& a);              // z-slices per brick (4 or 8) the free-running kernel takes for this launch
 int64_t dm3d_h3v2_skip_image_bytes(int cin, int cout);
 int dm3d_pack_skip_h3v2(const float* keras_kernel, int cin, int cout, int w_exp, void* packed, hipStream_t st);

@@ -1,6 +1,7 @@
 // dm3d_conv_h3_host.hip — what the 16x16x32 split-float16 Conv3d kernels (dm3d_conv_h3v3.hip: the free-running three-pass kernel;
-// dm3d_conv_h3w.hip: its Winograd-x form) share on the host side: brick counts and the Cin split of small grids (zero fill + two-way atomic
-// add, or raw partial sums into caller scratch + a reduce launch that applies the epilogue), the weight packers of the DM3D_WL_PAIR
+// dm3d_conv_h3w.hip: its Winograd-x form) share on the host side: brick counts and the Cin split of small grids (the hand-over form: raw
+// partial tiles into caller scratch, the last part of a tile to arrive sums them and runs the epilogue — one launch, no zero fill, no
+// atomics on the output, no reduce launch), the weight packers of the DM3D_WL_PAIR
 // geometry (plain / UpSample parity sums / Conv3DTranspose / the Winograd-x transform) and of the fused skip conv's image.
 // reference ops: Conv3D / UpSampling3D + Conv3D / Conv3DTranspose weights in Keras layouts (networks/conditional_dm3d.py:238-296,
 // networks/vqvae3d_monai.py:373-377).
@@ -9,138 +10,58 @@
 
 using namespace h3v2;
 
-namespace {
-
-// out = epilogue(sum of the ksplit partial-sum images, added in image order): + bias[c] + vec[row(b)][c] -> ReLU -> PReLU -> + res ->
-// ReLU.  One thread per 4 consecutive channels (or per element when cout % 4 != 0).
-__global__ __launch_bounds__(256) void conv_split_reduce_kernel(const float* __restrict__ part, int nsplit, long stride, float* __restrict__ out,
-                                                                int cout, long per_sample, const float* __restrict__ bias,
-                                                                const float* __restrict__ vec, const int* __restrict__ vec_idx, int vec_ld,
-                                                                int relu, const float* __restrict__ prelu, const float* __restrict__ res,
-                                                                int relu_out, int vec4, int* range_flag, float range_limit) {
-    const int w = vec4 ? 4 : 1;
-    const long total = stride / w;
-    float amax = 0.0f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long e0 = i * w;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < nsplit; ++s) {
-            if (vec4) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(part + (size_t)s * stride + e0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += q[j];
-            } else {
-                v[0] += part[(size_t)s * stride + e0];
-            }
-        }
-        const unsigned e32 = (unsigned)e0;                  // the launcher guarantees stride < 2^31
-        const int c0 = (int)(e32 % (unsigned)cout);
-        const unsigned b = e32 / (unsigned)per_sample;
-        const int vrow = vec ? (vec_idx ? vec_idx[b] : (int)b) : 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (j >= w) break;
-            float x = v[j];
-            if (bias) x += bias[c0 + j];
-            if (vec) x += vec[(size_t)vrow * vec_ld + c0 + j];
-            if (relu) x = fmaxf(x, 0.0f);
-            if (prelu) { const float al = prelu[e32 % (unsigned)per_sample + j]; x = x > 0.0f ? x : al * x; }
-            if (res) x += res[e0 + j];
-            if (relu_out) x = fmaxf(x, 0.0f);
-            DM3D_AMAX(amax, x);
-            out[e0 + j] = x;
-        }
-    }
-    if (range_flag && amax > range_limit) *range_flag = 1;
+// Everything around the conv launch itself that the two kernels share: brick counts, the Cin split of small grids, 16-byte epilogue
+// eligibility, where the GroupNormalization statistics come from.
+long dm3d_conv_split_tiles(const ConvArgs& a, int td) {
+    return (long)a.batch * ((a.od + td - 1) / td) * ((a.oh + 7) / 8) * ((a.ow + 7) / 8) * (a.coutpad / 64) * (a.parity ? 8 : 1);
 }
 
-// Zero fill as a kernel of our own: a hipMemsetAsync captured into the per-step HIP graph becomes a memset node, and replays of
-// that graph were observed to race it against the atomic adds of the following conv (two full T = 1000 chains diverged after
-// ~90 steps; eager launches and graphs without memset nodes did not).  A kernel node is ordered like every other launch.
-__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, long n4, long n) {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) reinterpret_cast<f32x4*>(p)[i] = z;
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[n4 * 4 + threadIdx.x] = 0.f;
-}
-
-}  // namespace
-
-// Everything around the conv launch itself that the v2 and v3 kernels share: brick counts, Cin splitting for small grids (zero fill +
-// two-way atomic add, or raw partial sums into caller scratch + a reduce launch that applies the epilogue), 16-byte epilogue eligibility.
 int dm3d_h3v2_pre_launch(ConvArgs& a, int td, H3v2Launch& L, hipStream_t st, int force_ksplit) {
+    (void)st;
     a.bd = (a.od + td - 1) / td;
     a.bh = (a.oh + 7) / 8;
     a.bw = (a.ow + 7) / 8;
     // Small grids (the 8^3 level at B = 32 has 64 bricks x 4 channel tiles = one workgroup per CU, i.e. one wave per SIMD with
-    // nothing to hide its barriers and LDS latency behind: in-kernel stamps showed 58 % MFMA occupancy inside the tap loop there;
-    // at B = 1 that level has 8 workgroups for 256 CUs) split the Cin chunks over several workgroups per brick.
-    const bool with_scratch = a.scratch != nullptr;
-    a.ksplit = force_ksplit > 0 ? force_ksplit
-             : (td != 4 || a.out_h2 || a.post_scale) ? 1 : dm3d_conv_h3v2_ksplit(a, with_scratch);     // the fused output forms live in the plain epilogue
-    const size_t out_elems = (size_t)a.batch * a.fd * a.fh * a.fw * a.cout;
-    a.split_atomic = 0;
-    a.split_stride = 0;
+    // nothing to hide its barriers and LDS latency behind; at B = 1 that level has 8 workgroups for 256 CUs) split the Cin chunks over
+    // several workgroups per tile.  Round 5: the parts meet INSIDE the launch (split_* in dm3d_conv_h3v2_parts.h) — every epilogue form,
+    // the fused output formats and the fused statistics included, since one workgroup sees the finished sums.
+    a.ksplit = force_ksplit > 0 ? force_ksplit : (td != 4 ? 1 : dm3d_conv_h3v2_ksplit(a));
     {
         auto al16 = [](const void* q) { return (reinterpret_cast<size_t>(q) & 15) == 0; };
         a.epi_vec4 = a.cout % 4 == 0 && al16(a.out) && al16(a.bias) && al16(a.res) && al16(a.prelu) && al16(a.post_scale) && al16(a.post_shift)
                      && al16(a.vec) && (a.vec == nullptr || a.vec_ld % 4 == 0);
     }
+    a.split_tile_floats = 0;
+    if (a.ksplit > 1) {
+        const long tiles = dm3d_conv_split_tiles(a, td);
+        a.split_tile_floats = (long)td * 8 * 8 * 64;                      // a whole brick x 64 columns, whatever part of it is inside the volume
+        DM3D_REQUIRE(a.split_counters && a.split_counter_words >= tiles, "conv: a Cin-split launch of %ld tiles needs split_counters of as many zeroed words (have %d)",
+                     tiles, a.split_counter_words);
+        DM3D_REQUIRE(a.scratch && (size_t)a.scratch_bytes >= (size_t)tiles * a.ksplit * a.split_tile_floats * sizeof(float),
+                     "conv: scratch of %ld bytes is too small for %d parts x %ld tiles (dm3d_conv_scratch_bytes)", a.scratch_bytes, a.ksplit, tiles);
+        DM3D_REQUIRE((size_t)a.ksplit * a.split_tile_floats * sizeof(float) < (1ull << 31), "conv: %d parts overflow a tile's buffer descriptor", a.ksplit);
+    }
     ConvArgs& k = L.k;
     k = a;
-    const bool linear = !a.relu && !a.prelu && !a.relu_out && a.res != a.out && a.x1 != a.out && a.x2 != a.out;
-    static const bool no_atomic = [] { const char* e = getenv("DM3D_CONV_NO_ATOMIC"); return e && e[0] == '1'; }();
-    const bool atomic2 = a.ksplit == 2 && linear && a.nchunks >= 8 && !(no_atomic && with_scratch);       // cheaper than a reduce launch when two parts suffice
-    L.out_elems = out_elems;
-    L.reduce = false;
-    // Fused GroupNormalization statistics: the kernel's 16-byte full-brick epilogue accumulates them (whole bricks, cout % 64 == 0, no Cin
-    // split, plain float32 output without PReLU); every other form leaves them to the stand-alone kernel behind the launch (post_launch).
+    // Fused GroupNormalization statistics: the kernel's 16-byte full-brick epilogue accumulates them (whole bricks, cout % 64 == 0, plain
+    // float32 output without PReLU; a split launch's last part runs that epilogue like any other); every other form leaves them to the
+    // stand-alone kernel behind the launch (post_launch).
     L.stats_after = false;
     if (a.gn_stats) {
 #ifdef DM3D_EPILOGUE_SCALAR
         const bool fused = false;            // (that A/B build compiles the 16-byte epilogue — the only form that accumulates — out)
 #else
-        const bool fused = a.od % td == 0 && a.oh % 8 == 0 && a.ow % 8 == 0 && a.cout % 64 == 0 && a.ksplit == 1 && a.epi_vec4 && !a.prelu
+        const bool fused = a.od % td == 0 && a.oh % 8 == 0 && a.ow % 8 == 0 && a.cout % 64 == 0 && a.epi_vec4 && !a.prelu
                            && !a.out_h2 && !a.post_scale;
 #endif
         if (!fused) { k.gn_stats = nullptr; L.stats_after = true; }
-    }
-    if (a.ksplit > 1 && (!with_scratch || atomic2)) {         // two halves, order-independent atomic add into the zeroed output
-        k.split_atomic = 1;
-        long zg = ((long)(out_elems / 4) + 255) / 256;
-        if (zg > 4096) zg = 4096;
-        if (zg < 1) zg = 1;
-        hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)zg), dim3(256), 0, st, a.out, (long)(out_elems / 4), (long)out_elems);
-        if (int zrc = dm3d_launch_check("zero_f32_kernel")) return zrc;
-    } else if (a.ksplit > 1) {                                // raw partial sums -> scratch; epilogue in the reduce launch
-        DM3D_REQUIRE((size_t)a.scratch_bytes >= out_elems * sizeof(float) * a.ksplit, "conv: scratch of %ld bytes is too small", a.scratch_bytes);
-        DM3D_REQUIRE(out_elems < (1ull << 31), "conv: split-K output of %zu elements overflows the reduce kernel's 32-bit index", out_elems);
-        k.out = static_cast<float*>(a.scratch);
-        k.split_stride = (long)out_elems;
-        k.bias = nullptr; k.vec = nullptr; k.res = nullptr; k.relu = 0; k.prelu = nullptr; k.relu_out = 0;
-        k.range_flag = nullptr;                               // the reduce launch checks the finished values
-        L.reduce = true;
     }
     return DM3D_OK;
 }
 
 int dm3d_h3v2_post_launch(const ConvArgs& a, const H3v2Launch& L, hipStream_t st) {
-    if (int rc = dm3d_h3v2_post_reduce(a, L, st)) return rc;
     if (L.stats_after) return dm3d_groupnorm_partials(a.out, a.batch, (int64_t)a.fd * a.fh * a.fw, a.cout, a.gn_stats, st);
     return DM3D_OK;
-}
-
-int dm3d_h3v2_post_reduce(const ConvArgs& a, const H3v2Launch& L, hipStream_t st) {
-    if (!L.reduce) return DM3D_OK;
-    const size_t out_elems = L.out_elems;
-    const long n4 = (long)(out_elems / 4);                    // cout % 4 == 0 is not required of cout: fall back to scalar lanes
-    const bool vec4 = a.cout % 4 == 0;
-    const long work = vec4 ? n4 : (long)out_elems;
-    long g = (work + 255) / 256;
-    if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(conv_split_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, static_cast<const float*>(a.scratch), a.ksplit,
-                       (long)out_elems, a.out, a.cout, (long)a.fd * a.fh * a.fw * a.cout, a.bias, a.vec, a.vec_idx, a.vec_ld, a.relu, a.prelu,
-                       a.res, a.relu_out, vec4 ? 1 : 0, a.range_flag, a.range_limit);
-    return dm3d_launch_check("conv_split_reduce_kernel");
 }
 
 namespace {
@@ -261,19 +182,14 @@ int dm3d_pack_skip_h3v2(const float* keras_kernel, int cin, int cout, int w_exp,
     return dm3d_launch_check("pack_skip_h3v2_kernel");
 }
 
-// Workgroups per brick along Cin.  Goal: at least ~2 workgroups per CU (512) while every part keeps >= 2 chunks.  Without scratch
-// only the two-way atomic form exists, and only behind a linear epilogue.
-int dm3d_conv_h3v2_ksplit(const ConvArgs& a, bool with_scratch) {
+// Workgroups per tile along Cin (the direct kernel's 4-slice form).  Goal: at least ~2 workgroups per CU (512) while every part keeps >= 2
+// chunks.  Only with split_counters (the host's statement that it provides the hand-over workspace: dm3d_conv_scratch_bytes).
+int dm3d_conv_h3v2_ksplit(const ConvArgs& a) {
     static const int mode = [] { const char* e = getenv("DM3D_CONV_KSPLIT"); return e ? atoi(e) : -1; }();   // 0: never split (A/B, debugging)
-    if (mode == 0) return 1;
-    const long bd = (a.od + 3) / 4, bh = (a.oh + 7) / 8, bw = (a.ow + 7) / 8;
-    const long wgs = (long)a.batch * bd * bh * bw * (a.coutpad / 64) * (a.parity ? 8 : 1);
+    if (mode == 0 || !a.split_counters) return 1;
+    const long wgs = dm3d_conv_split_tiles(a, 4);
     static const long wg_limit = [] { const char* e = getenv("DM3D_CONV_SPLIT_WGS"); return e ? atol(e) : 256L; }();   // A/B knob
     if (wgs > wg_limit || a.nchunks < 4) return 1;
-    if (!with_scratch) {
-        const bool linear = !a.relu && !a.prelu && !a.relu_out && a.res != a.out && a.x1 != a.out && a.x2 != a.out;
-        return (linear && a.nchunks >= 8 && a.nchunks % 2 == 0) ? 2 : 1;
-    }
     // A/B knobs (read once: dm3d_conv_scratch_bytes and the launch must agree): least chunks per part, workgroups to aim for, most parts
     static const int min_chunks = [] { const char* e = getenv("DM3D_CONV_SPLIT_MINCHUNKS"); return e ? atoi(e) : 2; }();
     static const long target = [] { const char* e = getenv("DM3D_CONV_SPLIT_TARGET"); return e ? atol(e) : 512L; }();

@@ -185,6 +185,87 @@ __device__ __forceinline__ void skip_phase(const ConvArgs& p, _Float16* smem, f3
 
 }
 
+// ---- Cin split, hand-over form (round 5; replaces zero fill + atomic adds and scratch + reduce launch).  A launch whose grid would leave
+// most of the chip idle runs P workgroups per tile (brick x 64 columns), each contracting 1/P of the chunks.  Every part stores its RAW
+// accumulator tiles (MFMA layout, 16 bytes per lane and piece: 1 KB per wave and instruction) into the caller's scratch, write-through
+// (sc1: the bytes leave the XCD's L2, no release fence needed), waits for them (vmcnt(0), every storing wave), meets at a workgroup
+// barrier, and ONE lane draws a ticket from the tile's counter (relaxed agent-scope add).  The part that draws P - 1 knows all others
+// have stored: it sums the parts IN PART ORDER (its own tiles, still in registers, at their place; the others by sc1 loads, which bypass
+// this CU's L1) — the result does not depend on which part came last —, zeroes the counter for the next launch and runs the ordinary
+// epilogue.  Nobody waits for anybody: a part that is not last is done.  (MI355X_MICROARCH.md, inter-workgroup visibility, the unsharded
+// counter row; cdna_hip_programming.md, in-launch split-K reduction.)  scratch layout: [tile][part][piece][256 threads] x 16 bytes.
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+struct SplitTile { __amdgpu_buffer_rsrc_t rs; unsigned lane_off, part_off; };
+__device__ __forceinline__ SplitTile split_tile(const ConvArgs& p, const long tile, const int part) {
+    SplitTile t;
+    char* base = static_cast<char*>(p.scratch) + (size_t)tile * p.ksplit * p.split_tile_floats * 4;      // (uniform)
+    t.rs = __builtin_amdgcn_make_buffer_rsrc(base, (short)0, (int)(p.ksplit * p.split_tile_floats * 4), 0x00020000);
+    // (from an opaque copy of the thread number: a lane constant hipcc can compute in front of the caller's main loop is one more register
+    // alive across it — in the Winograd kernel, whose step loop has none to spare, a spill reloaded behind a vmcnt(0) at every chunk)
+    int tx = threadIdx.x;
+    asm volatile("" : "+v"(tx));
+    t.lane_off = (unsigned)tx * 16u;
+    t.part_off = (unsigned)(part * p.split_tile_floats * 4);
+    return t;
+}
+// pieces piece0 .. piece0 + A * B - 1 of this part's image
+template <int A, int B>
+__device__ __forceinline__ void split_store(const SplitTile& t, const f32x4v (&v)[A][B], const int piece0) {
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v[a][b]), t.rs, t.lane_off + (unsigned)(piece0 + a * B + b) * 4096u, (int)t.part_off, 16);   // aux 16 = sc1
+}
+// true in the part that drew the tile's last ticket (uniform over the workgroup); word: 4 bytes of LDS nobody else uses right now
+__device__ __forceinline__ bool split_is_last(const ConvArgs& p, const long tile, unsigned* word) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave: its stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned tk = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(p.split_counters) + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tk == (unsigned)p.ksplit - 1u)                       // nobody touches the word again in this launch: the next one finds zero
+            __hip_atomic_store(reinterpret_cast<unsigned*>(p.split_counters) + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *word = tk;
+    }
+    __syncthreads();
+    const bool last = *word == (unsigned)p.ksplit - 1u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // (no instruction: keeps the compiler from moving the loads above the ticket)
+    return last;
+}
+// v = sum over the parts, in part order, of pieces piece0 ..; on entry v holds this part's own tiles
+template <int A, int B>
+__device__ __forceinline__ void split_gather(const SplitTile& t, const ConvArgs& p, const int part, f32x4v (&v)[A][B], const int piece0) {
+    f32x4v own[A][B];
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+        for (int b = 0; b < B; ++b) own[a][b] = v[a][b];
+    for (int q = 0; q < p.ksplit; ++q) {                         // (uniform)
+        if (q == part) {
+            if (q > 0) {
+#pragma unroll
+                for (int a = 0; a < A; ++a)
+#pragma unroll
+                    for (int b = 0; b < B; ++b) v[a][b] += own[a][b];
+            }
+            continue;
+        }
+        const int qoff = (int)(q * p.split_tile_floats * 4);
+        u32x4v x[A][B];
+#pragma unroll
+        for (int a = 0; a < A; ++a)
+#pragma unroll
+            for (int b = 0; b < B; ++b) x[a][b] = __builtin_amdgcn_raw_buffer_load_b128(t.rs, t.lane_off + (unsigned)(piece0 + a * B + b) * 4096u, qoff, 16);
+#pragma unroll
+        for (int a = 0; a < A; ++a)
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const f32x4v y = __builtin_bit_cast(f32x4v, x[a][b]);
+                v[a][b] = q == 0 ? y : v[a][b] + y;
+            }
+    }
+}
+
 // NCT = 16-column tiles per wave the caller computed (4: a whole 64-column tile; 1 / 2: the narrow forms for Cout <= 16 / 32)
 // zs: the z-slice of the brick these tiles belong to (-1: the wave index — one slice per wave); tile pi sits at brick column
 // xa * (pi & 1) + xb (xb < 0: the direct kernels' patch geometry, 4 * (pi & 1) + dx_of_row; the Winograd form passes 1, 2 * x-pair)
@@ -197,7 +278,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
     constexpr int TH = 8, TW = 8, NT = 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = lane & 15, g4 = lane >> 4;
-    const int b = br.b, oz0 = br.oz0, oy0 = br.oy0, ox0 = br.ox0, ooz = br.ooz, ooy = br.ooy, oox = br.oox, ntile = br.ntile, khalf = br.khalf;
+    const int b = br.b, oz0 = br.oz0, oy0 = br.oy0, ox0 = br.ox0, ooz = br.ooz, ooy = br.ooy, oox = br.oox, ntile = br.ntile;
     // ---- epilogue.  Accumulator register r of tile (patch pi, column tile ni): voxel (dy = 4*(pi>>1) + r, dx = 4*(pi&1) +
     // dx_of_row(4*g4)), output channel ni*16 + row.
     const int vrow = p.vec ? (p.vec_idx ? p.vec_idx[b] : b) : 0;
@@ -206,18 +287,16 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
     const int oz = oz0 + (zs < 0 ? wave : zs);
     const bool z_ok = oz < p.od;
     const size_t zbase = (((size_t)b * p.fd + (z_ok ? oz * p.os + ooz : 0)) * p.fh) * p.fw * p.cout;
-    float* outz = p.out + zbase + (size_t)khalf * p.split_stride;
-    // atomic mode: half 0 carries the epilogue operands; scratch mode: every part stores its raw partial sums into its own
-    // image (the launcher cleared the epilogue operands; dm3d_conv_split_reduce applies them)
-    const bool split = p.split_atomic != 0, lead = khalf == 0 || !split;
-    const float* resz = (p.res && lead) ? p.res + zbase : nullptr;
+    float* outz = p.out + zbase;
+    // (a Cin-split launch runs this once per tile, in the part that drew the last ticket, on the summed tiles: split_* above)
+    const float* resz = p.res ? p.res + zbase : nullptr;
     const float* prz = p.prelu ? p.prelu + (zbase - (size_t)b * p.fd * p.fh * p.fw * p.cout) : nullptr;
     const int dxl = xb < 0 ? dx_of_row(4 * g4) : xb;
     const int ystep = p.os * p.fw * p.cout;                              // one brick row further in the output
     float amax = 0.0f;                                                   // range guard: largest |value| this lane stores
-    const float rlim = split ? 0.5f * p.range_limit : p.range_limit;     // two atomic halves: either may carry half the sum
+    const float rlim = p.range_limit;
 #ifndef DM3D_EPILOGUE_SCALAR
-    if (full && !split && p.epi_vec4 && !prz) {
+    if (full && p.epi_vec4 && !prz) {
         // Full brick, plain stores, aligned operands, no PReLU (the common case; the autoencoder's PReLU convs take the scalar form below: a
         // per-tile slope load under a uniform `if` left an unconditional vmcnt(0) behind it, and with it every tile waited for the previous
         // tile's STORE to complete — 600-800 cycles per tile for every conv of the U-Net, in-kernel stamps of round 3).  The MFMA leaves a lane with ONE channel of FOUR voxels (r = 0..3: brick rows); stored
@@ -319,7 +398,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
     int rowq = row, dxq = dxl;
     asm volatile("" : "+v"(rowq), "+v"(dxq));
     if (full) {
-        // full brick, scalar form (split-K launches add their halves atomically; -DDM3D_EPILOGUE_SCALAR: the A/B arm of the form above):
+        // full brick, scalar form (unaligned operands, PReLU; -DDM3D_EPILOGUE_SCALAR: the A/B arm of the form above):
         // all 64 residual values of this lane are requested before the first one is used
         float rv[NCT][4][4];
         if (resz) {
@@ -337,7 +416,6 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
             const int n = n0 + ni * 16 + rowq;
             float add = p.bias ? p.bias[n] : 0.0f;
             if (p.vec) add += p.vec[(size_t)vrow * p.vec_ld + n];
-            if (!lead) add = 0.0f;
             const float ps = p.post_scale ? p.post_scale[n] : 1.0f, pt = p.post_scale ? p.post_shift[n] : 0.0f;
             // DM3D_FMT_H2 position of channel n inside its voxel's row (see dm3d_gemm_h3.hip): lanes n and n^1 exchange halves
             const int h2col = (n >> 4) * 64 + ((n >> 3) & 1) * 16 + ((n & 7) >> 1) * 4 + (n & 1) * 32 - n * 4;
@@ -359,8 +437,6 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
                         const unsigned int oth = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, false);   // lane ^ 1
                         const unsigned int word = (n & 1) ? ((oth >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (oth << 16));
                         *reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(outz) + (size_t)o * 4 + h2col) = word;
-                    } else if (split) {
-                        unsafeAtomicAdd(outz + o, v);
                     } else {
                         outz[o] = v;
                     }
@@ -377,7 +453,6 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
         const int nc = n_ok ? n : p.cout - 1;
         float add = p.bias ? p.bias[nc] : 0.0f;
         if (p.vec) add += p.vec[(size_t)vrow * p.vec_ld + nc];
-        if (!lead) add = 0.0f;
 #pragma unroll
         for (int pi = 0; pi < 4; ++pi) {
             const int oyb = oy0 + 4 * (pi >> 1), ox = ox0 + xa * (pi & 1) + dxq;
@@ -391,7 +466,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, f32x4v (&acc)[4][NCT
                 if (prz) { const float al = prz[o]; v = v > 0.0f ? v : al * v; }
                 if (resz) v += resz[o];
                 if (p.relu_out) v = fmaxf(v, 0.0f);
-                if (ok) { DM3D_AMAX(amax, v); if (split) unsafeAtomicAdd(outz + o, v); else outz[o] = v; }
+                if (ok) { DM3D_AMAX(amax, v); outz[o] = v; }
             }
         }
     }

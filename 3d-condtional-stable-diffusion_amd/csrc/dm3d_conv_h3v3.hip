@@ -97,14 +97,15 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v3(const ConvArgs p
         brick = (int)(w / (unsigned)ny);
         by = (int)(w - (unsigned)brick * (unsigned)ny);
     }
+    const int brick_all = brick;                                    // over the whole batch: the tile number of a Cin-split launch counts with it
     const int bpv = p.bd * p.bh * p.bw;
     const int b = brick / bpv;
     brick -= b * bpv;
     const int oz0 = (brick / (p.bh * p.bw)) * TD;
     const int oy0 = ((brick / p.bw) % p.bh) * TH;
     const int ox0 = (brick % p.bw) * TW;
-    // by = ntile + ntiles * khalf.  ksplit == 2 (small grids, linear epilogue): this workgroup contracts chunks [c_lo, c_hi) only and
-    // adds its partial sums into the zeroed output; the khalf == 0 half also carries bias / vec / residual.
+    // by = ntile + ntiles * khalf.  ksplit > 1 (small grids): this workgroup contracts chunks [c_lo, c_hi) only; the parts of a tile meet in
+    // the hand-over form below (split_* of dm3d_conv_h3v2_parts.h).
     const int ntiles = p.coutpad / NT;
     const int ntile = by % ntiles, khalf = by / ntiles;
     const int c_lo = khalf * (p.nchunks / p.ksplit), c_hi = c_lo + p.nchunks / p.ksplit;
@@ -417,6 +418,13 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v3(const ConvArgs p
     if constexpr (KS == 3 && NCT == 4) {            // (the launcher admits a skip conv behind k3 / stride 1 / Cout > 32 only)
         // (the launcher sizes the dynamic LDS for whichever of the two phases needs more: v3_lds_halfs)
         skip_phase<TD>(p, smem_v3, acc, br);
+    }
+    if (p.ksplit > 1) {                     // (uniform) Cin split: store this part's tiles; the last part of the tile to arrive sums them and goes on
+        const long tile = ((long)blockIdx.z * gridDim.x + brick_all) * ntiles + ntile;
+        const SplitTile stile = split_tile(p, tile, khalf);
+        split_store(stile, acc, 0);
+        if (!split_is_last(p, tile, reinterpret_cast<unsigned*>(smem_v3))) return;      // (the LDS is free: every wave is past the barrier above / the skip phase's last)
+        split_gather(stile, p, khalf, acc, 0);
     }
     if (p.gn_stats) {                       // fused GroupNormalization statistics of the output (uniform; the launcher admits the 16-byte full-brick form only)
         float gn[NCT * 8];

@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
     // the column tiles of one brick share all of its halo voxels).  XCD-aware as in dm3d_conv_h3v3.hip: dispatch ids d and d + 8 share an
     // XCD, XCD k takes the k-th contiguous eighth of the item list, and inside the XCD the G / 8 workgroups take its items round-robin, so
     // that the workgroups of one L2 work on neighbouring bricks at about the same time.  ksplit == 2 (grids that would leave half the CUs
-    // idle: the 8^3 level at B = 32): an item contracts chunks [c_lo, c_hi) only; the shared epilogue adds the two partial sums into the
-    // zeroed output (or stores them for the reduce launch).
+    // idle: the 8^3 level at B = 32): an item contracts chunks [c_lo, c_hi) only; the two parts of a tile meet behind the chunk loop (the
+    // hand-over form, below).
     const int ntiles = p.coutpad / NT;
     const unsigned ny = (unsigned)(ntiles * p.ksplit);
     const int bpv = p.bd * p.bh * p.bw;
@@ -764,14 +764,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
         }
         // ---- the shared epilogue, one slice at a time straight from the accumulators (the LDS holds the next item's image and weights):
         // tile (2g + parity, ni) of slice s = rows 4g .. 4g+3, x = 2 * x-pair + parity; without a skip conv the output transform happens here.
-        float gn[32];                       // fused GroupNormalization statistics of the output (ConvArgs.gn_stats): partial sums over both slices
-#pragma unroll
-        for (int i = 0; i < 32; ++i) gn[i] = 0.0f;
-        static_for<2>([&](auto S_) {
+        auto slice_tiles = [&](auto S_, f32x4v (&e)[4][4]) {
             constexpr int s = decltype(S_)::value;
-            __builtin_amdgcn_sched_barrier(0);
-            if (s == 1) STAMP(21);
-            f32x4v e[4][4];
             // (pinned in the accumulator file up to here: hipcc otherwise copies both slices' tiles out at the loop exit — 200 registers)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -794,9 +788,37 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
                         e[2 * g + 1][ni] = (m1 - m2) - m3;
                     }
             }
-            epilogue<TD, 4>(p, e, br, 2 * wave + s, 1, 2 * (lane >> 4), p.gn_stats ? gn : nullptr);
-        });
-        if (p.gn_stats) gn_flush<TD, 4>(p, gn, br, 2 * wave, 2);
+        };
+        // Cin split (the 8^3 level at B = 32): both parts store their transformed tiles, the part that draws the tile's last ticket sums them in
+        // part order and runs the epilogue (split_* in dm3d_conv_h3v2_parts.h); the other one goes on to its next item.
+        bool finish = true;                                     // (uniform)
+        const long tile = (long)(item / ny) * ntiles + cur.ntile;
+        SplitTile stile = {};
+        if (p.ksplit > 1) {
+            stile = split_tile(p, tile, cur.khalf);
+            static_for<2>([&](auto S_) {
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4v e[4][4];
+                slice_tiles(S_, e);
+                split_store(stile, e, 16 * decltype(S_)::value);
+            });
+            finish = split_is_last(p, tile, reinterpret_cast<unsigned*>(lds_in + HROWS * RREC * REC));      // (a word behind the image: nobody else's)
+        }
+        if (finish) {
+            float gn[32];                       // fused GroupNormalization statistics of the output (ConvArgs.gn_stats): partial sums over both slices
+#pragma unroll
+            for (int i = 0; i < 32; ++i) gn[i] = 0.0f;
+            static_for<2>([&](auto S_) {
+                constexpr int s = decltype(S_)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                if (s == 1) STAMP(21);
+                f32x4v e[4][4];
+                slice_tiles(S_, e);
+                if (p.ksplit > 1) split_gather(stile, p, cur.khalf, e, 16 * s);
+                epilogue<TD, 4>(p, e, br, 2 * wave + s, 1, 2 * (lane >> 4), p.gn_stats ? gn : nullptr);
+            });
+            if (p.gn_stats) gn_flush<TD, 4>(p, gn, br, 2 * wave, 2);
+        }
         STAMP(29);
         if (!has_next) break;
         // the accumulators of the next item: zeroed only now, with every old value dead (zeroing a slice's tiles as soon as they were read
@@ -821,7 +843,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
 
 template <int MODE>
 int launch_w(ConvArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)(4 * 2 * 64 * REC + 10 * 10 * 17 * REC) * sizeof(_Float16);      // 32 KB of weights + 106 KB of image
+    constexpr size_t lds = (size_t)(4 * 2 * 64 * REC + 10 * 10 * 17 * REC) * sizeof(_Float16) + 16;      // 32 KB of weights + 106 KB of image + the split form's ticket word
     static_assert(lds <= 160 * 1024, "one workgroup per CU");
     // (per device: the attribute and the CU count belong to the device the launch goes to)
     static std::atomic<int> cus[64] = {};
@@ -887,14 +909,12 @@ bool dm3d_conv_h3w_serves(const ConvArgs& a, int which) {
 }
 
 // Cin split of the Winograd form: two workgroups per brick and column tile where one would leave at least half of the CUs without work
-// (the 8^3 level at B = 32: 32 bricks x 4 column tiles), each contracting half of the chunks (at least eight), their partial sums meeting
-// in the shared epilogue (atomic add into the zeroed output when the epilogue is linear, else scratch + reduce launch: dm3d_h3v2_pre_launch).
-// The fused output forms (hand-off format, post-activation) live in the 16-byte epilogue and are not split; a fused skip conv's pairs are
-// spread over the two parts like the chunks.  DM3D_CONV_WINO_SPLIT=0: never.
+// (the 8^3 level at B = 32: 32 bricks x 4 column tiles), each contracting half of the chunks (at least eight) and half of a fused skip
+// conv's pairs; the halves meet inside the launch (the hand-over form, dm3d_conv_h3v2_parts.h: any epilogue, fused statistics and output
+// formats included).  Needs the host's split_counters (and scratch: dm3d_conv_scratch_bytes).  DM3D_CONV_WINO_SPLIT=0: never.
 int dm3d_conv_h3w_ksplit(const ConvArgs& a) {
     static const bool off = [] { const char* e = getenv("DM3D_CONV_WINO_SPLIT"); return e && e[0] == '0'; }();
-    if (off || a.out_h2 || a.post_scale || a.nchunks % 2 != 0 || a.nchunks < 16) return 1;
-    if (a.relu || a.prelu || a.relu_out || a.res == a.out || a.x1 == a.out || a.x2 == a.out) return 1;      // (a linear epilogue: the halves may meet by atomic add)
+    if (off || !a.split_counters || a.nchunks % 2 != 0 || a.nchunks < 16) return 1;
     const long wgs = (long)a.batch * (a.od / 8) * (a.oh / 8) * (a.ow / 8) * (a.coutpad / 64);
     return wgs <= 128 ? 2 : 1;
 }

@@ -141,11 +141,12 @@ def pack_weights_convt(kernel: torch.Tensor, h3: bool = False):
 
 def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False, pro_scale=None, pro_shift=None,
            vec=None, vec_idx=None, relu=False, res=None, precision=_lib.PREC_F32, w_exp=0, prelu_alpha=None,
-           relu_out=False, transpose=False, skip=None, x1_h2_channels=None, out_h2=False, post=None, wpk_wino=None, gn_stats=None) -> torch.Tensor:
+           relu_out=False, transpose=False, skip=None, x1_h2_channels=None, out_h2=False, post=None, wpk_wino=None, gn_stats=None, split=True) -> torch.Tensor:
     """Conv3D(padding="same") on NDHWC with the fused prologue / concat / upsample / epilogue of dm3d_conv3d_ndhwc.
     ``skip=(sx1, sx2_or_None, skip_wpk[, skip_wpk_frag])``: also accumulate Conv3D(cout, 1) of the raw concat(sx1, sx2) (H3, k3, stride 1).
     ``post=(scale, shift)``: out = silu(out*scale[c] + shift[c]) at the very end; ``out_h2``: store DM3D_FMT_H2;
-    ``x1_h2_channels=c``: x1 is a DM3D_FMT_H2 buffer of c logical channels (as written by ``out_h2``)."""
+    ``x1_h2_channels=c``: x1 is a DM3D_FMT_H2 buffer of c logical channels (as written by ``out_h2``).
+    ``split=False``: no split_counters, i.e. a small grid is not split along Cin (the A/B arm of the hand-over form)."""
     _f32c(x1, "x1")
     if x1.dim() != 5:
         raise ValueError("x1 must be [B,D,H,W,C]")
@@ -192,12 +193,26 @@ def conv3d(x1, wpk, cout, ksize, *, x2=None, bias=None, stride=1, upsample=False
             d.skip_wpk_frag = skip[3].data_ptr()
         _f32c(sx1, "skip x1")
         d.skip_x1, d.skip_x2, d.skip_c1, d.skip_c2, d.skip_wpk = sx1.data_ptr(), _p(sx2), sx1.shape[-1], (sx2.shape[-1] if sx2 is not None else 0), swpk.data_ptr()
-    need = lib().dm3d_conv_scratch_bytes(C.byref(d))
-    if need:
+    # the Cin split of small grids (include/dm3d.h, split_counters): tickets (zero before, zero after) and the parts' workspace
+    need, words = lib().dm3d_conv_scratch_bytes(C.byref(d)), lib().dm3d_conv_split_counter_words(C.byref(d))
+    if need and split:
         scratch = torch.empty(need // 4, dtype=torch.float32, device=x1.device)     # stays alive until the launches are enqueued:
         d.scratch, d.scratch_bytes = scratch.data_ptr(), need                       # same stream, so the allocator cannot reuse it early
+        counters = _split_counters(x1.device, words)
+        d.split_counters, d.split_counter_words = counters.data_ptr(), counters.numel()
     check(lib().dm3d_conv3d_ndhwc(C.byref(d), _st()), "conv3d")
     return out
+
+
+_COUNTERS = {}
+
+
+def _split_counters(device, words: int) -> torch.Tensor:
+    """One zeroed ticket buffer per device for the op-level calls (every launch leaves it zero; launches of a stream are ordered)."""
+    buf = _COUNTERS.get(device)
+    if buf is None or buf.numel() < words:
+        buf = _COUNTERS[device] = torch.zeros(max(4096, words), dtype=torch.int32, device=device)
+    return buf
 
 
 def split_h2(src: torch.Tensor, exp2: int = 0) -> torch.Tensor:

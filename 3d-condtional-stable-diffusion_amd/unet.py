@@ -508,6 +508,10 @@ class Plan:
         # H3 range guard (include/dm3d.h): every H3 launch of the plan reports into one flag; see UNet.check_range
         self.range_flag = torch.zeros(1, dtype=torch.int32, device=dev) if net.precision == "h3" else None
         self.uses_wino = False                  # some conv of this plan takes the Winograd-x form (dm3d_conv_tile_form() == 10)
+        # tickets of the Cin-split launches (include/dm3d.h, split_counters): zero now, and every launch leaves them zero, so one buffer
+        # serves every conv of the plan (launches are stream-ordered).  Every conv descriptor carries it from the start: the tile form and
+        # the split a descriptor answers for are then the ones the launch takes.
+        self.split_counters = torch.zeros(4096, dtype=torch.int32, device=dev)
         self.range_limit = net.range_limit
         self._build()
         if self.range_flag is not None and self.uses_wino:
@@ -525,6 +529,7 @@ class Plan:
             for d in self._keep:
                 if isinstance(d, ConvDesc):
                     d.scratch, d.scratch_bytes = self.scratch.data_ptr(), need
+        assert all(lib().dm3d_conv_split_counter_words(C.byref(d)) <= self.split_counters.numel() for d in self._keep if isinstance(d, ConvDesc))
 
     # -- buffer / op helpers ---------------------------------------------------------------------------------------
     def _buf(self, *shape) -> torch.Tensor:
@@ -598,6 +603,8 @@ class Plan:
             d.wpk_wino = w.wpk_wino.data_ptr()
         if self.range_flag is not None and w.precision == _lib.PREC_H3:
             d.range_flag, d.range_limit = self.range_flag.data_ptr(), self.range_limit
+        if w.precision == _lib.PREC_H3:
+            d.split_counters, d.split_counter_words = self.split_counters.data_ptr(), self.split_counters.numel()
         if self.net.cfg.norm == "group" and normed and not out_h2 and w.cout % 4 == 0:
             d.gn_stats = self._stats_alloc(out, w.cout, out.numel() // (self.B * w.cout))
         skip_flops = 0.0

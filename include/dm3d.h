@@ -21,10 +21,11 @@
 extern "C" {
 #endif
 
-#define DM3D_VERSION 110          /* major*100 + minor; the descriptor structs grew in 101 (w_layout), 102 (scratch), 103 (skip_*),
+#define DM3D_VERSION 111          /* major*100 + minor; the descriptor structs grew in 101 (w_layout), 102 (scratch), 103 (skip_*),
                                      104 (dm3d_attention), 105 (x1_fmt / out_fmt / post_*), 106 (ddpm seed_dev; conv/gemm range_flag; the
                                      training entries), 107 (conv wpk_f8: a float8 cross-term form, removed again in 109), 108 (conv wpk_wino: the Winograd-x form), 109 (wpk_f8 and
-                                     dm3d_pack_weights_h3f8 are gone; the Winograd-x image pairs its taps differently; dm3d_mlp_fused; conv skip_wpk_frag, gn_stats; dm3d_groupnorm_finalize2), 110 (dm3d_attn_front): a host built against an older header must be rebuilt */
+                                     dm3d_pack_weights_h3f8 are gone; the Winograd-x image pairs its taps differently; dm3d_mlp_fused; conv skip_wpk_frag, gn_stats; dm3d_groupnorm_finalize2), 110 (dm3d_attn_front), 111 (conv split_counters: the Cin split
+                                     meets inside the launch; dm3d_conv_split_counter_words): a host built against an older header must be rebuilt */
 
 #define DM3D_OK            0
 #define DM3D_EINVAL       -1      /* bad argument (shape, alignment, null pointer) */
@@ -175,25 +176,21 @@ typedef struct dm3d_conv_desc {
        are whole 4x8x8 bricks and cout % 64 == 0.  Zero / NULL when unused. */
     int32_t x1_fmt, out_fmt;
     const float* post_scale; const float* post_shift;
-    void* scratch;              /* optional workspace (16-byte aligned) of scratch_bytes bytes, or NULL.  With it, convs whose grid
-                                   would leave most of the chip idle (small batches, the 8^3 level) split their Cin range over up
-                                   to 16 workgroups per brick; the partial sums meet in a fixed order in a second launch that also
-                                   applies the epilogue, so results do not depend on timing.  dm3d_conv_scratch_bytes(d) says how
-                                   much a descriptor can use (0: none).  Without it such convs split at most two ways. */
+    void* scratch;              /* optional workspace (16-byte aligned) of scratch_bytes bytes, or NULL: see split_counters below.
+                                   dm3d_conv_scratch_bytes(d) says how much a descriptor can use (0: it never splits). */
     int64_t scratch_bytes;
     /* DM3D_PREC_H3 range guard.  An H3 consumer clamps float32 operands to the float16 range (+-65504) before the hi/lo split — a
        silent difference from the reference's float32 arithmetic if a value ever got there.  With range_flag set, this launch
        writes 1 to *range_flag when any |output value| exceeds range_limit (0 = 65504; hosts pass the smaller bound that also
-       covers a consumer's folded norm: (65504 - max|shift|) / max|scale|; a two-way atomic split compares its partial sums with
-       range_limit / 2).  The host reads the flag once per generate() / forward and raises instead of returning clamped results
+       covers a consumer's folded norm: (65504 - max|shift|) / max|scale|).  The host reads the flag once per generate() / forward and raises instead of returning clamped results
        (rerun with DM3D_PREC_F32).  NULL: no check. */
     int32_t* range_flag; float range_limit;
     /* Optional weight image of the Winograd F(2,3)-along-x form of a DM3D_PREC_H3 k3 / stride-1 conv with cout > 32 (dm3d_pack_weights_h3w,
        packed with THIS conv's w_exp): two neighbouring outputs of a row from four transformed inputs — 36 instead of 54 MFMA k-steps per
        output pair, same split-float16 products and float32 accumulation (results differ from the direct form in the last bits only).
        The kernel uses it when the volume is whole 8x8x8 bricks, Cin >= 32, a fused skip conv is short and there are enough bricks (a launch of
-       at most 128 of its work items with Cin >= 256 and a linear epilogue splits Cin two ways, the halves meeting by atomic add); without a
-       fused skip conv one persistent workgroup per CU walks the list of (brick, column tile, Cin part) items
+       at most 128 of its work items with Cin >= 256 splits Cin two ways: split_counters below); one
+       persistent workgroup per CU walks the list of (brick, column tile, Cin part) items
        (dm3d_conv_tile_form() == 10); otherwise wpk serves the launch as before.  The transformed inputs are up to 2 max|x|: producers of
        such a conv must keep |x| <= 32752 (pass range_limit <= 32752 to them).  NULL: never. */
     const void* wpk_wino;
@@ -208,10 +205,20 @@ typedef struct dm3d_conv_desc {
        atomics; every slot is written); behind any other kernel or form the library runs dm3d_groupnorm_partials on the finished output
        itself.  Float32 output only (cout % 4 == 0, 16-byte aligned buffer).  NULL: none. */
     float* gn_stats;
+    /* Cin split of small grids (DM3D_PREC_H3, DM3D_WL_PAIR).  A conv whose grid would leave most of the chip idle (small batches; the 8^3
+       level at B = 32) runs up to 16 workgroups per tile (brick x 64 output channels), each contracting a share of the input channels.  The
+       parts meet INSIDE the launch: each stores its raw accumulator tiles into `scratch`, draws a ticket from the tile's word of
+       split_counters, and the part that draws the last one sums all parts in part order (results do not depend on timing) and applies the
+       epilogue — every epilogue form, no zero fill, no atomic adds on the output, no second launch.  split_counters: at least
+       dm3d_conv_split_counter_words(d) int32 words, ZERO before the first launch that uses them; every launch leaves them zero, so one
+       buffer serves every conv of a stream.  Without split_counters (NULL / 0) no conv splits; with them a conv that wants to split
+       requires scratch of dm3d_conv_scratch_bytes(d) bytes (DM3D_EINVAL otherwise). */
+    int32_t* split_counters; int32_t split_counter_words;
 } dm3d_conv_desc;
 
 int     dm3d_conv3d_ndhwc(const dm3d_conv_desc* d, void* stream);
 int64_t dm3d_conv_scratch_bytes(const dm3d_conv_desc* d);
+int32_t dm3d_conv_split_counter_words(const dm3d_conv_desc* d);     /* words of split_counters a descriptor of this shape can use (0: it never splits) */
 /* Which tile form of the 16x16x32 conv kernels serves this descriptor: 8 (8 z-slices per brick, 512 threads, one workgroup per CU — launches
  * with enough bricks to give every CU two such workgroups in turn), 4 (4 slices, 256 threads, two workgroups per CU: small grids, the parity
  * form, launches with a fused skip conv, Cout <= 32), 10 (the Winograd-x form: wpk_wino given and eligible; conv3d_igemm_h3w<MODE>), 0 (another kernel).  Profiling

@@ -59,10 +59,10 @@ CONV_CASES = [
     ("k3_partial_brick_4", 2, (4, 4, 4), 32, 0, 64, 3, 1, False, "bias res"),
     ("k3_partial_brick_2", 2, (2, 2, 2), 16, 0, 64, 3, 1, False, "bias"),
     ("k3_16cube", 1, (16, 16, 16), 16, 0, 64, 3, 1, False, "bias"),
-    # small grids with >= 8 Cin chunks and a linear epilogue take the split-K path of the h3 kernel (two workgroups per brick, atomics)
+    # small grids with >= 4 Cin chunks take the Cin split of the h3 kernel (up to 16 workgroups per tile, meeting inside the launch)
     ("k3_splitk_all_linear", 2, (8, 8, 8), 128, 0, 128, 3, 1, False, "bias pro vec res"),
     ("k3_splitk_dual_partial", 1, (6, 6, 6), 96, 64, 72, 3, 1, False, "bias pro res"),
-    ("k3_deepk_relu_nosplit", 1, (8, 8, 8), 128, 0, 64, 3, 1, False, "bias relu res"),
+    ("k3_deepk_relu_split", 1, (8, 8, 8), 128, 0, 64, 3, 1, False, "bias relu res"),
     ("k3_upsample_splitk", 1, (4, 4, 4), 128, 0, 64, 3, 1, True, "bias res"),
     ("k3s2_8to4", 2, (8, 8, 8), 16, 0, 64, 3, 2, False, "bias"),
     ("k3s2_16to8", 1, (16, 16, 16), 32, 0, 32, 3, 2, False, "bias"),

@@ -90,7 +90,7 @@ def test_persistent_winograd_item_lists(dev, monkeypatch, case):
 
 def test_persistent_winograd_cin_split_lists(dev, monkeypatch):
     """The two-way Cin split under item lists: 64 items (8 bricks x 4 column tiles x 2 Cin parts) on 16 workgroups — the chunk range, the column
-    tile and the brick change between a workgroup's items, the halves meet by atomic add (8^3 level, Cin = 256)."""
+    tile and the brick change between a workgroup's items, the halves meet inside the launch (8^3 level, Cin = 256)."""
     from dm3d_amd import ops, _lib
     for v in ("DM3D_CONV_WINO_MINCHUNKS", "DM3D_CONV_WINO", "DM3D_CONV_WINO_SPLIT"):
         monkeypatch.delenv(v, raising=False)
@@ -184,7 +184,7 @@ def test_persistent_winograd_skip_tail_lists(dev, monkeypatch, case):
 
 def test_winograd_cin_split_with_a_skip_tail(dev, monkeypatch):
     """The 8^3-level conv2 + skip launches (256 -> 256 + k1(384)): two workgroups per brick and column tile, each contracting half of the chunks
-    AND half of the skip conv's pairs (an odd number of pairs here: 12 + 1 ragged), the halves meeting by atomic add."""
+    AND half of the skip conv's pairs (an odd number of pairs here: 12 + 1 ragged), the halves meeting inside the launch (hand-over form)."""
     from dm3d_amd import ops, _lib
     for v in ("DM3D_CONV_WINO_MINCHUNKS", "DM3D_CONV_WINO", "DM3D_CONV_WINO_SPLIT"):
         monkeypatch.delenv(v, raising=False)

@@ -136,7 +136,7 @@ def test_winograd_fused_skip_conv(dev, small_grids, case):
 
 def test_winograd_cin_split_on_a_small_grid(dev, monkeypatch):
     """B = 32 at 8^3 is 128 workgroups of the one-per-CU form: it runs as two workgroups per brick, each contracting half of the chunks, the
-    halves meeting by atomic add in the shared epilogue (linear epilogues only; Cin >= 256)."""
+    halves meeting inside the launch (the hand-over form of round 5: the part that draws the tile's last ticket sums both and runs the epilogue; Cin >= 256)."""
     from dm3d_amd import ops, _lib
     for v in ("DM3D_CONV_WIDE_WGS", "DM3D_CONV_WINO_MINCHUNKS", "DM3D_CONV_WINO", "DM3D_CONV_WINO_SPLIT"):
         monkeypatch.delenv(v, raising=False)
@@ -154,10 +154,16 @@ def test_winograd_cin_split_on_a_small_grid(dev, monkeypatch):
     yr = _ref_conv(x[:2], k, kw["bias"], ps, r[:2])
     assert not torch.equal(y_wino, y_direct), "the Winograd form did not run"
     assert _rel(y_wino[:2], yr) < 2e-5 and _rel(y_wino, y_direct) < 2e-5
-    # a ReLU epilogue is not linear: the launch stays on the direct kernel (bit-identical results with and without the second image)
+    # round 5: the halves meet inside the launch (hand-over form), so a non-linear epilogue splits like any other: ReLU before the residual
     y_a = ops.conv3d(x, wpk, cout, 3, relu=True, **kw)
     y_b = ops.conv3d(x, wpk, cout, 3, relu=True, wpk_wino=wino, **kw)
-    assert torch.equal(y_a, y_b)
+    yr2 = torch.relu(_ref_conv(x[:2], k, kw["bias"], ps)) + r[:2].double()
+    assert not torch.equal(y_a, y_b), "the Winograd form did not run behind a ReLU epilogue"
+    assert _rel(y_b[:2], yr2) < 2e-5 and _rel(y_a[:2], yr2) < 2e-5
+    # ... and without the ticket words nothing splits: the direct kernel serves the launch, with or without the second image
+    y_c = ops.conv3d(x, wpk, cout, 3, split=False, **kw)
+    y_d = ops.conv3d(x, wpk, cout, 3, wpk_wino=wino, split=False, **kw)
+    assert torch.equal(y_c, y_d) and _rel(y_c[:2], yr) < 2e-5
 
 
 def test_winograd_launch_policy(dev, monkeypatch):
@@ -169,8 +175,10 @@ def test_winograd_launch_policy(dev, monkeypatch):
         monkeypatch.delenv(v, raising=False)
     buf = torch.zeros(64, device=dev)
 
-    def form(batch=32, e=32, c1=128, cout=64, wino=True, skip=False, ed=None, skip_c=64):
+    def form(batch=32, e=32, c1=128, cout=64, wino=True, skip=False, ed=None, skip_c=64, counters=True):
         d = ConvDesc()
+        if counters:                             # (the host's statement that it provides the split workspace: include/dm3d.h)
+            d.split_counters, d.split_counter_words = buf.data_ptr(), 4096
         d.x1 = d.wpk = buf.data_ptr()
         d.out = buf.data_ptr() + 128
         d.c1, d.batch, d.in_d, d.in_h, d.in_w = c1, batch, ed or e, e, e
@@ -191,6 +199,7 @@ def test_winograd_launch_policy(dev, monkeypatch):
     assert form(batch=4) == 10 and form(batch=6) != 10       # exactly one workgroup per CU is a full round; 384 workgroups are a round and a half
     assert form(e=8, c1=256, cout=256) == 10     # 128 workgroups, Cin >= 256: two workgroups per brick (the Cin split)
     assert form(e=8, c1=128, cout=256) != 10     # too few chunks to split
+    assert form(e=8, c1=256, cout=256, counters=False) != 10      # no ticket words: no split, and 128 workgroups are too few
     assert form(ed=36) != 10                     # not whole 8-slice bricks
     assert form(cout=32) != 10
     assert form(skip=True) == 10                 # a fused skip conv: its tail is register-direct, the launch persistent like the others

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol(built_library):
         assert hasattr(handle, name), f"{name} declared in include/dm3d.h but not exported"
     from dm3d_amd import _lib
     assert set(_lib.SIGNATURES) == declared
-    assert _lib.lib().dm3d_version() == _lib.ABI_VERSION == 110
+    assert _lib.lib().dm3d_version() == _lib.ABI_VERSION == 111
     assert _lib.lib().dm3d_packed_weight_elems(27, 96, 64) == 27 * 64 * 96
     assert _lib.lib().dm3d_packed_weight_elems(1, 8, 8) == 64 * 16
 

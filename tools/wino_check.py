@@ -43,7 +43,7 @@ for name, B, e, c1, c2, cout, pro, res in [("plain 8^3 16->64", 1, 8, 16, 0, 64,
     ok = e1 < 2e-5 and not torch.equal(y0, y1)
     bad += not ok
     print(f"{name:34s} direct {e0:.2e}  wino {e1:.2e}  wino-direct {d:.2e}  {'ok' if ok else 'FAIL (or the Winograd form did not run)'}", flush=True)
-# Cin split: a grid of 128 workgroups (B = 32 at 8^3) runs as two workgroups per brick, their halves meeting by atomic add
+# Cin split: a grid of 128 workgroups (B = 32 at 8^3) runs as two workgroups per brick, their halves meeting inside the launch
 os.environ.pop("DM3D_CONV_WIDE_WGS", None)
 for name, B, e, cin, cout, res in [("split 8^3 B=32 256->256 +res", 32, 8, 256, 256, 1), ("split 8^3 B=32 512->256", 32, 8, 512, 256, 0)]:
     x = torch.randn(B, e, e, e, cin, device=dev)
