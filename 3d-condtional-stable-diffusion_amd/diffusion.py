@@ -147,25 +147,22 @@ class DiffusionModel:
             self.load_state_dict(dict(np.load(path)))
             return
         from . import tf_checkpoint as tc
-        self.load_state_dict(tc.load_unet_state(str(path), self.network.cfg, root=tuple(root)))
+        # (with the Adam slots and step count of a compiled model's checkpoint, if it carries them: the reference resumes training with
+        # model.load_weights(<epoch>.ckpt), main_conditional_dm.py:174-183)
+        self.load_state_dict(tc.load_unet_state(str(path), self.network.cfg, root=tuple(root), with_optimizer=True))
         rd = tc.BundleReader(str(path))
         if any(k.startswith("vqvae_trainer/") for k in rd.entries):
             self.vqvae_trainer.load_weights(path, root=("vqvae_trainer",))
 
     def save_weights(self, path, root=("network",)):
         self._sync_from_trainer()
+        # the Adam slots and step count travel with the weights, as in the reference's save_weights_only TF checkpoints of a compiled model
+        opt = self._trainer.optimizer_state() if self._trainer is not None and self._trainer.step_count > 0 else (getattr(self, "_pending_optimizer", None) or {})
         if str(path).endswith(".npz"):
-            # the Adam slots travel with the weights (as in the reference's save_weights_only TF checkpoints); the TF-format writer
-            # below stores the network only
-            opt = self._trainer.optimizer_state() if self._trainer is not None and self._trainer.step_count > 0 else (getattr(self, "_pending_optimizer", None) or {})
             np.savez(path, **self.network.state_dict(), **opt)
             return
         from . import tf_checkpoint as tc
-        if (self._trainer is not None and self._trainer.step_count > 0) or getattr(self, "_pending_optimizer", None):
-            import warnings
-            warnings.warn("save_weights: the TF-checkpoint writer stores the network only; the Adam slots and step count of this trained model "
-                          "are NOT written (a resume from this file restarts the bias correction). Save to an .npz path to keep them.")
-        tc.save_unet_checkpoint(str(path), self.network.state_dict(), self.network.cfg, root=tuple(root))
+        tc.save_unet_checkpoint(str(path), self.network.state_dict(), self.network.cfg, root=tuple(root), optimizer=opt or None)
 
     def _drop_graphs(self):
         for g in self._graphs.values():

@@ -79,11 +79,21 @@ class VQGAN(VQVAE):
 
     # ---- weights -----------------------------------------------------------------------------------------------------
     def load_weights(self, path, root=()):
+        """keras ``VQGAN.load_weights(prefix)`` (main_exp_vqgan.py:23-38 builds the model the checkpoint belongs to): the encoder, decoder
+        and quantizer of a TF2 checkpoint written by the reference's ``save_weights`` — the discriminators, LPIPS network and optimizer
+        slots it also holds are not read —, or an .npz of the state dict."""
         if str(path).endswith(".npz"):
             self.load_state_dict(dict(np.load(path)))
             return
-        raise NotImplementedError("TF-checkpoint import is mapped for networks/vqvae3d_monai.py and the U-Net only (tf_checkpoint.py); "
-                                  "load a VQGAN from an .npz state dict")
+        from ..tf_checkpoint import load_vqvae_state
+        self.load_state_dict(load_vqvae_state(str(path), self.spec, root=tuple(root), parts=("encoder", "decoder", "quantizer")))
+
+    def save_weights(self, path, root=()):
+        if str(path).endswith(".npz"):
+            np.savez(path, **self.state)
+            return
+        from ..tf_checkpoint import save_vqvae_checkpoint
+        save_vqvae_checkpoint(str(path), self.state, self.spec, root=tuple(root))
 
     def _folded(self, conv: str, bn: str, transpose: bool = False):
         """Conv kernel / bias with the inference BatchNormalization that follows folded in: W' = W*scale[co], b' = b*scale + shift."""

@@ -116,6 +116,45 @@ def _f_varint(num, v): return _field(num, 0, _varint(v))
 def _f_bytes(num, b): return _field(num, 2, _varint(len(b)) + b)
 
 
+def _sint64(v: int) -> int:
+    """a protobuf int64 read as a varint: two's complement for negative values"""
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+# ---- OrderedCode (tensorflow/core/lib/strings/ordered_code.cc), as far as slice keys need it -----------------------------------
+def _oc_num_increasing(v: int) -> bytes:
+    body = v.to_bytes((v.bit_length() + 7) // 8, "big") if v else b""
+    return bytes([len(body)]) + body
+
+
+def _oc_string(b: bytes) -> bytes:
+    return b"".join(b"\x00\xff" if c == 0 else (b"\xff\x00" if c == 255 else bytes([c])) for c in b) + b"\x00\x01"
+
+
+def _oc_signed_increasing(val: int) -> bytes:
+    x = ~val if val < 0 else val
+    if x < 64:
+        return bytes([(0x80 ^ val) & 0xFF])
+    n = 2
+    while 7 * n - 1 < x.bit_length():                           # n bytes carry 7 n - 1 value bits behind the unary length header
+        n += 1
+    buf = bytearray((val & ((1 << 80) - 1)).to_bytes(10, "big"))
+    header = [(0, 0), (0x80, 0), (0xC0, 0), (0xE0, 0), (0xF0, 0), (0xF8, 0), (0xFC, 0), (0xFE, 0), (0xFF, 0), (0xFF, 0x80), (0xFF, 0xC0)][n]
+    buf[10 - n] ^= header[0]
+    buf[11 - n] ^= header[1]
+    return bytes(buf[10 - n:])
+
+
+def encode_slice_key(name: str, extents) -> bytes:
+    """checkpoint::EncodeTensorNameSlice: 0, the name, the rank, then (start, length) per axis with (-1, -1) for a whole axis."""
+    out = _oc_num_increasing(0) + _oc_string(name.encode()) + _oc_num_increasing(len(extents))
+    for st, ln in extents:
+        if ln < 0:
+            st = -1
+        out += _oc_signed_increasing(st) + _oc_signed_increasing(ln)
+    return out
+
+
 # ---- sorted string table -----------------------------------------------------------------------------------------------------
 def _read_block(f, offset: int, size: int, verify: bool) -> bytes:
     f.seek(offset)
@@ -231,14 +270,26 @@ class BundleReader:
             if 2 in m:
                 for d in parse_message(m[2][0]).get(2, []):
                     shape.append(parse_message(d).get(1, [0])[0])
-            if 7 in m:
-                raise ValueError(f"{k!r}: sliced (partitioned) variables are not supported")
-            self.entries[k.decode()] = dict(dtype=m.get(1, [0])[0], shape=tuple(shape), shard=m.get(3, [0])[0],
-                                            offset=m.get(4, [0])[0], size=m.get(5, [0])[0], crc=m.get(6, [None])[0])
+            slices = None
+            if 7 in m:                                      # a partitioned variable: the pieces live under their own (binary) keys
+                slices = []
+                for sl in m[7]:
+                    ext = []
+                    for e in parse_message(sl).get(1, []):
+                        em = parse_message(e)
+                        ext.append((_sint64(em.get(1, [0])[0]), _sint64(em[2][0]) if 2 in em else -1))      # (start, length); length -1: the whole axis
+                    slices.append(tuple(ext))
+            try:
+                name = k.decode()
+            except UnicodeDecodeError:
+                name = k.decode("latin-1")                  # slice keys (OrderedCode): kept byte for byte
+            self.entries[name] = dict(dtype=m.get(1, [0])[0], shape=tuple(shape), shard=m.get(3, [0])[0],
+                                      offset=m.get(4, [0])[0], size=m.get(5, [0])[0], crc=m.get(6, [None])[0], slices=slices)
         self._maps: Dict[int, np.memmap] = {}
 
     def keys(self) -> List[str]:
-        return sorted(self.entries)
+        """The variables (slice pieces of partitioned variables are reached through their variable's key)."""
+        return sorted(k for k in self.entries if not k.startswith("\x00"))
 
     def shape(self, key: str) -> Tuple[int, ...]:
         return self.entries[key]["shape"]
@@ -256,6 +307,24 @@ class BundleReader:
         e = self.entries[key]
         if e["dtype"] not in _NP:
             raise ValueError(f"{key}: dtype {e['dtype']} is not numeric")
+        if e["slices"] is not None:
+            # tf.Variable partitioned by a partitioner / saved with a SaveSliceInfo: the full-tensor entry lists the slices, every slice is
+            # an entry of its own under checkpoint::EncodeTensorNameSlice(name, slice) (tensorflow/core/util/saved_tensor_slice_util.cc)
+            out = np.empty(e["shape"], dtype=_NP[e["dtype"]])
+            covered = np.zeros(e["shape"], dtype=bool)
+            for ext in e["slices"]:
+                sk = encode_slice_key(key, ext).decode("latin-1")
+                if sk not in self.entries:
+                    raise ValueError(f"{key}: slice {ext} is listed but has no entry")
+                idx = tuple(slice(None) if ln < 0 else slice(st, st + ln) for st, ln in ext)
+                piece = self.tensor(sk, verify)
+                if piece.shape != out[idx].shape:
+                    raise ValueError(f"{key}: slice {ext} has shape {piece.shape}, expected {out[idx].shape}")
+                out[idx] = piece
+                covered[idx] = True
+            if not covered.all():
+                raise ValueError(f"{key}: the saved slices do not cover the variable")
+            return out
         buf = self._shard(e["shard"])[e["offset"]:e["offset"] + e["size"]]
         if verify and e["crc"] is not None and mask_crc(crc32c(bytes(buf))) != e["crc"]:
             raise ValueError(f"{key}: tensor checksum mismatch")
@@ -311,7 +380,11 @@ class ObjectGraph:
             for a in m.get(2, []):
                 am = parse_message(a)
                 attrs[am.get(1, [b""])[0].decode()] = (am.get(2, [b""])[0].decode(), am.get(3, [b""])[0].decode())
-            self.nodes.append({"children": children, "vars": attrs})
+            slots = []                                   # SlotVariableReference {original_variable_node_id = 1, slot_name = 2, slot_variable_node_id = 3}
+            for sr in m.get(3, []):
+                sm = parse_message(sr)
+                slots.append((sm.get(1, [0])[0], sm.get(2, [b""])[0].decode(), sm.get(3, [0])[0]))
+            self.nodes.append({"children": children, "vars": attrs, "slots": slots})
 
     def child(self, node: int, *path: str) -> int:
         for p in path:
@@ -330,6 +403,8 @@ def serialize_object_graph(nodes: List[dict]) -> bytes:
             body += _f_bytes(1, _f_varint(1, nid) + _f_bytes(2, name.encode()))
         for attr, (full, key) in n.get("vars", {}).items():
             body += _f_bytes(2, _f_bytes(1, attr.encode()) + _f_bytes(2, full.encode()) + _f_bytes(3, key.encode()))
+        for orig, slot, node in n.get("slots", []):
+            body += _f_bytes(3, _f_varint(1, orig) + _f_bytes(2, slot.encode()) + _f_varint(3, node))
         out += _f_bytes(1, body)
     return out
 
@@ -422,9 +497,13 @@ def _collect(graph: ObjectGraph, node: int, path=()):
     return out
 
 
-def load_unet_state(prefix: str, cfg, root: Tuple[str, ...] = ("network",), verify: bool = False) -> Dict[str, np.ndarray]:
+def load_unet_state(prefix: str, cfg, root: Tuple[str, ...] = ("network",), verify: bool = False, with_optimizer: bool = False) -> Dict[str, np.ndarray]:
     """Reads the U-Net weights of a reference checkpoint (``DiffusionModel.save_weights(prefix)``; ``root=()`` for a bare
-    ``network.save_weights``) into this package's state dict.  Raises with the offending names on any count or shape mismatch."""
+    ``network.save_weights``) into this package's state dict.  Raises with the offending names on any count or shape mismatch.
+    ``with_optimizer``: also the Adam state of a compiled model's checkpoint (``optimizer`` child of the root with ``iter`` and the m / v
+    slot variables, referenced through the object graph's slot_variables — the layout OptimizerV2 writes, TF <= 2.10 and
+    tf.keras.optimizers.legacy) as ``optimizer/iter``, ``optimizer/m/<name>``, ``optimizer/v/<name>``: what ``model.load_weights(<epoch>.ckpt)``
+    resumes with in the reference (main_conditional_dm.py:174-183).  A checkpoint without them yields the weights alone."""
     from .weights import param_spec
     rd = BundleReader(prefix)
     if OBJECT_GRAPH_KEY not in rd.entries:
@@ -452,6 +531,7 @@ def load_unet_state(prefix: str, cfg, root: Tuple[str, ...] = ("network",), veri
         want.setdefault(cls, []).append(name)
     spec = param_spec(cfg)
     state: Dict[str, np.ndarray] = {}
+    key_of_target: Dict[str, str] = {}
     for cls, names in want.items():
         have = sorted(by_class.get(cls, []))
         if len(have) != len(names):
@@ -467,6 +547,7 @@ def load_unet_state(prefix: str, cfg, root: Tuple[str, ...] = ("network",), veri
                 else:
                     target = f"{name}.{_VAR[attr]}"
                 arr = rd.tensor(key, verify)
+                key_of_target[target] = key
                 if target not in spec:
                     raise ValueError(f"checkpoint variable {key} maps to unknown parameter {target}")
                 if tuple(arr.shape) != tuple(spec[target]):
@@ -475,11 +556,22 @@ def load_unet_state(prefix: str, cfg, root: Tuple[str, ...] = ("network",), veri
     missing = [n for n in spec if n not in state]
     if missing:
         raise ValueError(f"checkpoint lacks {len(missing)} parameters, e.g. {missing[:4]}")
+    if with_optimizer and "optimizer" in graph.nodes[0]["children"]:
+        opt = graph.nodes[0]["children"]["optimizer"]
+        node_of_key = {v["vars"]["VARIABLE_VALUE"][1]: i for i, v in enumerate(graph.nodes) if "VARIABLE_VALUE" in v["vars"]}
+        target_of_node = {node_of_key[key]: target for target, key in key_of_target.items() if key in node_of_key}
+        it = graph.nodes[opt]["children"].get("iter")
+        if it is not None and graph.variable(it) is not None:
+            state["optimizer/iter"] = np.asarray(rd.tensor(graph.variable(it)[1], verify), np.int64).reshape(())
+        for orig, slot, node in graph.nodes[opt]["slots"]:
+            if orig in target_of_node and slot in ("m", "v") and graph.variable(node) is not None:
+                state[f"optimizer/{slot}/{target_of_node[orig]}"] = rd.tensor(graph.variable(node)[1], verify).astype(np.float32, copy=False)
     return state
 
 
 def save_unet_checkpoint(prefix: str, state: Dict[str, np.ndarray], cfg, root: Tuple[str, ...] = ("network",),
-                         first_index: Optional[Dict[str, int]] = None, shuffle_seed: Optional[int] = None) -> None:
+                         first_index: Optional[Dict[str, int]] = None, shuffle_seed: Optional[int] = None,
+                         optimizer: Optional[Dict[str, np.ndarray]] = None) -> None:
     """Writes ``state`` as an object-based checkpoint laid out the way Keras would for the reference's model: auto layer names
     numbered per class in creation order (``first_index`` = numbers already used by models built earlier in the process, e.g.
     the VQ-VAE), ``layer_with_weights-N`` indices in an order unrelated to creation order (``shuffle_seed``), custom-layer
@@ -512,12 +604,15 @@ def save_unet_checkpoint(prefix: str, state: Dict[str, np.ndarray], cfg, root: T
         nodes[parent]["children"][r] = n
         parent, prefix_key = n, prefix_key + r + "/"
 
+    var_nodes: Dict[int, Tuple[int, str, str]] = {}          # id(array of ``state``) -> (node, key path, keras full name)
+
     def add_var(owner, owner_key, attr, full, arr):
         v = new_node()
         nodes[owner]["children"][attr] = v
         key = f"{owner_key}/{attr}{VALUE_SUFFIX}"
         nodes[v]["vars"]["VARIABLE_VALUE"] = (full, key)
         tensors[key] = np.asarray(arr, np.float32)
+        var_nodes[id(arr)] = (v, f"{owner_key}/{attr}", full)
 
     def params_of(name):
         return [(k[len(name) + 1:], v) for k, v in state.items() if k.startswith(name + ".") and "." not in k[len(name) + 1:]]
@@ -550,6 +645,29 @@ def save_unet_checkpoint(prefix: str, state: Dict[str, np.ndarray], cfg, root: T
         else:
             for short, arr in params_of(name):
                 add_var(layer, lkey, inv_var[short], f"{lname}/{inv_var[short]}", arr)
+    # ``optimizer``: {"optimizer/iter", "optimizer/m/<name>", "optimizer/v/<name>"} (Trainer.optimizer_state()): the Adam state as
+    # OptimizerV2 checkpoints it — an ``optimizer`` child of the root with ``iter``, and one slot variable per (trainable variable, slot)
+    # under <variable key>/.OPTIMIZER_SLOT/optimizer/<slot>, referenced from the optimizer object's slot_variables
+    if optimizer:
+        opt = new_node()
+        nodes[0]["children"]["optimizer"] = opt
+        itn = new_node()
+        nodes[opt]["children"]["iter"] = itn
+        nodes[itn]["vars"]["VARIABLE_VALUE"] = ("Adam/iter", f"optimizer/iter{VALUE_SUFFIX}")
+        tensors[f"optimizer/iter{VALUE_SUFFIX}"] = np.asarray(optimizer["optimizer/iter"], np.int64).reshape(())
+        nodes[opt]["slots"] = []
+        for name, arr in state.items():
+            if id(arr) not in var_nodes:
+                continue
+            v, kpath, full = var_nodes[id(arr)]
+            for slot in ("m", "v"):
+                if f"optimizer/{slot}/{name}" not in optimizer:
+                    continue
+                sn = new_node()
+                key = f"{kpath}/.OPTIMIZER_SLOT/optimizer/{slot}{VALUE_SUFFIX}"
+                nodes[sn]["vars"]["VARIABLE_VALUE"] = (f"Adam/{full}/{slot}", key)
+                tensors[key] = np.asarray(optimizer[f"optimizer/{slot}/{name}"], np.float32)
+                nodes[opt]["slots"].append((v, slot, sn))
     tensors[OBJECT_GRAPH_KEY] = serialize_object_graph(nodes)
     write_bundle(prefix, tensors)
 
@@ -589,9 +707,13 @@ def _all_variables(graph: ObjectGraph, node: int):
     return [(full, key) for key, full in out.items()]
 
 
-def load_vqvae_state(prefix: str, spec: Dict[str, tuple], root: Tuple[str, ...] = (), verify: bool = False) -> Dict[str, np.ndarray]:
+def load_vqvae_state(prefix: str, spec: Dict[str, tuple], root: Tuple[str, ...] = (), verify: bool = False,
+                     parts: Optional[Tuple[str, ...]] = None) -> Dict[str, np.ndarray]:
     """Autoencoder weights of a reference checkpoint (``vqvae.save_weights``: root (); inside a DiffusionModel checkpoint:
-    root ("vqvae_trainer",)) -> the state dict of ``networks.vqvae3d_monai.VQVAE``."""
+    root ("vqvae_trainer",)) -> the state dict of ``networks.vqvae3d_monai.VQVAE``.  ``parts``: only these children of the saved object
+    are read — ("encoder", "decoder", "quantizer") for ``networks/vqgan.py``, whose checkpoints also carry two discriminators (Conv3D /
+    Conv2D / Dense layers created AFTER the autoencoder: their creation numbers follow the autoencoder's), the LPIPS network, metric
+    trackers and the optimizers' slots (vqgan.py:644-696)."""
     rd = BundleReader(prefix)
     if OBJECT_GRAPH_KEY not in rd.entries:
         raise ValueError("not an object-based TF2 checkpoint (no _CHECKPOINTABLE_OBJECT_GRAPH)")
@@ -602,7 +724,14 @@ def load_vqvae_state(prefix: str, spec: Dict[str, tuple], root: Tuple[str, ...] 
         raise ValueError(f"object {'/'.join(root)} not found under the checkpoint root") from e
     layers: Dict[Tuple[str, int], Dict[str, str]] = {}
     state: Dict[str, np.ndarray] = {}
-    for full, key in _all_variables(graph, top):
+    if parts is None:
+        found = _all_variables(graph, top)
+    else:
+        missing_parts = [q for q in parts if q not in graph.nodes[top]["children"]]
+        if missing_parts:
+            raise ValueError(f"checkpoint object has no {missing_parts} (children: {sorted(graph.nodes[top]['children'])})")
+        found = [v for q in parts for v in _all_variables(graph, graph.nodes[top]["children"][q])]
+    for full, key in found:
         parts = full.split("/")
         attr = parts[-1].split(":")[0]
         if attr.startswith("embeddings_vqvae"):
@@ -631,7 +760,7 @@ def load_vqvae_state(prefix: str, spec: Dict[str, tuple], root: Tuple[str, ...] 
 
 
 def save_vqvae_checkpoint(prefix: str, state: Dict[str, np.ndarray], spec: Dict[str, tuple], root: Tuple[str, ...] = (),
-                          first_index: Optional[Dict[str, int]] = None) -> None:
+                          first_index: Optional[Dict[str, int]] = None, extra: Optional[Dict[str, np.ndarray]] = None) -> None:
     """Writes the autoencoder ``state`` with Keras-style names (auto layer names per class in creation order, nested under
     encoder / decoder / quantizer objects).  Export path and test-fixture generator."""
     counters = dict(first_index or {})
@@ -679,5 +808,15 @@ def save_vqvae_checkpoint(prefix: str, state: Dict[str, np.ndarray], spec: Dict[
                 key = f"{lkey}/{attr}{VALUE_SUFFIX}"
                 nodes[v]["vars"]["VARIABLE_VALUE"] = (f"vqvae/{part_key[part]}/{lname}/{attr}", key)
                 tensors[key] = np.asarray(state[k], np.float32)
+    # ``extra``: variables of sibling objects a real checkpoint holds beside the autoencoder (the VQGAN's discriminators): name
+    # "discriminator/conv3d_40/kernel" -> child "discriminator", layer_with_weights-k, Keras full name as given
+    for j, (full, arr) in enumerate((extra or {}).items()):
+        obj, lname, attr = full.split("/")
+        onode = nodes[top]["children"].get(obj) or new_node(top, obj)
+        layer = new_node(onode, f"layer_with_weights-{j}")
+        v = new_node(layer, attr)
+        key = f"{key_prefix}{obj}/layer_with_weights-{j}/{attr}{VALUE_SUFFIX}"
+        nodes[v]["vars"]["VARIABLE_VALUE"] = (f"{lname}/{attr}", key)
+        tensors[key] = np.asarray(arr, np.float32)
     tensors[OBJECT_GRAPH_KEY] = serialize_object_graph(nodes)
     write_bundle(prefix, tensors)

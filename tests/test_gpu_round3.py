@@ -252,8 +252,17 @@ def test_optimizer_state_survives_save_and_load(dev, tmp_path):
     assert c._trainer is not None and c.trainer.step_count == 1
     sc2 = c.network.state_dict()
     assert all(np.array_equal(sc[k], sc2[k]) for k in sc)
-    with pytest.warns(UserWarning, match="Adam slots"):                 # the TF-format writer stores the network only and says so
-        a.save_weights(str(tmp_path / "tfck"))
+    # round 5: the TF-format writer carries the Adam slots and the step count too (OptimizerV2 layout: optimizer/iter + slot variables)
+    a.save_weights(str(tmp_path / "tfck"))
+    d = cdm.DiffusionModel(8, 1024, 4, None, _args(T, B), weights=W)
+    d.compile(optimizer=SimpleNamespace(learning_rate=1e-4))
+    d.load_weights(str(tmp_path / "tfck"))
+    assert d._pending_optimizer is not None and int(d._pending_optimizer["optimizer/iter"]) == 3
+    assert d.trainer.step_count == 3
+    sd, sa2 = d.network.state_dict(), a.network.state_dict()
+    assert all(np.array_equal(sd[k], sa2[k]) for k in sa2)
+    oa, od = a.trainer.optimizer_state(), d.trainer.optimizer_state()
+    assert set(oa) == set(od) and all(np.array_equal(np.asarray(oa[k]), np.asarray(od[k])) for k in oa)
 
 
 def test_data_parallel_train_step_two_ranks(dev, tmp_path):
