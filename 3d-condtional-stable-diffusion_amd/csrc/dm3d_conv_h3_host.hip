@@ -86,7 +86,9 @@ __global__ __launch_bounds__(256) void pack_weights_h3v2_kernel(const float* __r
         const int p16 = pos & 15;
         int c = 0;
         for (int cc = 0; cc < 16; ++cc) if (pi_pos(cc) == p16) c = cc;
-        const int ci = chunk * 16 + k, co = nt * 64 + (pos & ~15) + c;
+        // column c of 16-column tile pos >> 4: output channel 16 tile + c; the Winograd image (mode 3): 4 c + tile — a lane's four column tiles are
+        // four consecutive channels (epilogue_cq, dm3d_conv_h3v2_parts.h)
+        const int ci = chunk * 16 + k, co = nt * 64 + (mode == 3 ? 4 * c + (pos >> 4) : (pos & ~15) + c);
         float v = 0.f;
         if (ci < cin && co < cout && tap < taps) {
             if (mode == 3) {
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void pack_skip_h3v2_kernel(const float* __rest
 
 // the same 1x1 kernel as MFMA operand fragments: [coutpad/64][npairs][4 column tiles][hi | lo][64 lanes][8 halfs]; lane (column c = lane & 15,
 // k group = lane >> 4: chunk 2 pair + (k group >> 1), channels 8 (k group & 1) .. + 7 of it) holds its 8 consecutive k of output channel
-// 64 ntile + 16 tile + c — what the v_mfma_f32_16x16x32_f16 B operand of that lane is
+// 64 ntile + 4 c + tile (the Winograd kernel's column mapping) — what the v_mfma_f32_16x16x32_f16 B operand of that lane is
 __global__ __launch_bounds__(256) void pack_skip_h3f_kernel(const float* __restrict__ w, int cin, int cout, int npairs, int ntiles,
                                                             float scale, _Float16* __restrict__ out) {
     const long npieces = (long)ntiles * npairs * 4 * 2 * 64;
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void pack_skip_h3f_kernel(const float* __restr
         const int pair = (int)(q % npairs);
         const int nt = (int)(q / npairs);
         const int kg = lane >> 4;
-        const int ci = (pair * 2 + (kg >> 1)) * 16 + (kg & 1) * 8 + j, co = nt * 64 + ni * 16 + (lane & 15);
+        const int ci = (pair * 2 + (kg >> 1)) * 16 + (kg & 1) * 8 + j, co = nt * 64 + 4 * (lane & 15) + ni;      // (the Winograd kernel's channel-quad mapping)
         const float v = (ci < cin && co < cout) ? w[(long)ci * cout + co] * scale : 0.0f;
         const _Float16 hi = (_Float16)v;
         out[i] = hilo ? (_Float16)(v - (float)hi) : hi;

@@ -513,4 +513,143 @@ __device__ __forceinline__ void gn_flush(const ConvArgs& p, float (&gn)[NCT * 8]
     }
 }
 
+// ---- The Winograd kernel's epilogue (round 5): the CHANNEL-QUAD column mapping.  Which output channel an MFMA column computes is the weight
+// packer's choice.  The direct kernel's image puts channel 16 ni + j into column j of column tile ni, so a lane (column j) holds ONE channel of
+// four voxels per tile and the 16-byte form above first transposes every tile across a quad of lanes.  The Winograd image
+// (dm3d_pack_weights_h3w, and the fused skip conv's operand fragments) puts channel 4 j + ni there instead: the four column tiles of a lane
+// are four CONSECUTIVE channels of one voxel — register r of tiles (t, 0..3) is a 16-byte piece as it stands.  No transpose (16 of ~60
+// instructions per tile), and the sixteen lanes of a row group write 256 contiguous bytes of a voxel: a store instruction covers 8 whole
+// cache lines instead of 16 half lines (timing-only bound of fully coalesced stores: profiles/r05_ab_store_coalescing.log).
+// e[2 g + parity][ni][r]: voxel (y = 4 g + r, x = 2 * x-pair + parity) of z-slice zs, channel 64 ntile + 4 j + ni; lane = 16 * x-pair + j.
+// Whole 8 x 8 x 8 bricks only (dm3d_conv_h3w_serves), stride-1 outputs.  gn: this lane's partial (sum, sum of squares) of its four
+// channels, [ni][2] (gn_flush_cq below).
+template <int TD>
+__device__ __forceinline__ void epilogue_cq(const ConvArgs& p, f32x4v (&e)[4][4], const Brick& br, const int zs, float* gn = nullptr) {
+    constexpr int NT = 64;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                       // (lane constants made here, not alive — spilled — across the caller's main loop)
+    const int lane = tid & 63, j4 = (lane & 15) * 4, xp = lane >> 4;
+    const int n0 = br.ntile * NT, n = n0 + j4;           // this lane's first channel
+    const int vrow = p.vec ? (p.vec_idx ? p.vec_idx[br.b] : br.b) : 0;
+    const size_t zbase = (((size_t)br.b * p.fd + br.oz0 + zs) * p.fh) * p.fw * p.cout;
+    float* const outz = p.out + zbase;
+    const float* const resz = p.res ? p.res + zbase : nullptr;
+    const float* const prz = p.prelu ? p.prelu + (zbase - (size_t)br.b * p.fd * p.fh * p.fw * p.cout) : nullptr;
+    // element offset of voxel (y = oy0 + 4 g + r, x = ox0 + 2 xp + parity), channel n
+    auto voff = [&](const int t, const int r) { return ((br.oy0 + 4 * (t >> 1) + r) * p.fw + br.ox0 + 2 * xp + (t & 1)) * p.cout + n; };
+    float amax = 0.0f;
+#ifndef DM3D_EPILOGUE_SCALAR
+    if (n0 + NT <= p.cout && p.epi_vec4 && !prz) {
+        f32x4 rv[4][4];                                  // [tile][row]
+        if (resz) {                                      // every load before the first store (vmcnt counts both, in order)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rv[t][r] = *reinterpret_cast<const f32x4*>(resz + voff(t, r));
+        }
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, one = {1.f, 1.f, 1.f, 1.f};
+        f32x4 add = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : zero;
+        if (p.vec) {
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(p.vec + (size_t)vrow * p.vec_ld + n);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) add[c] += vv[c];
+        }
+        const f32x4 ps = p.post_scale ? *reinterpret_cast<const f32x4*>(p.post_scale + n) : one;
+        const f32x4 pt = p.post_scale ? *reinterpret_cast<const f32x4*>(p.post_shift + n) : zero;
+        const int h2off = (n >> 4) * 64 + ((n >> 3) & 1) * 16 + (n & 7) * 2 - n * 4;       // DM3D_FMT_H2 position of channels n .. n + 3 inside their voxel's row
+        auto tiles = [&](auto POST_T, auto H2_T, auto GN_T) {
+            constexpr bool POST = decltype(POST_T)::value, H2 = decltype(H2_T)::value, GN = decltype(GN_T)::value;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f32x4 v4;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float v = fmaf(e[t][c][r], p.out_scale, add[c]);
+                        if (p.relu) v = fmaxf(v, 0.0f);
+                        if (resz) v += rv[t][r][c];
+                        if (p.relu_out) v = fmaxf(v, 0.0f);
+                        if constexpr (POST) v = dm3d_silu(fmaf(v, ps[c], pt[c]));
+                        DM3D_AMAX(amax, v);
+                        v4[c] = v;
+                        if constexpr (GN) { gn[c * 2] += v; gn[c * 2 + 1] = fmaf(v, v, gn[c * 2 + 1]); }
+                    }
+                    const int o = voff(t, r);
+                    if constexpr (H2) {
+                        const unsigned int w0 = split1_bits(v4[0]), w1 = split1_bits(v4[1]), w2 = split1_bits(v4[2]), w3 = split1_bits(v4[3]);
+                        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                        char* dst = reinterpret_cast<char*>(outz) + (size_t)o * 4 + h2off;
+                        *reinterpret_cast<u32x2*>(dst) = u32x2{(w0 & 0xffffu) | (w1 << 16), (w2 & 0xffffu) | (w3 << 16)};
+                        *reinterpret_cast<u32x2*>(dst + 32) = u32x2{(w0 >> 16) | (w1 & 0xffff0000u), (w2 >> 16) | (w3 & 0xffff0000u)};
+                    } else {
+                        *reinterpret_cast<f32x4*>(outz + o) = v4;
+                    }
+                }
+        };
+        const std::true_type yes_t;
+        const std::false_type no_t;
+        if (p.post_scale) { if (p.out_h2) tiles(yes_t, yes_t, no_t); else tiles(yes_t, no_t, no_t); }
+        else if (p.out_h2) tiles(no_t, yes_t, no_t);
+        else if (gn) tiles(no_t, no_t, yes_t);
+        else tiles(no_t, no_t, no_t);
+        if (p.range_flag && amax > p.range_limit) *p.range_flag = 1;
+        return;
+    }
+#endif
+    // the general form: a ragged last column tile, unaligned operands, PReLU (the autoencoders' residual units) — element by element
+    int nq = n;
+    asm volatile("" : "+v"(nq));                         // (keeps this form's address arithmetic out of the 16-byte form's way)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const bool n_ok = nq + c < p.cout;
+        const int nc = n_ok ? nq + c : p.cout - 1;
+        float add = p.bias ? p.bias[nc] : 0.0f;
+        if (p.vec) add += p.vec[(size_t)vrow * p.vec_ld + nc];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = n_ok ? voff(t, r) - nq + nc : 0;
+                float v = fmaf(e[t][c][r], p.out_scale, add);
+                if (p.relu) v = fmaxf(v, 0.0f);
+                if (prz) { const float al = prz[o]; v = v > 0.0f ? v : al * v; }
+                if (resz) v += resz[o];
+                if (p.relu_out) v = fmaxf(v, 0.0f);
+                if (n_ok) { DM3D_AMAX(amax, v); outz[o] = v; }
+            }
+    }
+    if (p.range_flag && amax > p.range_limit) *p.range_flag = 1;
+}
+
+// The fused GroupNormalization statistics of epilogue_cq: a lane's partial sums of its four channels over the tiles of `slices` z-slices are
+// added over the four lanes that hold the same channels (the x-pairs: lane bits 4-5) and stored as the slot of z-slice zs
+// (gn_stats[b][slot][cout][2], as gn_flush does; the further slices' slots are written as zeros).
+template <int TD>
+__device__ __forceinline__ void gn_flush_cq(const ConvArgs& p, float (&gn)[8], const Brick& br, const int zs, const int slices) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float v = gn[i];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        gn[i] = v;
+    }
+    if (lane < 16) {
+        const int bh = p.oh / 8, bw = p.ow / 8;
+        const long nslots = (long)p.od * bh * bw;
+        const long slot = ((long)(br.oz0 + zs) * bh + br.oy0 / 8) * bw + br.ox0 / 8;
+        float* dst = p.gn_stats + (((size_t)br.b * nslots + slot) * p.cout + br.ntile * 64 + lane * 4) * 2;
+        *reinterpret_cast<f32x4*>(dst) = f32x4{gn[0], gn[1], gn[2], gn[3]};
+        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{gn[4], gn[5], gn[6], gn[7]};
+        for (int k = 1; k < slices; ++k) {
+            float* dz = dst + (size_t)k * bh * bw * p.cout * 2;
+            *reinterpret_cast<f32x4*>(dz) = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(dz + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
 }  // namespace h3v2

@@ -25,6 +25,9 @@
 // The LDS image holds, per halo row (z, y) of the brick, 16 records [t][x-pair] of 16 channels (hi / lo, 64 bytes) at a pitch of 17
 // records (100 rows = 106 KB), slots XOR-swizzled by the row's y: the 4 y x 4 x-pair reads of a fragment hit 16 different 16-byte bank
 // groups, and so do the stores of one record index by the 64 rows of a wave (pitch 16 would put them all into one 64-byte window).
+// Output channels: column j of column tile ni computes channel 64 ntile + 4 j + ni (the packers' choice — dm3d_pack_weights_h3w and the skip conv's
+// operand fragments —, NOT the direct kernel's 16 ni + j): a lane's four column tiles are four consecutive channels of one voxel, and the
+// epilogue (epilogue_cq, dm3d_conv_h3v2_parts.h) stores 16-byte pieces without a transpose, 256 contiguous bytes per voxel and row group.
 // A step = one pair of (dz, dy) taps (the lane half picks the tap; the tenth tap is a zero pad) x one transform term: 20 steps per
 // 16-channel chunk, TERM-MAJOR (t = step / 5), three passes of 16 MFMAs each (al.bh, ah.bh, ah.bl) on registers; weights by LDS-DMA
 // through a ring of four 8 KB buffers, one barrier per step.  Term-major order is what keeps the staging out of the register file: the
@@ -805,9 +808,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
             finish = split_is_last(p, tile, reinterpret_cast<unsigned*>(lds_in + HROWS * RREC * REC));      // (a word behind the image: nobody else's)
         }
         if (finish) {
-            float gn[32];                       // fused GroupNormalization statistics of the output (ConvArgs.gn_stats): partial sums over both slices
+            float gn[8];                        // fused GroupNormalization statistics of the output (ConvArgs.gn_stats): this lane's four channels over both slices
 #pragma unroll
-            for (int i = 0; i < 32; ++i) gn[i] = 0.0f;
+            for (int i = 0; i < 8; ++i) gn[i] = 0.0f;
             static_for<2>([&](auto S_) {
                 constexpr int s = decltype(S_)::value;
                 __builtin_amdgcn_sched_barrier(0);
@@ -816,12 +819,12 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
                 slice_tiles(S_, e);
                 if (p.ksplit > 1) split_gather(stile, p, cur.khalf, e, 16 * s);
 #ifndef DM3D_EXP_NO_EPILOGUE                    // (timing-only A/B arm, tools/mk_variant_conv.sh: what hiding the whole epilogue could buy at most)
-                epilogue<TD, 4>(p, e, br, 2 * wave + s, 1, 2 * (lane >> 4), p.gn_stats ? gn : nullptr);
+                epilogue_cq<TD>(p, e, br, 2 * wave + s, p.gn_stats ? gn : nullptr);
 #else
                 if (e[0][0][0] == 12345.678f) p.out[0] = e[1][1][1] + e[2][2][2] + e[3][3][3];
 #endif
             });
-            if (p.gn_stats) gn_flush<TD, 4>(p, gn, br, 2 * wave, 2);
+            if (p.gn_stats) gn_flush_cq<TD>(p, gn, br, 2 * wave, 2);
         }
         STAMP(29);
         if (!has_next) break;
