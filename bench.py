@@ -13,7 +13,7 @@ Contract (one JSON line from rank 0):  python bench.py --gpus N --steps K --warm
     GPU — relays rank 0's JSON line and exits non-zero if any rank fails.
   * roofline: the dominant kernel is the k3/stride-1 Conv3d with the norm+SiLU prologue in its Winograd F(2,3)-along-x form,
     conv3d_igemm_h3w<1> (23 launches/step at B = 32: every Cin >= 32 conv of the 32^3 / 16^3 levels that reads a float32 tensor, and the
-    Cin >= 256 convs of the 8^3 level with their two-way Cin split, with or without a fused 1x1 skip tail; ~52 % of the step; persistent
+    Cin >= 256 convs of the 8^3 level with their two-way Cin split (the halves meet inside the launch), with or without a fused 1x1 skip tail; ~52 % of the step; persistent
     workgroups, one per CU); its MODE-2 twin behind a DM3D_FMT_H2 hand-off (10 launches, ~28 %), the direct kernel conv3d_igemm_h3v3
     (conv_in / conv_out, the UpSample parity convs, the first 8^3 conv, every k3 conv of small batches) and the stride-2 convs are listed
     under per_kernel_kind;
@@ -336,7 +336,8 @@ def main():
                      "per SIMD with 256 accumulator registers, persistent workgroups (one per CU walks a list of bricks; the next brick's first image "
                      "and weight steps are staged during the last chunk of the current one), 40 k-steps per output pair instead of 54; float16 hi+lo "
                      "split, 3 x v_mfma_f32_16x16x32_f16 per transformed product, fp32 accumulate; a fused 1x1 skip conv runs as a register-direct tail on the "
-                     "transformed tiles; launches with Cin < 32, partial bricks or grids too small even with the two-way Cin split stay on the direct "
+                     "transformed tiles; channel-quad column mapping: a lane's four column tiles are four consecutive channels, 16-byte stores "
+                     "without a transpose; launches with Cin < 32, partial bricks or grids too small even with the two-way Cin split stay on the direct "
                      "kernel conv3d_igemm_h3v3, listed as conv_k3s1_td4 / conv_k3s1_n32 / conv_up)")
             peak, passes = PEAK_F16_MFMA_TFLOPS, round(3 * 40 / 54, 3)
         elif args.precision == "h3":
