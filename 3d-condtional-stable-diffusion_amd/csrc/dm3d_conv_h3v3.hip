@@ -36,15 +36,21 @@
 using namespace h3v2;
 
 // Diagnostic build only (-DDM3D_CLOCK_STAMPS, tools/mk_stamp_variants.py -> variants/cck.so; the product library carries none of it): thread 0 of
-// every workgroup writes s_memtime / s_memrealtime at kernel entry (0), around the chunk loop (1, 28) and at the end (29) into a buffer of its
-// own — the in-kernel clock and matrix-pipe duty of tools/kernel_clock.py (MI355X_MICROARCH.md, 'DVFS give-back' item 6).
+// every workgroup writes s_memtime / s_memrealtime at kernel entry (0), when the first halo is back (2), around the chunk loop (1, 28), behind
+// the skip phase (19), behind the hand-over store / ticket / gather of a Cin-split launch (20, 21, 22) and at the end (29) into a buffer of its
+// own — the in-kernel clock and matrix-pipe duty of tools/kernel_clock.py (MI355X_MICROARCH.md, 'DVFS give-back' item 6) and the phase table
+// of tools/split_phases.py.
 #ifdef DM3D_CLOCK_STAMPS
 __device__ unsigned long long* g_dbg_stamps_c = nullptr;
 extern "C" int dm3d_debug_set_stamps_conv(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_stamps_c), &p, sizeof(p)); }
-#define STAMP(i) do { if (g_dbg_stamps_c && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 4096) { \
-    g_dbg_stamps_c[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
-    if ((i) == 1) g_dbg_stamps_c[blockIdx.x * 32 + 30] = __builtin_amdgcn_s_memrealtime(); \
-    if ((i) == 28) g_dbg_stamps_c[blockIdx.x * 32 + 31] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define STAMP(i) do { const unsigned wg_ = blockIdx.x + gridDim.x * blockIdx.y; \
+    if (g_dbg_stamps_c && threadIdx.x == 0 && blockIdx.z == 0 && wg_ < 4096) { \
+    g_dbg_stamps_c[wg_ * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if ((i) == 0) g_dbg_stamps_c[wg_ * 32 + 24] = __builtin_amdgcn_s_memrealtime(); \
+    if ((i) == 20) g_dbg_stamps_c[wg_ * 32 + 26] = __builtin_amdgcn_s_memrealtime(); \
+    if ((i) == 29) g_dbg_stamps_c[wg_ * 32 + 25] = __builtin_amdgcn_s_memrealtime(); \
+    if ((i) == 1) g_dbg_stamps_c[wg_ * 32 + 30] = __builtin_amdgcn_s_memrealtime(); \
+    if ((i) == 28) g_dbg_stamps_c[wg_ * 32 + 31] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -236,12 +242,18 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v3(const ConvArgs p
         raw0[j] = __builtin_bit_cast(f32x4, shi_j);
         raw1[j] = __builtin_bit_cast(f32x4, slo_j);
     };
+    // (the lo piece's address is made on the spot inside the asm pair: as C++ stores hipcc keeps the NSLOT hi AND lo addresses as lane
+    // constants across the chunk loop, and in the 4-slice prologue form — 256 registers at two waves per SIMD — spilled six of them: every
+    // store of the image then reloaded its address behind a vmcnt(0), i.e. behind the weight DMA pieces just issued)
+    const unsigned img_addr = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)lds_in;
     auto store_image = [&]() {
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) {
             if (st_off[j] >= 0) {
-                *reinterpret_cast<h8*>(lds_in + st_off[j]) = __builtin_bit_cast(h8, raw0[j]);
-                *reinterpret_cast<h8*>(lds_in + (st_off[j] ^ 16)) = __builtin_bit_cast(h8, raw1[j]);
+                const unsigned addr = img_addr + (unsigned)st_off[j] * 2u;
+                unsigned lo_addr;
+                asm volatile("ds_write_b128 %1, %2\n\tv_xor_b32 %0, 32, %1\n\tds_write_b128 %0, %3"
+                             : "=&v"(lo_addr) : "v"(addr), "v"(raw0[j]), "v"(raw1[j]) : "memory");
             }
         }
     };
@@ -258,6 +270,7 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v3(const ConvArgs p
     for (int j = 0; j < NSLOT; ++j) load_halo_slot(c_lo, j);
     load_chunk_params(c_lo);
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0) (with an instruction hipcc's wait-count pass sees): halo and the three weight pairs
+    STAMP(2);
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) convert_slot(j);
     store_image();
@@ -419,12 +432,16 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v3(const ConvArgs p
         // (the launcher sizes the dynamic LDS for whichever of the two phases needs more: v3_lds_halfs)
         skip_phase<TD>(p, smem_v3, acc, br);
     }
+    STAMP(19);
     if (p.ksplit > 1) {                     // (uniform) Cin split: store this part's tiles; the last part of the tile to arrive sums them and goes on
         const long tile = ((long)blockIdx.z * gridDim.x + brick_all) * ntiles + ntile;
         const SplitTile stile = split_tile(p, tile, khalf);
         split_store(stile, acc, 0);
+        STAMP(20);
         if (!split_is_last(p, tile, reinterpret_cast<unsigned*>(smem_v3))) return;      // (the LDS is free: every wave is past the barrier above / the skip phase's last)
+        STAMP(21);
         split_gather(stile, p, khalf, acc, 0);
+        STAMP(22);
     }
     if (p.gn_stats) {                       // fused GroupNormalization statistics of the output (uniform; the launcher admits the 16-byte full-brick form only)
         float gn[NCT * 8];
