@@ -520,7 +520,7 @@ __device__ __forceinline__ void gn_flush(const ConvArgs& p, float (&gn)[NCT * 8]
 // are four CONSECUTIVE channels of one voxel — register r of tiles (t, 0..3) is a 16-byte piece as it stands.  No transpose (16 of ~60
 // instructions per tile), and the sixteen lanes of a row group write 256 contiguous bytes of a voxel: a store instruction covers 8 whole
 // cache lines instead of 16 half lines (timing-only bound of fully coalesced stores: profiles/r05_ab_store_coalescing.log).
-// e[2 g + parity][ni][r]: voxel (y = 4 g + r, x = 2 * x-pair + parity) of z-slice zs, channel 64 ntile + 4 j + ni; lane = 16 * x-pair + j.
+// e[2 g + parity][ni][r]: voxel (y = 4 g + r, x = 2 * x-pair + parity) of z-slice zs, channel 64 ntile + 4 j + ni; lane = 16 * g + j with x-pair = g ^ (g >> 1).
 // Whole 8 x 8 x 8 bricks only (dm3d_conv_h3w_serves), stride-1 outputs.  gn: this lane's partial (sum, sum of squares) of its four
 // channels, [ni][2] (gn_flush_cq below).
 template <int TD>
@@ -528,7 +528,7 @@ __device__ __forceinline__ void epilogue_cq(const ConvArgs& p, f32x4v (&e)[4][4]
     constexpr int NT = 64;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));                       // (lane constants made here, not alive — spilled — across the caller's main loop)
-    const int lane = tid & 63, j4 = (lane & 15) * 4, xp = lane >> 4;
+    const int lane = tid & 63, j4 = (lane & 15) * 4, xp = (lane >> 4) ^ (lane >> 5);       // (accumulator row group g holds x-pair g ^ (g >> 1): the Winograd kernel's fragment order)
     const int n0 = br.ntile * NT, n = n0 + j4;           // this lane's first channel
     const int vrow = p.vec ? (p.vec_idx ? p.vec_idx[br.b] : br.b) : 0;
     const size_t zbase = (((size_t)br.b * p.fd + br.oz0 + zs) * p.fh) * p.fw * p.cout;
