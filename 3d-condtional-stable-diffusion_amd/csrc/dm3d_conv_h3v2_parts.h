@@ -523,14 +523,37 @@ __device__ __forceinline__ void gn_flush(const ConvArgs& p, float (&gn)[NCT * 8]
 // e[2 g + parity][ni][r]: voxel (y = 4 g + r, x = 2 * x-pair + parity) of z-slice zs, channel 64 ntile + 4 j + ni; lane = 16 * g + j with x-pair = g ^ (g >> 1).
 // Whole 8 x 8 x 8 bricks only (dm3d_conv_h3w_serves), stride-1 outputs.  gn: this lane's partial (sum, sum of squares) of its four
 // channels, [ni][2] (gn_flush_cq below).
+// The per-channel operands of epilogue_cq's 16-byte form — bias + vector row, post-norm scale / shift of this lane's four channels — are
+// the same for every z-slice of a work item: loaded ONCE per item (epilogue_cq_vecs, in front of the first slice).  Loaded per slice, the
+// second slice's requests queued behind the first slice's stores (vmcnt counts loads and stores together, in order) and waited out their
+// whole write latency.  vrow: the row of the vector tensor (dm3d_conv_desc.vec_idx), which the caller reads early (a dependent scalar load).
+struct EpiVecs { f32x4 add, ps, pt; };
+__device__ __forceinline__ EpiVecs epilogue_cq_vecs(const ConvArgs& p, const Brick& br, const int vrow) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int n = br.ntile * 64 + (tid & 15) * 4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, one = {1.f, 1.f, 1.f, 1.f};
+    EpiVecs ev;
+    ev.add = zero; ev.ps = one; ev.pt = zero;
+    if (br.ntile * 64 + 64 <= p.cout && p.epi_vec4) {            // (the general form loads element by element itself)
+        if (p.bias) ev.add = *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.vec) {
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(p.vec + (size_t)vrow * p.vec_ld + n);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ev.add[c] += vv[c];
+        }
+        if (p.post_scale) { ev.ps = *reinterpret_cast<const f32x4*>(p.post_scale + n); ev.pt = *reinterpret_cast<const f32x4*>(p.post_shift + n); }
+    }
+    return ev;
+}
+
 template <int TD>
-__device__ __forceinline__ void epilogue_cq(const ConvArgs& p, f32x4v (&e)[4][4], const Brick& br, const int zs, float* gn = nullptr) {
+__device__ __forceinline__ void epilogue_cq(const ConvArgs& p, f32x4v (&e)[4][4], const Brick& br, const int zs, const EpiVecs& ev, const int vrow, float* gn = nullptr) {
     constexpr int NT = 64;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));                       // (lane constants made here, not alive — spilled — across the caller's main loop)
     const int lane = tid & 63, j4 = (lane & 15) * 4, xp = (lane >> 4) ^ (lane >> 5);       // (accumulator row group g holds x-pair g ^ (g >> 1): the Winograd kernel's fragment order)
     const int n0 = br.ntile * NT, n = n0 + j4;           // this lane's first channel
-    const int vrow = p.vec ? (p.vec_idx ? p.vec_idx[br.b] : br.b) : 0;
     const size_t zbase = (((size_t)br.b * p.fd + br.oz0 + zs) * p.fh) * p.fw * p.cout;
     float* const outz = p.out + zbase;
     const float* const resz = p.res ? p.res + zbase : nullptr;
@@ -547,15 +570,7 @@ __device__ __forceinline__ void epilogue_cq(const ConvArgs& p, f32x4v (&e)[4][4]
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rv[t][r] = *reinterpret_cast<const f32x4*>(resz + voff(t, r));
         }
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, one = {1.f, 1.f, 1.f, 1.f};
-        f32x4 add = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : zero;
-        if (p.vec) {
-            const f32x4 vv = *reinterpret_cast<const f32x4*>(p.vec + (size_t)vrow * p.vec_ld + n);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) add[c] += vv[c];
-        }
-        const f32x4 ps = p.post_scale ? *reinterpret_cast<const f32x4*>(p.post_scale + n) : one;
-        const f32x4 pt = p.post_scale ? *reinterpret_cast<const f32x4*>(p.post_shift + n) : zero;
+        const f32x4 add = ev.add, ps = ev.ps, pt = ev.pt;
         const int h2off = (n >> 4) * 64 + ((n >> 3) & 1) * 16 + (n & 7) * 2 - n * 4;       // DM3D_FMT_H2 position of channels n .. n + 3 inside their voxel's row
         auto tiles = [&](auto POST_T, auto H2_T, auto GN_T) {
             constexpr bool POST = decltype(POST_T)::value, H2 = decltype(H2_T)::value, GN = decltype(GN_T)::value;

@@ -146,6 +146,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
         return it;
     };
     Item cur = decode(item);
+    // the item's row of the epilogue's vector operand (dm3d_conv_desc.vec_idx[b]): a scalar load issued here, a whole chunk loop before its
+    // use — read inside the epilogue it headed a chain of two dependent misses (index, then the row) in front of the first tile
+    auto vec_row = [&](const Item& it) { return p.vec ? (p.vec_idx ? p.vec_idx[it.b] : it.b) : 0; };
+    int vrow_s = vec_row(cur);
     int c_lo = cur.khalf * cpp, c_hi = c_lo + cpp;
     STAMP(0);
 
@@ -815,6 +819,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
         }
         if (finish) {
             float gn[8];                        // fused GroupNormalization statistics of the output (ConvArgs.gn_stats): this lane's four channels over both slices
+            const EpiVecs ev = epilogue_cq_vecs(p, br, vrow_s);
 #pragma unroll
             for (int i = 0; i < 8; ++i) gn[i] = 0.0f;
             static_for<2>([&](auto S_) {
@@ -825,7 +830,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
                 slice_tiles(S_, e);
                 if (p.ksplit > 1) split_gather(stile, p, cur.khalf, e, 16 * s);
 #ifndef DM3D_EXP_NO_EPILOGUE                    // (timing-only A/B arm, tools/mk_variant_conv.sh: what hiding the whole epilogue could buy at most)
-                epilogue_cq<TD>(p, e, br, 2 * wave + s, p.gn_stats ? gn : nullptr);
+                epilogue_cq<TD>(p, e, br, 2 * wave + s, ev, vrow_s, p.gn_stats ? gn : nullptr);
 #else
                 if (e[0][0][0] == 12345.678f) p.out[0] = e[1][1][1] + e[2][2][2] + e[3][3][3];
 #endif
@@ -848,6 +853,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_h3w(const ConvArgs p) {
                 }
         item += item_step;
         cur = decode(item);
+        vrow_s = vec_row(cur);
         c_lo = cur.khalf * cpp; c_hi = c_lo + cpp;
         has_next = item + item_step < item_end;
     }
