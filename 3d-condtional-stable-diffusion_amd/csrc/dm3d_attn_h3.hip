@@ -142,7 +142,11 @@ __global__ __launch_bounds__(256, 1) void attn_fused_h3(const AttnArgs p) {
     for (int t = 0; t < ntiles; ++t) {
         // tile t has landed (every wave waits for its own DMAs, then all meet); everyone is past tile t-1, whose buffer tile t+1 now takes
         if (t < 8) ASTAMP(t * 8 + 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (the builtin, not inline asm: hipcc's wait-count pass must SEE that nothing is in flight here.  With an asm wait it still counted
+        // the query-row loads of the kernel's head as possibly pending at the loop head and guarded every qh[s] / ql[s] with vmcnt(32 - 2s) ..
+        // vmcnt(0) — waits that in every later tile drain the next tile's DMA pieces just issued: the score phase took 3 700 cycles for
+        // 1 536 of MFMA, tools/attn_stamps.py.)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0), expcnt 7, lgkmcnt 15
         __syncthreads();
         if (t < 8) ASTAMP(t * 8 + 1);
         const bool more = t + 1 < ntiles;
@@ -158,10 +162,15 @@ __global__ __launch_bounds__(256, 1) void attn_fused_h3(const AttnArgs p) {
         f32x16 sacc, sacc1, sacc2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sacc[r] = 0.0f; sacc1[r] = 0.0f; sacc2[r] = 0.0f; }
+        // (the K fragments of step s + 1 are requested in front of step s's MFMAs: left to hipcc, each pair was read right in front of its
+        // first use and the LDS round trip — nothing else to run on this SIMD — stood between every two steps)
+        h8 kh = *reinterpret_cast<const h8*>(lds_k + k_hi), kl = *reinterpret_cast<const h8*>(lds_k + (k_hi ^ 16));
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const h8 kh = *reinterpret_cast<const h8*>(lds_k + k_hi + s * (KT * REC));
-            const h8 kl = *reinterpret_cast<const h8*>(lds_k + (k_hi ^ 16) + s * (KT * REC));
+            const int sn = s < 15 ? s + 1 : 15;
+            const h8 kh_n = *reinterpret_cast<const h8*>(lds_k + k_hi + sn * (KT * REC));
+            const h8 kl_n = *reinterpret_cast<const h8*>(lds_k + (k_hi ^ 16) + sn * (KT * REC));
+            __builtin_amdgcn_sched_barrier(0);
             sacc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sacc1, 0, 0, 0);
             sacc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sacc2, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc, 0, 0, 0);
@@ -170,11 +179,23 @@ __global__ __launch_bounds__(256, 1) void attn_fused_h3(const AttnArgs p) {
                 fetch_part(nkey0, nbuf, s >> 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            kh = kh_n; kl = kl_n;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] += sacc1[r] + sacc2[r];        // small terms first
         if (t < 8) ASTAMP(t * 8 + 3);
 
+        // The V^T fragments run one MFMA pass ahead of their use: the lo set of the tile's first k-step (keys 0-15) is requested HERE, in
+        // front of the softmax arithmetic, every later set while the pass before its first use runs (each register right behind the last
+        // MFMA that reads it).  Requested where they are used, 16 reads and their round trip stood in front of each k-step's 24 MFMAs with
+        // nothing else to issue on this SIMD (P.V phase 2 600 cycles for 1 536 of MFMA, tools/attn_stamps.py).  (Both sets of the first
+        // k-step in front of the softmax: 35 spilled registers.)
+        h8 vh[8], vl[8];
+        auto v_read_h = [&](const int j, const int mt) { vh[mt] = *reinterpret_cast<const h8*>(lds_v + v_hi + (j * AC + mt * 32) * REC); };
+        auto v_read_l = [&](const int j, const int mt) { vl[mt] = *reinterpret_cast<const h8*>(lds_v + (v_hi ^ 16) + (j * AC + mt * 32) * REC); };
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) v_read_l(0, mt);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- online softmax of column l32 (its 32 keys of this tile sit in lanes l32 and l32 + 32, 16 registers each)
         float mloc = -INFINITY;
 #pragma unroll
@@ -204,36 +225,62 @@ __global__ __launch_bounds__(256, 1) void attn_fused_h3(const AttnArgs p) {
 
         if (t < 8) ASTAMP(t * 8 + 4);
         // ---- O^T += V^T P^T: the B operand of k-step j is registers 8j..8j+7 of the probabilities, split in place
+        h8 ph[2], pl[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            h8 ph, pl;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float pv = sacc[8 * j + e];
                 const _Float16 hi = (_Float16)pv;
-                ph[e] = hi;
-                pl[e] = (_Float16)(pv - (float)hi);
+                ph[j][e] = hi;
+                pl[j][e] = (_Float16)(pv - (float)hi);
             }
-            // pass-major over the 8 channel tiles: consecutive MFMAs write different accumulators
-            h8 vh[8], vl[8];
+        __builtin_amdgcn_sched_barrier(0);
+        // pass-major over the 8 channel tiles: consecutive MFMAs write different accumulators
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) {
-                vh[mt] = *reinterpret_cast<const h8*>(lds_v + v_hi + (j * AC + mt * 32) * REC);
-                vl[mt] = *reinterpret_cast<const h8*>(lds_v + (v_hi ^ 16) + (j * AC + mt * 32) * REC);
-            }
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt) oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[mt], ph, oacc[mt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt) oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[mt], pl, oacc[mt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt) oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[mt], ph, oacc[mt], 0, 0, 0);
+        for (int mt = 0; mt < 8; ++mt) {
+            oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[mt], ph[0], oacc[mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            v_read_h(0, mt);
+            __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[mt], pl[0], oacc[mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            v_read_l(1, mt);                                  // (the lo fragment's last reader issued a pass ago)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[mt], ph[0], oacc[mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            v_read_h(1, mt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[mt], ph[1], oacc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[mt], pl[1], oacc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[mt], ph[1], oacc[mt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (t < 8) ASTAMP(t * 8 + 5);
     }
     ASTAMP(120);
 
-    // ---- epilogue: O = O^T^T / row sum (+ res), through LDS so that the stores are whole rows
+    // ---- epilogue: O = O^T^T / row sum (+ res), through LDS so that the stores are whole rows.  All 32 residual pieces of this lane are
+    // requested FIRST, in front of the transposition (the query-row registers are dead): as a load under `if (res)` inside the store loop
+    // every iteration waited vmcnt(0) — for its own load and, the counter being one for loads and stores, for the previous iteration's
+    // store to complete: 21-25 thousand cycles of a 155-thousand-cycle workgroup (tools/attn_stamps.py).
+    const size_t row0 = (size_t)b * lq + q0 + wave * 32;
+    f32x4 rr[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int idx = lane + i * 64;                                  // 32 rows x 64 float4
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        rr[i] = ps.res ? *reinterpret_cast<const f32x4*>(ps.res + (row0 + (idx >> 6)) * ps.ldo + (idx & 63) * 4) : zero;
+    }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     __syncthreads();                                                    // the K / V images are dead: the float32 image overlays them
@@ -245,16 +292,12 @@ __global__ __launch_bounds__(256, 1) void attn_fused_h3(const AttnArgs p) {
             lds_o[l32 * O_LD + mt * 32 + dm3d_acc_row(r, half)] = oacc[mt][r] * inv;
     __builtin_amdgcn_s_waitcnt(0xC07F);                                 // lgkmcnt(0): this wave's own image is complete (no other wave reads it)
     __builtin_amdgcn_wave_barrier();
-    const size_t row0 = (size_t)b * lq + q0 + wave * 32;
-#pragma unroll 4
+#pragma unroll
     for (int i = 0; i < 32; ++i) {
-        const int idx = lane + i * 64;                                  // 32 rows x 64 float4
+        const int idx = lane + i * 64;
         const int qr = idx >> 6, c4 = idx & 63;
         f32x4 v = *reinterpret_cast<const f32x4*>(lds_o + qr * O_LD + c4 * 4);
-        if (ps.res) {
-            const f32x4 rr = *reinterpret_cast<const f32x4*>(ps.res + (row0 + qr) * ps.ldo + c4 * 4);
-            v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3];
-        }
+        if (ps.res) { v[0] += rr[i][0]; v[1] += rr[i][1]; v[2] += rr[i][2]; v[3] += rr[i][3]; }
         *reinterpret_cast<f32x4*>(ps.out + (row0 + qr) * ps.ldo + c4 * 4) = v;
     }
     ASTAMP(121);

@@ -848,7 +848,8 @@ class Plan:
         self._keep += [g1, b1, g2, b2, g3, b3]
         # proj_in + the three LayerNormalizations + the q|k, v^T, q2 projections as ONE launch (dm3d_attn_front, round 4): y, n1, n2 stay on the
         # CU.  Same shape rule as the fused MLP (u = 256, enough 64-row tiles to fill the chip); otherwise the three launches below.
-        front = (u == 256 and M % 64 == 0 and M >= 64 * 128 and all(getattr(w, "ftiled", None) is not None for w in (pin, qk, val))
+        min_rows = int(os.environ.get("DM3D_FUSED_MIN_ROWS", str(64 * 128)))
+        front = (u == 256 and M % 64 == 0 and M >= min_rows and all(getattr(w, "ftiled", None) is not None for w in (pin, qk, val))
                  and os.environ.get("DM3D_ATTN_FRONT", "1") != "0")
         n3 = self._buf(M, u)
         if front:
@@ -876,7 +877,7 @@ class Plan:
                                                         n3.data_ptr()), "layernorm", {}))
         # the MLP (Dense(4u, relu) -> Dense(u), :132-133) as ONE launch with the hidden activation in LDS (dm3d_mlp_fused, round 4) where the
         # kernel's shape fits (u = 256 and enough row tiles to fill the chip); otherwise its first Dense joins the grouped launch below
-        mlp_fused = u == 256 and M >= 64 * 128 and getattr(m0, "tiled", None) is not None and os.environ.get("DM3D_MLP_FUSED", "1") != "0"
+        mlp_fused = u == 256 and M % 64 == 0 and M >= min_rows and getattr(m0, "tiled", None) is not None and os.environ.get("DM3D_MLP_FUSED", "1") != "0"
         hid = None if mlp_fused else self._buf(M, 4 * u)
         group = []
         if not front:
