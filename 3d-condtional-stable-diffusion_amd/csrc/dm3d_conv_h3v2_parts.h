@@ -94,14 +94,18 @@ __device__ __forceinline__ void skip_phase(const ConvArgs& p, _Float16* smem, f3
             }
         };
         constexpr int WS = 8 / TD;                                         // 1 KB DMA pieces per wave and pair
-        const char* sw_img = reinterpret_cast<const char*>(p.swpk) + (size_t)ntile * p.s_npairs * (2 * NT * REC * 2) + wave * 1024 + lane * 16;
+        // (buffer form of the LDS-DMA, as the main loop's weights: a FLAT-encoded global_load_lds in flight makes hipcc's wait-count pass treat
+        // both counters as out of order and guard every load / LDS-read result with a wait for zero)
+        const auto sw_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(p.swpk)), (short)0, (int)((long)(p.coutpad / NT) * p.s_npairs * (2 * NT * REC * 2)), 0x00020000);
+        const int sw_voff = wave * 1024 + lane * 16, wave_u = __builtin_amdgcn_readfirstlane(wave);
+        const unsigned sw_tile = (unsigned)__builtin_amdgcn_readfirstlane(ntile * p.s_npairs * (2 * NT * REC * 2));
         auto sdma = [&](int pp, int buf) {                                 // 8 KB per pair (past the end: the last pair again)
-            const char* src = sw_img + (size_t)(pp < np ? pp : np - 1) * (2 * NT * REC * 2);
-            char* dst = reinterpret_cast<char*>(lds_sw) + buf * (2 * NT * REC * 2) + wave * 1024;
+            const unsigned off = sw_tile + (unsigned)__builtin_amdgcn_readfirstlane((pp < np ? pp : np - 1) * (2 * NT * REC * 2));
+            char* dst = reinterpret_cast<char*>(lds_sw) + __builtin_amdgcn_readfirstlane(buf) * (2 * NT * REC * 2) + wave_u * 1024;
 #pragma unroll
             for (int i = 0; i < WS; ++i)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * (TD * 1024)),
-                                                 (__attribute__((address_space(3))) void*)(dst + i * (TD * 1024)), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(sw_rsrc, (__attribute__((address_space(3))) void*)(dst + i * (TD * 1024)), 16, sw_voff,
+                                                         (int)(off + i * (TD * 1024)), 0, 0);
         };
         const int sa_rec = (wave * TH + (row & 3)) * HWP + dx_of_row(row) + half * SREC;
         const int sb_hi = b_hi;                                            // same [2 taps][NT][REC] row layout as a main weight pair

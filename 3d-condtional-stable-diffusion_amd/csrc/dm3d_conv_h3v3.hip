@@ -156,15 +156,25 @@ __global__ __launch_bounds__(TD * 64, 2) void conv3d_igemm_h3v3(const ConvArgs p
 
     // weights go global -> LDS by LDS-DMA: the packed image IS the LDS image, pair pq of this (column tile) is a linear 8 KB copy; wave w
     // moves the 1 KB pieces w, w + TD.  Ring slot = running pair number mod 4 (NP mod 4 = 2 for k3: the phase differs from chunk to chunk).
-    const char* w_img = reinterpret_cast<const char*>(wbase + (size_t)ntile * p.nchunks * NP * WPAIR) + wave * 1024 + lane * 16;
+    // Buffer form of the LDS-DMA (as in dm3d_conv_h3w.hip): the image's descriptor in scalar registers, ONE constant 32-bit lane offset, the
+    // pair as a scalar byte offset.  The flat form (global_load_lds with a 64-bit lane address) is a FLAT-encoded instruction to hipcc's
+    // wait-count pass: with one pending it treats the vector-memory counter as out of order and turns every wait of its own for a plain
+    // load's result into vmcnt(0) — in the 4-pair parity form, whose staging slots are converted one pair behind their request, that put a
+    // vmcnt(0) in front of the kernel's own counted wait in every chunk, draining the weight ring (isa listing of <2, 0, 4, 4>, round 5).
+    const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(wbase), (short)0, (int)((long)ntiles * p.nchunks * (NP * WPAIR * 2)), 0x00020000);
+    const int w_voff = wave * 1024 + lane * 16;
+    // (uniform values that hipcc computed on the vector unit — the divisions of the work assignment — go through readfirstlane: the scalar
+    // offset and M0 must be scalar registers, and for a value it cannot prove uniform hipcc builds a waterfall loop around the instruction)
+    const unsigned w_tile = (unsigned)__builtin_amdgcn_readfirstlane((ntile * p.nchunks) * (NP * WPAIR * 2));      // byte offset of this column tile's pairs
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int pq_end = c_hi * NP;
     auto fetch_w = [&](int pq, int slot) {              // unconditional (past the end the last pair is fetched again): hipcc can count what is in flight
-        const char* src = w_img + (size_t)(pq < pq_end ? pq : pq_end - 1) * (WPAIR * 2);
-        char* dst = reinterpret_cast<char*>(lds_w) + slot * (WPAIR * 2) + wave * 1024;
+        const unsigned off = w_tile + (unsigned)__builtin_amdgcn_readfirstlane((pq < pq_end ? pq : pq_end - 1) * (WPAIR * 2));
+        char* dst = reinterpret_cast<char*>(lds_w) + __builtin_amdgcn_readfirstlane(slot) * (WPAIR * 2) + wave_u * 1024;
 #pragma unroll
         for (int i = 0; i < WSLOT; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * (TD * 1024)),
-                                             (__attribute__((address_space(3))) void*)(dst + i * (TD * 1024)), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(dst + i * (TD * 1024)), 16, w_voff,
+                                                     (int)(off + i * (TD * 1024)), 0, 0);
     };
     int pq = c_lo * NP;                                  // running pair number of the pair being multiplied
     int ws = 0;                                          // its ring slot
