@@ -159,3 +159,29 @@ def test_cin_split_hand_over_keeps_the_fused_output_forms(dev, monkeypatch):
     s = gn.double().sum(1)
     want = torch.stack([y2.double().sum((1, 2, 3)), (y2.double() ** 2).sum((1, 2, 3))], -1)
     assert float((s - want).abs().max() / want.abs().max()) < 1e-5
+
+
+def test_fused_attention_block_kernels_below_their_row_threshold(dev, monkeypatch):
+    """DM3D_FUSED_MIN_ROWS (round 5): dm3d_attn_front / dm3d_mlp_fused take over from the grouped GEMM launches from n rows (B x tokens) up;
+    the default (8192) is the measured break-even, smaller values are slower but must compute the same eps: B = 2 (1024 rows per block,
+    32-row tiles of the front kernel, 16 workgroups of the MLP kernel) with the threshold at 512 against the default plan."""
+    import dm3d_amd
+    from dm3d_amd.unet import UNet
+    cfg = dm3d_amd.UNetConfig(img_size=32, img_channels=8)
+    W = dm3d_amd.synthetic_weights(cfg, seed=5)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 32, 32, 32, 8, generator=g).to(dev)
+    t = torch.tensor([700, 3])
+    ctx = torch.ones(2, 1, 1, dtype=torch.int64)
+    monkeypatch.delenv("DM3D_FUSED_MIN_ROWS", raising=False)
+    ref_net = UNet(cfg, weights=W)
+    ref = ref_net([x, t, ctx]).clone()
+    kinds_ref = {op[2] for op in ref_net.plan(2, 1000, False).ops}
+    monkeypatch.setenv("DM3D_FUSED_MIN_ROWS", "512")
+    net = UNet(cfg, weights=W)
+    out = net([x, t, ctx]).clone()
+    kinds = {op[2] for op in net.plan(2, 1000, False).ops}
+    torch.cuda.synchronize()
+    assert "attn_front" in kinds and "mlp_fused" in kinds and "attn_front" not in kinds_ref
+    assert torch.isfinite(out).all()
+    assert float((out - ref).abs().max() / ref.abs().max()) < 2e-5
